@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (nils-werner/pymf).
+
+Runs only in the build container, where /root/reference is mounted.  The
+reference is Python 2; it is imported UNMODIFIED through a shim:
+  * builtins.xrange = range                       (nmf.py:182)
+  * a synthetic empty package 'pymf' whose __path__ points at the reference so
+    pymf/__init__.py (which imports cvxopt via nmfals.py:19) is never executed
+  * for nmfnnls: module-level eager `map` (Py2 semantics, nmfnnls.py:73,80)
+Only inputs (or their seeds) and outputs are written: tests/golden/*.npz.
+"""
+import builtins
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("PYMF_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference():
+    builtins.xrange = range
+    pkg = types.ModuleType("pymf")
+    pkg.__path__ = [os.path.join(REF, "pymf")]
+    sys.modules["pymf"] = pkg
+    mods = {}
+    for name in ("nmf", "snmf", "nmfnnls"):
+        mods[name] = importlib.import_module("pymf." + name)
+    mods["nmfnnls"].map = lambda f, *a: list(builtins.map(f, *a))
+    return mods
+
+
+def run_case(cls, V, k, niter, seed, cast32, flags=None, w0=None, h0=None):
+    """Run reference class; returns dict of arrays."""
+    np.random.seed(seed)
+    m, n = V.shape
+    W0 = np.random.random((m, k)) if w0 is None else w0
+    H0 = np.random.random((k, n)) if h0 is None else h0
+    if cast32:
+        W0 = W0.astype(np.float32)
+        H0 = H0.astype(np.float32)
+    mdl = cls(V, num_bases=k)
+    mdl.W = W0.copy()
+    mdl.H = H0.copy()
+    flags = flags or {}
+    mdl.factorize(niter=niter, **flags)
+    out = dict(W0=W0, H0=H0, W=np.asarray(mdl.W), H=np.asarray(mdl.H))
+    if hasattr(mdl, "ferr"):
+        out["ferr"] = np.asarray(mdl.ferr, dtype=np.float64)
+    return out
+
+
+def main():
+    mods = load_reference()
+    NMF, SNMF, NNLS = mods["nmf"].NMF, mods["snmf"].SNMF, mods["nmfnnls"].NMFNNLS
+    cases = {}
+
+    def add(name, cls, V, vdesc, k, niter, seed, cast32, **kw):
+        r = run_case(cls, V, k, niter, seed, cast32, **kw)
+        r.update(vdesc)
+        r["k"] = np.int64(k)
+        r["niter"] = np.int64(niter)
+        r["seed"] = np.int64(seed)
+        cases[name] = r
+
+    # (i) BASELINE cfg1: 100x50, k=4, niter=50; float64-default init and fp32 init
+    V1 = np.random.RandomState(20260101).random_sample((100, 50)).astype(np.float32)
+    d1 = dict(V=V1)
+    for cname, cls in (("nmf", NMF), ("snmf", SNMF)):
+        add(cname + "_cfg1_f64", cls, V1, d1, 4, 50, 42, False)
+        add(cname + "_cfg1_f32", cls, V1, d1, 4, 50, 42, True)
+    # (ii) 512x128, k=16, 10 iterations, fp32
+    V2 = np.random.RandomState(7).random_sample((512, 128)).astype(np.float32)
+    for cname, cls in (("nmf", NMF), ("snmf", SNMF)):
+        add(cname + "_512x128_k16", cls, V2, dict(V=V2), 16, 10, 42, True)
+    # (iii) shrunken analogues of cfg2/cfg4 (V stored by seed only)
+    for (m, n, k, it, tag) in ((2048, 256, 64, 8, "cfg4s"), (1024, 512, 32, 8, "cfg2s"),
+                               (384, 128, 128, 6, "cfg5s_dense")):
+        Vs = np.random.RandomState(1234).random_sample((m, n)).astype(np.float32)
+        desc = dict(V_seed=np.int64(1234), V_shape=np.array([m, n], dtype=np.int64))
+        add("nmf_" + tag, NMF, Vs, desc, k, it, 42, True)
+        add("snmf_" + tag, SNMF, Vs, desc, k, it, 42, True)
+    # sparse-like data densified (cfg5 analogue: ~1% nnz)
+    rs = np.random.RandomState(99)
+    Vsp = (rs.random_sample((768, 128)) < 0.01) * rs.random_sample((768, 128))
+    Vsp = Vsp.astype(np.float32)
+    add("snmf_sparse1pct", SNMF, Vsp, dict(V=Vsp), 16, 6, 42, True)
+    # ragged / odd shapes (padding paths)
+    V3 = np.random.RandomState(5).random_sample((37, 29)).astype(np.float32)
+    add("nmf_37x29_k5", NMF, V3, dict(V=V3), 5, 12, 3, False)
+    add("snmf_37x29_k5", SNMF, V3, dict(V=V3), 5, 12, 3, False)
+    # (vi) the reference test's own data: tests/test_pymf.py:32-33,69,77
+    np.random.seed(400401)
+    A = np.random.random((3, 50)) + 2.0
+    add("nmf_reftest", NMF, A, dict(V=A), 4, 20, 11, False)
+    add("snmf_reftest", SNMF, A, dict(V=A), 4, 20, 11, False)
+    # (iv) flag variants + repeated calls (tests/test_pymf.py:92-95)
+    np.random.seed(21)
+    mdl = NMF(V1, num_bases=4)
+    mdl.factorize(niter=5)
+    seq = dict(V=V1, W0=None)
+    w_a, h_a, f_a = mdl.W.copy(), mdl.H.copy(), mdl.ferr.copy()
+    mdl.factorize(niter=5, compute_h=False)
+    w_b, h_b, f_b = mdl.W.copy(), mdl.H.copy(), mdl.ferr.copy()
+    mdl.factorize(niter=5, compute_w=False)
+    w_c, h_c, f_c = mdl.W.copy(), mdl.H.copy(), mdl.ferr.copy()
+    mdl.factorize(niter=5, compute_err=False)
+    w_d, h_d, f_d = mdl.W.copy(), mdl.H.copy(), mdl.ferr.copy()
+    cases["nmf_flagseq"] = dict(V=V1, seed=np.int64(21), k=np.int64(4),
+                                W_a=w_a, H_a=h_a, ferr_a=f_a, W_b=w_b, H_b=h_b, ferr_b=f_b,
+                                W_c=w_c, H_c=h_c, ferr_c=f_c, W_d=w_d, H_d=h_d, ferr_d=f_d)
+    # (v) early exit: exact data, compute_w=False -> len(ferr)==2 (nmf.py:198-202)
+    Vx = np.array([[1.0, 0.0, 2.0, 1.0, 0.5], [0.0, 1.0, 1.0, 3.0, 0.25]])
+    mdl = NMF(Vx, num_bases=2)
+    mdl.W = np.array([[1.0, 0.0], [0.0, 1.0]])
+    np.random.seed(1)
+    mdl.H = np.random.random((2, 5))
+    H0x = mdl.H.copy()
+    mdl.factorize(niter=20, compute_w=False)
+    cases["nmf_earlyexit"] = dict(V=Vx, W0=np.eye(2), H0=H0x, W=mdl.W, H=mdl.H,
+                                  ferr=mdl.ferr, k=np.int64(2), niter=np.int64(20))
+    # NMFALS proxy: the reference's NNLS sibling minimises the same objective
+    V4 = np.random.RandomState(8).random_sample((24, 18)).astype(np.float64)
+    add("nnls_24x18_k4", NNLS, V4, dict(V=V4), 4, 5, 9, False)
+    np.random.seed(400401)
+    A = np.random.random((3, 50)) + 2.0
+    add("nnls_reftest", NNLS, A, dict(V=A), 4, 10, 11, False)
+
+    for name, d in cases.items():
+        d = {k: v for k, v in d.items() if v is not None}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        f = d.get("ferr")
+        print("%-24s ferr[-1]=%s len=%s" % (name, None if f is None else "%.9f" % f[-1],
+                                             None if f is None else len(f)))
+
+
+if __name__ == "__main__":
+    main()
