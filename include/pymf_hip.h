@@ -1,0 +1,129 @@
+/*
+ * pymf_hip.h -- C ABI of libpymf_hip.so: the MI355X (gfx950) implementation of the
+ * iterative factorize() hot path of nils-werner/pymf (NMF / NMFALS / SNMF).
+ *
+ * Plain C, no C++ or torch types.  One pmf_ctx drives ONE GPU from one host
+ * thread (thread-compatible, not thread-safe); multi-GPU = one process (ctx)
+ * per GPU, rows of V/W sharded, RCCL all-reduce inside pmf_update_h /
+ * pmf_factorize.  The caller owns every host buffer; the library owns all
+ * device memory, its HIP stream and its RCCL communicator.
+ *
+ * Reference interface each entry point replaces (paths into nils-werner/pymf):
+ *   pmf_ctx_create        NMF.__init__                 pymf/nmf.py:71-97
+ *   pmf_set_v_*           self.data (aliased ndarray)  pymf/nmf.py:93,123,129 (data[:,:])
+ *   pmf_set_w/h, get_w/h  self.W / self.H attributes   pymf/nmf.py:116-120,173-177
+ *   pmf_update_w          NMF.update_w                 pymf/nmf.py:128-132
+ *                         SNMF.update_w                pymf/snmf.py:67-70
+ *                         NMFALS.update_w              pymf/nmfals.py:85-97
+ *   pmf_update_h          NMF.update_h                 pymf/nmf.py:122-126
+ *                         SNMF.update_h                pymf/snmf.py:72-91
+ *                         NMFALS.update_h              pymf/nmfals.py:70-82
+ *   pmf_frobenius         NMF.frobenius_norm           pymf/nmf.py:100-114
+ *   pmf_factorize         NMF.factorize loop body      pymf/nmf.py:182-202
+ *                         (incl. NMF.converged         pymf/nmf.py:134-139)
+ *
+ * Every function returns PMF_OK (0) or a negative status and never throws;
+ * pmf_last_error() gives a human-readable message for the last failure.
+ */
+#ifndef PYMF_HIP_H
+#define PYMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pmf_ctx pmf_ctx;
+
+enum {
+  PMF_OK = 0,
+  PMF_EINVAL = -1,   /* bad argument / unsupported shape / call order */
+  PMF_EHIP = -2,     /* a HIP runtime call failed */
+  PMF_ENCCL = -3,    /* an RCCL call failed */
+  PMF_ENOMEM = -4    /* device or host allocation failed */
+};
+
+enum { PMF_ALGO_NMF = 0, PMF_ALGO_NMFALS = 1, PMF_ALGO_SNMF = 2 };
+
+/* pmf_factorize flags (the reference's factorize() keyword arguments, nmf.py:141-142) */
+enum { PMF_COMPUTE_W = 1u, PMF_COMPUTE_H = 2u, PMF_COMPUTE_ERR = 4u };
+
+#define PMF_NCCL_ID_BYTES 128
+
+/* Number of visible HIP devices. */
+int pmf_device_count(int32_t* out);
+
+/* Fill out[PMF_NCCL_ID_BYTES] with a fresh RCCL unique id (call on rank 0, hand the
+ * bytes to every rank by any means, then pass them to pmf_ctx_create). */
+int pmf_nccl_unique_id(void* out);
+
+/*
+ * Create a context on HIP device `device`.
+ *   algo      PMF_ALGO_*
+ *   m_local   rows of V (= rows of W) held by THIS rank (the whole matrix when nranks==1)
+ *   n         columns of V (= columns of H), identical on all ranks
+ *   k         num_bases
+ *   rank,nranks,nccl_id   RCCL world; nranks==1 -> nccl_id may be NULL and RCCL is not touched
+ */
+int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int32_t k,
+                   int32_t device, int32_t rank, int32_t nranks, const void* nccl_id);
+int pmf_ctx_destroy(pmf_ctx* ctx);
+const char* pmf_last_error(const pmf_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* V: host row-major m_local x n float32 with leading dimension ld (elements). Copied. */
+int pmf_set_v_dense_f32(pmf_ctx* ctx, const float* V, int64_t ld);
+/* V as CSR (m_local rows): indptr[m_local+1] int64, indices[nnz] int32, vals[nnz] f32. */
+int pmf_set_v_csr_f32(pmf_ctx* ctx, const int64_t* indptr, const int32_t* indices,
+                      const float* vals, int64_t nnz);
+/* Fill V on the device with the bench's synthetic U[0,1) stream (counter-based, so
+ * the values depend only on (seed, global row, column)); row0 = first global row. */
+int pmf_fill_v_uniform(pmf_ctx* ctx, uint64_t seed, int64_t row0);
+
+/* W: m_local x k row-major (ld = k).  H: k x n row-major (ld = n). Host buffers. */
+int pmf_set_w_f32(pmf_ctx* ctx, const float* W);
+int pmf_get_w_f32(pmf_ctx* ctx, float* W);
+int pmf_set_h_f32(pmf_ctx* ctx, const float* H);
+int pmf_get_h_f32(pmf_ctx* ctx, float* H);
+int pmf_fill_w_uniform(pmf_ctx* ctx, uint64_t seed, int64_t row0);
+int pmf_fill_h_uniform(pmf_ctx* ctx, uint64_t seed);
+
+/* One hook each (blocking until done on the device). */
+int pmf_update_w(pmf_ctx* ctx);
+int pmf_update_h(pmf_ctx* ctx);
+int pmf_frobenius(pmf_ctx* ctx, double* out);   /* sqrt(sum((V - W H)^2)), all ranks' rows */
+
+/*
+ * The factorize() loop: for i in [0,niter): [update_w] [update_h] [ferr[i] = frobenius]
+ * and, when PMF_COMPUTE_ERR and i > 1, stop if |ferr[i]-ferr[i-1]|/n < conv_eps
+ * (nmf.py:134-139,198-202).  On convergence at iteration i, *converged_at = i
+ * (the caller truncates ferr to ferr[:i] as the reference does) else -1.
+ * *iters_done = number of loop bodies executed.  ferr may be NULL without PMF_COMPUTE_ERR.
+ * Blocks until the device loop has finished.
+ */
+int pmf_factorize(pmf_ctx* ctx, int32_t niter, uint32_t flags, double conv_eps,
+                  double* ferr, int32_t* iters_done, int32_t* converged_at);
+
+/* Device time (ms, HIP events on the library's stream) of the last pmf_factorize loop. */
+int pmf_last_loop_ms(pmf_ctx* ctx, double* ms);
+
+/*
+ * Per-kernel timing for bench.py's roofline: when enabled, every launch of the
+ * dominant kernel of the current algo is bracketed by HIP events on the
+ * library's stream.  pmf_kernel_stats returns the kernel's name, launch count
+ * and mean duration since the last reset.
+ */
+int pmf_profile_enable(pmf_ctx* ctx, int32_t on);
+int pmf_kernel_stats(pmf_ctx* ctx, const char** name, int64_t* launches, double* mean_ms,
+                     double* flops_per_launch, double* bytes_per_launch);
+
+int pmf_synchronize(pmf_ctx* ctx);
+
+/* Introspection used by tests: which code path update_w/update_h take for this shape.
+ * Returns a static string such as "fused_k64_n256" or "tiled". */
+const char* pmf_path_name(const pmf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYMF_HIP_H */

@@ -1,0 +1,220 @@
+"""ctypes binding of libpymf_hip.so (C ABI in include/pymf_hip.h).
+
+The shared library is built in-tree by pymf_amd/csrc/build.py (hipcc,
+--offload-arch=gfx950).  There is no CPU fallback: if the library is missing or
+cannot be loaded, every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpymf_hip.so")
+
+PMF_OK = 0
+ALGO_NMF, ALGO_NMFALS, ALGO_SNMF = 0, 1, 2
+COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
+NCCL_ID_BYTES = 128
+
+# every symbol include/pymf_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_ctx = _c.c_void_p
+_fp = _c.POINTER(_c.c_float)
+SYMBOLS = [
+    ("pmf_device_count", _c.c_int, [_c.POINTER(_c.c_int32)]),
+    ("pmf_nccl_unique_id", _c.c_int, [_c.c_void_p]),
+    ("pmf_ctx_create", _c.c_int, [_c.POINTER(_ctx), _c.c_int32, _c.c_int64, _c.c_int64, _c.c_int32,
+                                  _c.c_int32, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    ("pmf_ctx_destroy", _c.c_int, [_ctx]),
+    ("pmf_last_error", _c.c_char_p, [_ctx]),
+    ("pmf_set_v_dense_f32", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64]),
+    ("pmf_set_v_csr_f32", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64]),
+    ("pmf_fill_v_uniform", _c.c_int, [_ctx, _c.c_uint64, _c.c_int64]),
+    ("pmf_set_w_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_get_w_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_set_h_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_get_h_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_fill_w_uniform", _c.c_int, [_ctx, _c.c_uint64, _c.c_int64]),
+    ("pmf_fill_h_uniform", _c.c_int, [_ctx, _c.c_uint64]),
+    ("pmf_update_w", _c.c_int, [_ctx]),
+    ("pmf_update_h", _c.c_int, [_ctx]),
+    ("pmf_frobenius", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
+    ("pmf_factorize", _c.c_int, [_ctx, _c.c_int32, _c.c_uint32, _c.c_double, _c.c_void_p,
+                                 _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32)]),
+    ("pmf_last_loop_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
+    ("pmf_profile_enable", _c.c_int, [_ctx, _c.c_int32]),
+    ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
+                                    _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
+                                    _c.POINTER(_c.c_double)]),
+    ("pmf_synchronize", _c.c_int, [_ctx]),
+    ("pmf_path_name", _c.c_char_p, [_ctx]),
+]
+
+_lib = None
+
+
+class PmfError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libpymf_hip.so and bind every declared symbol.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PmfError("libpymf_hip.so not built: run `python -m pymf_amd.csrc.build` "
+                       "(hipcc, gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != PMF_OK:
+        msg = load().pmf_last_error(ctx)
+        raise PmfError("libpymf_hip error %d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))
+
+
+def device_count():
+    n = ctypes.c_int32(0)
+    rc = load().pmf_device_count(ctypes.byref(n))
+    if rc != PMF_OK:
+        return 0
+    return int(n.value)
+
+
+def nccl_unique_id():
+    buf = ctypes.create_string_buffer(NCCL_ID_BYTES)
+    check(load().pmf_nccl_unique_id(buf))
+    return buf.raw
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context(object):
+    """Thin owner of one pmf_ctx*."""
+
+    def __init__(self, algo, m_local, n, k, device=0, rank=0, nranks=1, nccl_id=None):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(nccl_id, NCCL_ID_BYTES) if nccl_id else None
+        check(self._lib.pmf_ctx_create(ctypes.byref(self._h), algo, m_local, n, k, device, rank,
+                                       nranks, idbuf))
+        self.m, self.n, self.k = int(m_local), int(n), int(k)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pmf_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        check(rc, self._h)
+
+    @property
+    def path_name(self):
+        return self._lib.pmf_path_name(self._h).decode()
+
+    def set_v_dense(self, V):
+        V = np.asarray(V)
+        if V.dtype != np.float32 or not V.flags.c_contiguous:
+            V = _f32c(V)
+        assert V.shape == (self.m, self.n)
+        self._chk(self._lib.pmf_set_v_dense_f32(self._h, V.ctypes.data, V.shape[1]))
+
+    def set_v_csr(self, indptr, indices, vals):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        vals = _f32c(vals)
+        assert indptr.shape[0] == self.m + 1
+        self._chk(self._lib.pmf_set_v_csr_f32(self._h, indptr.ctypes.data, indices.ctypes.data,
+                                              vals.ctypes.data, int(vals.shape[0])))
+
+    def fill_v_uniform(self, seed, row0=0):
+        self._chk(self._lib.pmf_fill_v_uniform(self._h, seed, row0))
+
+    def fill_w_uniform(self, seed, row0=0):
+        self._chk(self._lib.pmf_fill_w_uniform(self._h, seed, row0))
+
+    def fill_h_uniform(self, seed):
+        self._chk(self._lib.pmf_fill_h_uniform(self._h, seed))
+
+    def set_w(self, W):
+        W = _f32c(W)
+        assert W.shape == (self.m, self.k)
+        self._chk(self._lib.pmf_set_w_f32(self._h, W.ctypes.data))
+
+    def set_h(self, H):
+        H = _f32c(H)
+        assert H.shape == (self.k, self.n)
+        self._chk(self._lib.pmf_set_h_f32(self._h, H.ctypes.data))
+
+    def get_w(self):
+        W = np.empty((self.m, self.k), dtype=np.float32)
+        self._chk(self._lib.pmf_get_w_f32(self._h, W.ctypes.data))
+        return W
+
+    def get_h(self):
+        H = np.empty((self.k, self.n), dtype=np.float32)
+        self._chk(self._lib.pmf_get_h_f32(self._h, H.ctypes.data))
+        return H
+
+    def update_w(self):
+        self._chk(self._lib.pmf_update_w(self._h))
+
+    def update_h(self):
+        self._chk(self._lib.pmf_update_h(self._h))
+
+    def frobenius(self):
+        out = ctypes.c_double(0.0)
+        self._chk(self._lib.pmf_frobenius(self._h, ctypes.byref(out)))
+        return float(out.value)
+
+    def factorize(self, niter, compute_w=True, compute_h=True, compute_err=True, conv_eps=1e-8):
+        """Returns (ferr ndarray or None, iters_done, converged_at)."""
+        flags = (COMPUTE_W if compute_w else 0) | (COMPUTE_H if compute_h else 0) | \
+                (COMPUTE_ERR if compute_err else 0)
+        ferr = np.zeros(max(int(niter), 1), dtype=np.float64) if compute_err else None
+        done = ctypes.c_int32(0)
+        conv = ctypes.c_int32(-1)
+        self._chk(self._lib.pmf_factorize(self._h, int(niter), flags, float(conv_eps),
+                                          ferr.ctypes.data if compute_err else None,
+                                          ctypes.byref(done), ctypes.byref(conv)))
+        if compute_err:
+            ferr = ferr[:int(niter)]
+        return ferr, int(done.value), int(conv.value)
+
+    def last_loop_ms(self):
+        ms = ctypes.c_double(0.0)
+        self._chk(self._lib.pmf_last_loop_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        self._chk(self._lib.pmf_profile_enable(self._h, 1 if on else 0))
+
+    def kernel_stats(self):
+        name = ctypes.c_char_p()
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0.0)
+        fl = ctypes.c_double(0.0)
+        by = ctypes.c_double(0.0)
+        self._chk(self._lib.pmf_kernel_stats(self._h, ctypes.byref(name), ctypes.byref(n),
+                                             ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        return dict(name=(name.value or b"").decode(), launches=int(n.value), mean_ms=float(ms.value),
+                    flops_per_launch=float(fl.value), bytes_per_launch=float(by.value))
+
+    def synchronize(self):
+        self._chk(self._lib.pmf_synchronize(self._h))

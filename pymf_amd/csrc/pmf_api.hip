@@ -1,0 +1,656 @@
+// pmf_api.hip -- host side of libpymf_hip.so: the C ABI declared in include/pymf_hip.h.
+//
+// One pmf_ctx = one GPU, one HIP stream, optionally one RCCL communicator.
+// Device layout (all float32, zero padded, row-major):
+//   V  [mp][np]   mp = m rounded up to 64, np = n rounded up to 64
+//   W  [mp][KP]   KP = 16*NT, NT in {1,2,4,8} (k <= 128)
+//   H  [KP][np]
+//   G  [KP][KP]   H H^T          PS [KP][np+KP]  (W^T V | W^T W)
+// Zero padding is exactly neutral for all three update rules (a padded W column
+// or H row/column stays 0 through every multiplicative step; SNMF/NMFALS put 1 on
+// the padded diagonal of the k x k systems).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pymf_hip.h"
+#include "pmf_dev.h"
+#include "pmf_small.h"
+#include "pmf_tiled.h"
+#include "pmf_fused.h"
+#include "pmf_nnls.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct KernelStat {
+  const char* name = "none";
+  double flops = 0.0, bytes = 0.0;
+  std::vector<hipEvent_t> ev;   // pairs
+  size_t used = 0;              // events recorded since reset
+};
+
+}  // namespace
+
+struct pmf_ctx {
+  int algo = 0;
+  int64_t m = 0, n = 0;
+  int k = 0, device = 0, rank = 0, nranks = 1;
+  int64_t mp = 0;
+  int np = 0, KP = 0, NT = 0;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float *dV = nullptr, *dW = nullptr, *dH = nullptr, *dG = nullptr, *dPS = nullptr;
+  float *dSlab = nullptr, *dW1 = nullptr, *dGinvT = nullptr;
+  double *dGd = nullptr, *dPart = nullptr, *dScal = nullptr;
+  // CSR V (SNMF sparse path)
+  int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
+  bool v_csr = false;
+  int nchunks = 0, rows_per_chunk = 0;
+  int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
+  bool have_v = false, have_w = false, have_h = false, g_valid = false;
+  bool profile = false;
+  double last_loop_ms = 0.0;
+  KernelStat stat;
+  std::string err;
+  std::string path;
+};
+
+namespace {
+
+int fail(pmf_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((c), e_ == hipErrorOutOfMemory ? PMF_ENOMEM : PMF_EHIP,                 \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+
+#define NCCLCHK(c, expr)                                                                  \
+  do {                                                                                    \
+    ncclResult_t r_ = (expr);                                                             \
+    if (r_ != ncclSuccess)                                                                \
+      return fail((c), PMF_ENCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));    \
+  } while (0)
+
+#define PMFCHK(expr)                 \
+  do {                               \
+    int rc_ = (expr);                \
+    if (rc_ != PMF_OK) return rc_;   \
+  } while (0)
+
+int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+int csr_ps(pmf_ctx* c) { return fail(c, PMF_EINVAL, "CSR path not built yet"); }
+int csr_vht(pmf_ctx* c) { return fail(c, PMF_EINVAL, "CSR path not built yet"); }
+
+template <typename T>
+int dalloc(pmf_ctx* c, T** p, size_t count) {
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+  HIPCHK(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
+  return PMF_OK;
+}
+
+// ---- profiling of the dominant kernel -------------------------------------------------
+void stat_begin(pmf_ctx* c) {
+  if (!c->profile) return;
+  KernelStat& s = c->stat;
+  if (s.used + 2 > s.ev.size()) {
+    for (int q = 0; q < 2; ++q) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      s.ev.push_back(e);
+    }
+  }
+  hipEventRecord(s.ev[s.used], c->stream);
+}
+void stat_end(pmf_ctx* c) {
+  if (!c->profile) return;
+  KernelStat& s = c->stat;
+  if (s.used + 2 > s.ev.size()) return;
+  hipEventRecord(s.ev[s.used + 1], c->stream);
+  s.used += 2;
+}
+
+// ---- kernel launch helpers --------------------------------------------------------------
+template <int NT, int EPI>
+int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
+                   float* W, const float* G, float* C) {
+  const size_t smem = rowgemm_smem_bytes<NT>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowgemm<NT, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)(c->mp / 64)), dim3(256), smem, c->stream,
+                     A, lda, kdimA, B, ldb, W, G, C);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+template <int EPI>
+int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
+            float* W, const float* G, float* C) {
+  switch (c->NT) {
+    case 1: return launch_rowgemm<1, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
+    case 2: return launch_rowgemm<2, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
+    case 4: return launch_rowgemm<4, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
+    case 8: return launch_rowgemm<8, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
+  }
+  return fail(c, PMF_EINVAL, "bad NT");
+}
+
+int colgemm(pmf_ctx* c) {
+  dim3 grid((unsigned)c->nchunks, (unsigned)((c->np + 255) / 256));
+  switch (c->NT) {
+    case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 8: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    default: return fail(c, PMF_EINVAL, "bad NT");
+  }
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int64_t ps_elems(const pmf_ctx* c) { return (int64_t)c->KP * (c->np + c->KP); }
+
+int reduce_slabs(pmf_ctx* c, int nslabs) {
+  const int64_t E = ps_elems(c);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream,
+                     c->dSlab, nslabs, E, c->dPS);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int allreduce_ps(pmf_ctx* c) {
+  if (c->nranks > 1)
+    NCCLCHK(c, ncclAllReduce(c->dPS, c->dPS, (size_t)ps_elems(c), ncclFloat, ncclSum, c->comm, c->stream));
+  return PMF_OK;
+}
+
+int ensure_gram(pmf_ctx* c, double pad_diag) {
+  if (c->g_valid) return PMF_OK;
+  dim3 grid((unsigned)(c->KP / 16), (unsigned)(c->KP / 16));
+  hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k,
+                     pad_diag, c->dG, c->dGd);
+  HIPCHK(c, hipGetLastError());
+  c->g_valid = true;
+  return PMF_OK;
+}
+
+int need(pmf_ctx* c, bool v, bool w, bool h) {
+  if (!c) return PMF_EINVAL;
+  if (v && !c->have_v) return fail(c, PMF_EINVAL, "V has not been set (pmf_set_v_*)");
+  if (w && !c->have_w) return fail(c, PMF_EINVAL, "W has not been set (pmf_set_w_f32)");
+  if (h && !c->have_h) return fail(c, PMF_EINVAL, "H has not been set (pmf_set_h_f32)");
+  HIPCHK(c, hipSetDevice(c->device));
+  return PMF_OK;
+}
+
+// ---- NMF (multiplicative update) ---------------------------------------------------------
+int nmf_update_w(pmf_ctx* c) {
+  PMFCHK(ensure_gram(c, 0.0));
+  return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
+}
+
+int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
+  PMFCHK(allreduce_ps(c));
+  const size_t smem = (size_t)c->KP * 16 * sizeof(float);
+  if (c->algo == PMF_ALGO_SNMF)
+    hipLaunchKernelGGL(k_snmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
+                       (int64_t)c->np, c->np, c->KP, c->dPS);
+  else
+    hipLaunchKernelGGL(k_nmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
+                       (int64_t)c->np, c->np, c->KP, c->dPS);
+  HIPCHK(c, hipGetLastError());
+  c->g_valid = false;
+  return PMF_OK;
+}
+
+int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
+  if (c->v_csr) return csr_ps(c);
+  PMFCHK(colgemm(c));
+  return reduce_slabs(c, c->nchunks);
+}
+
+int nmf_update_h(pmf_ctx* c) {
+  PMFCHK(ps_tiled(c));
+  return h_step_from_ps(c);
+}
+
+// One pass over V doing update_w AND the partials for update_h (pmf_fused.h).
+int nmf_fused_iteration(pmf_ctx* c) {
+  PMFCHK(ensure_gram(c, 0.0));
+  stat_begin(c);
+  PMFCHK(launch_fused(c->stream, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab));
+  stat_end(c);
+  HIPCHK(c, hipGetLastError());
+  PMFCHK(reduce_slabs(c, c->fused_wgs));
+  return h_step_from_ps(c);
+}
+
+// ---- SNMF -----------------------------------------------------------------------------------
+int snmf_update_w(pmf_ctx* c) {
+  PMFCHK(ensure_gram(c, 1.0));
+  const size_t smem = ((size_t)c->k * c->k) * sizeof(double) + ((size_t)c->k + 1) * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_inverse, dim3(1), dim3(256), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
+  HIPCHK(c, hipGetLastError());
+  if (c->v_csr) PMFCHK(csr_vht(c));
+  else PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
+  return rowgemm<EPI_STORE>(c, c->dW1, c->KP, c->KP, c->dGinvT, c->KP, nullptr, nullptr, c->dW);
+}
+
+int snmf_update_h(pmf_ctx* c) {
+  PMFCHK(ps_tiled(c));
+  return h_step_from_ps(c);
+}
+
+// ---- NMFALS ---------------------------------------------------------------------------------
+int als_update_w(pmf_ctx* c) {
+  // HA = H H^T (nmfals.py:93), -FA = V H^T (nmfals.py:88), one QP per row (nmfals.py:89-90)
+  PMFCHK(ensure_gram(c, 1.0));
+  PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
+  stat_begin(c);
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, c->KP, 1, c->dW, c->KP, 1, c->mp);
+  stat_end(c);
+  if (rc != PMF_OK) return fail(c, rc, "nnqp launch (W) failed");
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int als_update_h(pmf_ctx* c) {
+  // HA = W^T W (nmfals.py:78), -FA = W^T V (nmfals.py:73), one QP per column (nmfals.py:74-75)
+  PMFCHK(ps_tiled(c));
+  PMFCHK(allreduce_ps(c));
+  const int64_t ldp = (int64_t)c->np + c->KP;
+  hipLaunchKernelGGL(k_hessian_from_ps, dim3((unsigned)((c->KP * c->KP + 255) / 256)), dim3(256), 0,
+                     c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
+  HIPCHK(c, hipGetLastError());
+  // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, 1, ldp, c->dH, 1, c->np, c->np);
+  if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
+  HIPCHK(c, hipGetLastError());
+  c->g_valid = false;
+  return PMF_OK;
+}
+
+int do_update_w(pmf_ctx* c) {
+  switch (c->algo) {
+    case PMF_ALGO_NMF: return nmf_update_w(c);
+    case PMF_ALGO_SNMF: return snmf_update_w(c);
+    case PMF_ALGO_NMFALS: return als_update_w(c);
+  }
+  return fail(c, PMF_EINVAL, "bad algo");
+}
+
+int do_update_h(pmf_ctx* c) {
+  switch (c->algo) {
+    case PMF_ALGO_NMF: return nmf_update_h(c);
+    case PMF_ALGO_SNMF: return snmf_update_h(c);
+    case PMF_ALGO_NMFALS: return als_update_h(c);
+  }
+  return fail(c, PMF_EINVAL, "bad algo");
+}
+
+int do_frobenius(pmf_ctx* c, double* out) {
+  if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
+  const int nb = (int)(c->mp / 64);
+  switch (c->NT) {
+    case 1: hipLaunchKernelGGL((k_resid<1>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
+    case 2: hipLaunchKernelGGL((k_resid<2>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
+    case 4: hipLaunchKernelGGL((k_resid<4>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
+    case 8: hipLaunchKernelGGL((k_resid<8>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+  HIPCHK(c, hipGetLastError());
+  if (c->nranks > 1)
+    NCCLCHK(c, ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  double ss = 0.0;
+  HIPCHK(c, hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = std::sqrt(ss);
+  return PMF_OK;
+}
+
+int upload_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64_t sld, int64_t rows,
+                  int64_t cols) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dld * sizeof(float), src, (size_t)sld * sizeof(float),
+                             (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+
+int download_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64_t sld, int64_t rows,
+                    int64_t cols) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dld * sizeof(float), src, (size_t)sld * sizeof(float),
+                             (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+
+void set_stat_model(pmf_ctx* c) {
+  // Algorithmic flops / bytes of ONE launch of the dominant kernel on THIS rank's rows
+  // (SURVEY.md section 8(d)): the fused kernel does the four m-sized contractions of an
+  // iteration in one pass over V: F = 4 m n k + 4 m k^2, B = 4 (m n + 2 m k).
+  const double m = (double)c->m, n = (double)c->n, k = (double)c->k;
+  if (c->algo == PMF_ALGO_NMF && c->fused_wgs > 0) {
+    c->stat.name = fused_kernel_name(c->NT, c->np);
+    c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;
+    c->stat.bytes = 4.0 * (m * n + 2.0 * m * k);
+  } else if (c->algo == PMF_ALGO_NMFALS) {
+    c->stat.name = "k_nnqp(update_w)";
+    c->stat.flops = 0.0;
+    c->stat.bytes = 4.0 * (2.0 * m * k);
+  }
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int pmf_device_count(int32_t* out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); *out = 0; return PMF_EHIP; }
+  *out = n;
+  return PMF_OK;
+}
+
+int pmf_nccl_unique_id(void* out) {
+  static_assert(sizeof(ncclUniqueId) == PMF_NCCL_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = ncclGetErrorString(r); return PMF_ENCCL; }
+  std::memcpy(out, &id, sizeof(id));
+  return PMF_OK;
+}
+
+int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int32_t k, int32_t device,
+                   int32_t rank, int32_t nranks, const void* nccl_id) {
+  if (!out) return fail(nullptr, PMF_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (algo < 0 || algo > 2) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS) or 2 (SNMF)");
+  if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
+  if (k > 128) return fail(nullptr, PMF_EINVAL, "num_bases > 128 is not supported by this build");
+  if (n > (1 << 24)) return fail(nullptr, PMF_EINVAL, "n too large");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, PMF_EINVAL, "bad rank/nranks");
+  if (nranks > 1 && !nccl_id) return fail(nullptr, PMF_EINVAL, "nccl_id required when nranks > 1");
+  pmf_ctx* c = new (std::nothrow) pmf_ctx();
+  if (!c) return fail(nullptr, PMF_ENOMEM, "host allocation failed");
+  c->algo = algo; c->m = m_local; c->n = n; c->k = k; c->device = device; c->rank = rank; c->nranks = nranks;
+  c->mp = round_up(m_local, 64);
+  c->np = (int)round_up(n, 64);
+  c->NT = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+  c->KP = 16 * c->NT;
+  int rc = [&]() -> int {
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    if (nranks > 1) {
+      ncclUniqueId id;
+      std::memcpy(&id, nccl_id, sizeof(id));
+      NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    }
+    // partial-slab geometry for the tiled W^T V path: ~1024 row chunks over the grid
+    const int n_panels = (c->np + 255) / 256;
+    int want = std::max(1, 1024 / n_panels);
+    int64_t blocks16 = c->mp / 16;
+    c->nchunks = (int)std::min<int64_t>(want, blocks16);
+    c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
+    c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
+    c->fused_wgs = (algo == PMF_ALGO_NMF) ? fused_grid_for(c->NT, c->np, c->mp) : 0;
+    const int nslabs = std::max(c->nchunks, c->fused_wgs);
+    PMFCHK(dalloc(c, &c->dV, (size_t)c->mp * c->np));
+    PMFCHK(dalloc(c, &c->dW, (size_t)c->mp * c->KP));
+    PMFCHK(dalloc(c, &c->dH, (size_t)c->KP * c->np));
+    PMFCHK(dalloc(c, &c->dG, (size_t)c->KP * c->KP));
+    PMFCHK(dalloc(c, &c->dGd, (size_t)c->KP * c->KP));
+    PMFCHK(dalloc(c, &c->dPS, (size_t)ps_elems(c)));
+    PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
+    PMFCHK(dalloc(c, &c->dPart, (size_t)(c->mp / 64)));
+    PMFCHK(dalloc(c, &c->dScal, 8));
+    if (algo != PMF_ALGO_NMF) {
+      PMFCHK(dalloc(c, &c->dW1, (size_t)c->mp * c->KP));
+      PMFCHK(dalloc(c, &c->dGinvT, (size_t)c->KP * c->KP));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  }();
+  if (rc != PMF_OK) {
+    g_create_error = c->err;
+    pmf_ctx_destroy(c);
+    return rc;
+  }
+  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np)) : std::string("tiled");
+  set_stat_model(c);
+  *out = c;
+  return PMF_OK;
+}
+
+int pmf_ctx_destroy(pmf_ctx* c) {
+  if (!c) return PMF_OK;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  for (void* p : {(void*)c->dV, (void*)c->dW, (void*)c->dH, (void*)c->dG, (void*)c->dPS, (void*)c->dSlab,
+                  (void*)c->dW1, (void*)c->dGinvT, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
+                  (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
+    if (p) hipFree(p);
+  for (hipEvent_t e : c->stat.ev) hipEventDestroy(e);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return PMF_OK;
+}
+
+const char* pmf_last_error(const pmf_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+const char* pmf_path_name(const pmf_ctx* c) { return c ? c->path.c_str() : ""; }
+
+int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
+  if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f32: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
+  c->have_v = true; c->v_csr = false;
+  return PMF_OK;
+}
+
+int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices, const float* vals,
+                      int64_t nnz) {
+  if (!c || !indptr || (nnz > 0 && (!indices || !vals)) || nnz < 0)
+    return fail(c, PMF_EINVAL, "pmf_set_v_csr_f32: bad arguments");
+  if (c->algo != PMF_ALGO_SNMF) return fail(c, PMF_EINVAL, "CSR input is only wired for SNMF");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (void* p : {(void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals}) if (p) hipFree(p);
+  c->dIndptr = nullptr; c->dIndices = nullptr; c->dVals = nullptr;
+  PMFCHK(dalloc(c, &c->dIndptr, (size_t)c->mp + 1));
+  PMFCHK(dalloc(c, &c->dIndices, (size_t)nnz));
+  PMFCHK(dalloc(c, &c->dVals, (size_t)nnz));
+  std::vector<int64_t> ip((size_t)c->mp + 1);
+  for (int64_t r = 0; r <= c->mp; ++r) ip[(size_t)r] = indptr[std::min(r, c->m)];
+  HIPCHK(c, hipMemcpyAsync(c->dIndptr, ip.data(), ip.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  if (nnz) {
+    HIPCHK(c, hipMemcpyAsync(c->dIndices, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dVals, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->nnz = nnz; c->have_v = true; c->v_csr = true;
+  return PMF_OK;
+}
+
+static int fill(pmf_ctx* c, float* X, int64_t ld, int64_t rows, int64_t cols, int64_t row0, uint64_t seed) {
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t E = rows * cols;
+  hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, X, ld,
+                     rows, cols, row0, cols, seed);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+
+int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
+  if (!c) return PMF_EINVAL;
+  PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
+  c->have_v = true; c->v_csr = false;
+  return PMF_OK;
+}
+int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
+  if (!c) return PMF_EINVAL;
+  PMFCHK(fill(c, c->dW, c->KP, c->m, c->k, row0, seed));
+  c->have_w = true;
+  return PMF_OK;
+}
+int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
+  if (!c) return PMF_EINVAL;
+  PMFCHK(fill(c, c->dH, c->np, c->k, c->n, 0, seed));
+  c->have_h = true; c->g_valid = false;
+  return PMF_OK;
+}
+
+int pmf_set_w_f32(pmf_ctx* c, const float* W) {
+  if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f32: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(upload_padded(c, c->dW, c->KP, W, c->k, c->m, c->k));
+  c->have_w = true;
+  return PMF_OK;
+}
+int pmf_get_w_f32(pmf_ctx* c, float* W) {
+  PMFCHK(need(c, false, true, false));
+  if (!W) return fail(c, PMF_EINVAL, "W is NULL");
+  return download_padded(c, W, c->k, c->dW, c->KP, c->m, c->k);
+}
+int pmf_set_h_f32(pmf_ctx* c, const float* H) {
+  if (!c || !H) return fail(c, PMF_EINVAL, "pmf_set_h_f32: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
+  c->have_h = true; c->g_valid = false;
+  return PMF_OK;
+}
+int pmf_get_h_f32(pmf_ctx* c, float* H) {
+  PMFCHK(need(c, false, false, true));
+  if (!H) return fail(c, PMF_EINVAL, "H is NULL");
+  return download_padded(c, H, c->n, c->dH, c->np, c->k, c->n);
+}
+
+int pmf_update_w(pmf_ctx* c) {
+  PMFCHK(need(c, true, true, true));
+  PMFCHK(do_update_w(c));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+int pmf_update_h(pmf_ctx* c) {
+  PMFCHK(need(c, true, true, true));
+  PMFCHK(do_update_h(c));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+int pmf_frobenius(pmf_ctx* c, double* out) {
+  PMFCHK(need(c, true, true, true));
+  if (!out) return fail(c, PMF_EINVAL, "out is NULL");
+  return do_frobenius(c, out);
+}
+
+int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, double* ferr,
+                  int32_t* iters_done, int32_t* converged_at) {
+  PMFCHK(need(c, true, true, true));
+  const bool cw = flags & PMF_COMPUTE_W, ch = flags & PMF_COMPUTE_H, ce = flags & PMF_COMPUTE_ERR;
+  if (niter < 0 || (ce && !ferr)) return fail(c, PMF_EINVAL, "pmf_factorize: bad arguments");
+  if (iters_done) *iters_done = 0;
+  if (converged_at) *converged_at = -1;
+  const bool fused = cw && ch && c->algo == PMF_ALGO_NMF && c->fused_wgs > 0;
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  int done = 0;
+  for (int i = 0; i < niter; ++i) {                       // nmf.py:182
+    if (fused) {
+      PMFCHK(nmf_fused_iteration(c));                     // update_w + update_h, one pass over V
+    } else {
+      if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184
+      if (ch) PMFCHK(do_update_h(c));                     // nmf.py:186-187
+    }
+    ++done;
+    if (ce) {
+      PMFCHK(do_frobenius(c, &ferr[i]));                  // nmf.py:189-190
+      if (i > 1) {                                        // nmf.py:198
+        const double derr = std::fabs(ferr[i] - ferr[i - 1]) / (double)c->n;   // nmf.py:135
+        if (derr < conv_eps) {                            // nmf.py:136
+          if (converged_at) *converged_at = i;            // caller: ferr = ferr[:i] (nmf.py:201)
+          break;
+        }
+      }
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->last_loop_ms = ms;
+  if (iters_done) *iters_done = done;
+  return PMF_OK;
+}
+
+int pmf_last_loop_ms(pmf_ctx* c, double* ms) {
+  if (!c || !ms) return PMF_EINVAL;
+  *ms = c->last_loop_ms;
+  return PMF_OK;
+}
+
+int pmf_profile_enable(pmf_ctx* c, int32_t on) {
+  if (!c) return PMF_EINVAL;
+  c->profile = on != 0;
+  c->stat.used = 0;
+  return PMF_OK;
+}
+
+int pmf_kernel_stats(pmf_ctx* c, const char** name, int64_t* launches, double* mean_ms,
+                     double* flops_per_launch, double* bytes_per_launch) {
+  if (!c) return PMF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double tot = 0.0;
+  const size_t pairs = c->stat.used / 2;
+  for (size_t q = 0; q < pairs; ++q) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->stat.ev[2 * q], c->stat.ev[2 * q + 1]));
+    tot += ms;
+  }
+  if (name) *name = c->stat.name;
+  if (launches) *launches = (int64_t)pairs;
+  if (mean_ms) *mean_ms = pairs ? tot / (double)pairs : 0.0;
+  if (flops_per_launch) *flops_per_launch = c->stat.flops;
+  if (bytes_per_launch) *bytes_per_launch = c->stat.bytes;
+  return PMF_OK;
+}
+
+int pmf_synchronize(pmf_ctx* c) {
+  if (!c) return PMF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// pmf_small.h -- the k x k / k x n sized kernels around the two big contractions.
+#pragma once
+#include "pmf_dev.h"
+
+// G = H H^T (KP x KP, contraction over np columns), float64 accumulation.
+// grid = (KP/16, KP/16), block = 256: thread (a = tid>>4, b = tid&15) of tile (bx, by).
+// Gf: float32 copy (MFMA operand), Gd: float64 copy (SNMF inverse, NMFALS Hessian).
+// Rows/cols >= k (padding) get `pad_diag` on the diagonal and 0 elsewhere.
+__global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64_t ldh, int np,
+                                              int KP, int k, double pad_diag,
+                                              float* __restrict__ Gf, double* __restrict__ Gd) {
+  __shared__ float ha[16][65];
+  __shared__ float hb[16][65];
+  const int tid = threadIdx.x;
+  const int a = tid >> 4, b = tid & 15;
+  const int ra = blockIdx.x * 16, rb = blockIdx.y * 16;
+  double acc = 0.0;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    for (int q = tid; q < 16 * 64; q += 256) {
+      const int r = q >> 6, c = q & 63;
+      ha[r][c] = H[(int64_t)(ra + r) * ldh + c0 + c];
+      hb[r][c] = H[(int64_t)(rb + r) * ldh + c0 + c];
+    }
+    __syncthreads();
+    float s = 0.f;   // 64-term f32 chain per panel, panels summed in f64
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) s = fmaf(ha[a][c], hb[b][c], s);
+    acc += (double)s;
+    __syncthreads();
+  }
+  const int ga = ra + a, gb = rb + b;
+  if (ga >= k || gb >= k) acc = (ga == gb) ? pad_diag : 0.0;
+  Gf[(int64_t)ga * KP + gb] = (float)acc;
+  if (Gd) Gd[(int64_t)ga * KP + gb] = acc;
+}
+
+// NMF H step (pymf/nmf.py:122-126): H <- (H * P) / (S H + 1e-9), P = W^T V, S = W^T W.
+// PS: [KP][np + KP] (P | S).  One block per 16 columns of H; in place.
+__global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ldh, int np, int KP,
+                                               const float* __restrict__ PS) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
+  const int tid = threadIdx.x;
+  const int c = tid & 15;
+  const int col = blockIdx.x * 16 + c;
+  const int64_t ldp = (int64_t)np + KP;
+  for (int kk = tid >> 4; kk < KP; kk += 16) hs[kk * 16 + c] = H[(int64_t)kk * ldh + col];
+  __syncthreads();
+  for (int kk = tid >> 4; kk < KP; kk += 16) {
+    const float* srow = PS + (int64_t)kk * ldp + np;
+    float den = 0.f;
+    for (int j = 0; j < KP; ++j) den = fmaf(srow[j], hs[j * 16 + c], den);
+    const float h = hs[kk * 16 + c];
+    const float p = PS[(int64_t)kk * ldp + col];
+    H[(int64_t)kk * ldh + col] = (h * p) / (den + PMF_EPS_DEN);
+  }
+}
+
+// SNMF H step (pymf/snmf.py:72-91) with XW = P^T (P = W^T V) and WW = S = W^T W:
+//   H1 = pos(XW)^T + (H^T neg(WW))^T,  H2 = neg(XW)^T + (H^T pos(WW))^T + 1e-9,
+//   H *= sqrt(H1 / H2).
+__global__ __launch_bounds__(256) void k_snmf_h(float* __restrict__ H, int64_t ldh, int np, int KP,
+                                                const float* __restrict__ PS) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
+  const int tid = threadIdx.x;
+  const int c = tid & 15;
+  const int col = blockIdx.x * 16 + c;
+  const int64_t ldp = (int64_t)np + KP;
+  for (int kk = tid >> 4; kk < KP; kk += 16) hs[kk * 16 + c] = H[(int64_t)kk * ldh + col];
+  __syncthreads();
+  for (int kk = tid >> 4; kk < KP; kk += 16) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int j = 0; j < KP; ++j) {
+      const float ww = PS[(int64_t)j * ldp + np + kk];     // WW[j][kk]
+      const float hj = hs[j * 16 + c];
+      const float wp = (fabsf(ww) + ww) * 0.5f;            // snmf.py:73-74
+      const float wn = (fabsf(ww) - ww) * 0.5f;            // snmf.py:76-77
+      a1 = fmaf(hj, wn, a1);
+      a2 = fmaf(hj, wp, a2);
+    }
+    const float xw = PS[(int64_t)kk * ldp + col];
+    const float h1 = (fabsf(xw) + xw) * 0.5f + a1;
+    const float h2 = (fabsf(xw) - xw) * 0.5f + a2 + PMF_EPS_DEN;
+    H[(int64_t)kk * ldh + col] *= sqrtf(h1 / h2);
+  }
+}
+
+// In-place float64 Gauss-Jordan inverse with partial pivoting of the leading k x k
+// block of Gd (ld = KP), staged in LDS; writes float32 inv(G)^T into GinvT[KP][KP]
+// (identity on the padding) so that k_rowgemm's B[n][k] operand reads inv[k][n].
+// One block of 256 threads.  Mirrors np.linalg.inv (snmf.py:70) semantics: no
+// singularity handling beyond what LAPACK's getrf/getri would do.
+__global__ __launch_bounds__(256) void k_inverse(const double* __restrict__ Gd, int KP, int k,
+                                                 float* __restrict__ GinvT) {
+  extern __shared__ __attribute__((aligned(16))) double a[];   // [k][k] + int piv[k+1]
+  int* ipiv = reinterpret_cast<int*>(a + (size_t)k * k);
+  int& s_piv = ipiv[k];
+  const int tid = threadIdx.x;
+  for (int q = tid; q < k * k; q += 256) a[q] = Gd[(int64_t)(q / k) * KP + (q % k)];
+  __syncthreads();
+  for (int p = 0; p < k; ++p) {
+    if (tid < 64) {   // wave 0: argmax |a[r][p]|, r >= p
+      double best = -1.0;
+      int bi = p;
+      for (int r = p + tid; r < k; r += 64) {
+        const double v = fabs(a[r * k + p]);
+        if (v > best) { best = v; bi = r; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (tid == 0) { s_piv = bi; ipiv[p] = bi; }
+    }
+    __syncthreads();
+    const int piv = s_piv;
+    if (piv != p)
+      for (int j = tid; j < k; j += 256) {
+        const double t = a[p * k + j]; a[p * k + j] = a[piv * k + j]; a[piv * k + j] = t;
+      }
+    __syncthreads();
+    const double d = 1.0 / a[p * k + p];
+    __syncthreads();
+    if (tid == 0) a[p * k + p] = 1.0;
+    __syncthreads();
+    for (int j = tid; j < k; j += 256) a[p * k + j] *= d;
+    __syncthreads();
+    // eliminate column p from every other row
+    for (int q = tid; q < k * k; q += 256) {
+      const int r = q / k, j = q % k;
+      if (r == p) continue;
+      const double f = a[r * k + p];
+      if (j != p) a[q] -= f * a[p * k + j];
+    }
+    __syncthreads();
+    for (int r = tid; r < k; r += 256)
+      if (r != p) a[r * k + p] = -a[r * k + p] * a[p * k + p];
+    __syncthreads();
+  }
+  for (int p = k - 1; p >= 0; --p) {   // undo the row swaps as column swaps
+    const int piv = ipiv[p];
+    if (piv != p)
+      for (int r = tid; r < k; r += 256) {
+        const double t = a[r * k + p]; a[r * k + p] = a[r * k + piv]; a[r * k + piv] = t;
+      }
+    __syncthreads();
+  }
+  for (int q = tid; q < KP * KP; q += 256) {
+    const int r = q / KP, c = q % KP;   // GinvT[r][c] = inv[c][r]
+    float v = (r == c) ? 1.f : 0.f;
+    if (r < k && c < k) v = (float)a[c * k + r];
+    GinvT[q] = v;
+  }
+}
+
+// sum of part[0..n) in float64, fixed order; out[0] = sum.
+__global__ void k_sum_f64(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double ws[4];
+  double s = 0.0;
+  for (int q = threadIdx.x; q < n; q += 256) s += part[q];
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// Synthetic U[0,1) fill of the logical rows x cols block of a padded [.,ld] buffer.
+__global__ void k_fill_uniform(float* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
+                               int64_t row0, int64_t cols_global, uint64_t seed) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int64_t r = e / cols, c = e % cols;
+  X[r * ld + c] = u01_from(seed, (uint64_t)((row0 + r) * cols_global + c));
+}

@@ -1,0 +1,263 @@
+// pmf_tiled.h -- general-shape MFMA kernels (any padded m, n; k padded to 16*NT).
+//
+// These serve every shape the fused one-pass kernel (pmf_fused.h) does not take,
+// and the single-hook calls update_w()/update_h() of the reference's plugin API.
+//
+//   k_rowgemm<NT,EPI>  C[64-row block][KP] = A[rows][K] * B[KP][K]^T  (+ epilogue)
+//       EPI_NMF_W : Num = V H^T, Den = W G (G = H H^T), W <- (W*Num)/(Den+1e-9)
+//                   pymf/nmf.py:128-132 with (W H) H^T reassociated to W (H H^T)
+//       EPI_STORE : C = A B^T            (SNMF V H^T and W1 inv(HH^T), snmf.py:68-70;
+//                                          NMFALS V H^T, nmfals.py:88)
+//   k_colgemm<NT>      per row-chunk partials of P = W^T V (KP x n) and S = W^T W
+//                      (pymf/nmf.py:124-125; snmf.py:79,81; nmfals.py:73,78)
+//   k_resid<NT>        sum((V - W H)^2) partials (pymf/nmf.py:110)
+#pragma once
+#include "pmf_dev.h"
+
+enum { EPI_STORE = 0, EPI_NMF_W = 1 };
+
+// A [R][64] f32 panel travelling global -> registers -> swizzled LDS, 256 threads.
+template <int R>
+struct PanelStage {
+  static constexpr int CH = (R * 16) / 256 > 0 ? (R * 16) / 256 : 1;
+  f32x4 r[CH];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int col0,
+                                       int kdim, int tid) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int id = tid + 256 * q;
+      const int row = id >> 4, c = id & 15;
+      const int col = col0 + 4 * c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < R && col < kdim) v = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld + col);
+      r[q] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int id = tid + 256 * q;
+      const int row = id >> 4, c = id & 15;
+      if (row < R) lds_write4(lds, row, c, r[q]);
+    }
+  }
+};
+
+// acc[nt] (+)= A_tile[64 x kdim] * B[KP x kdim]^T for this wave's 16 rows.
+// sa: 2 x [64][64] floats, sb: 2 x [KP][64] floats.  kdim % 4 == 0.
+template <int NT>
+__device__ __forceinline__ void tile_gemm_nt(f32x4 (&acc)[NT], const float* __restrict__ A,
+                                             int64_t lda, const float* __restrict__ B,
+                                             int64_t ldb, int kdim, float* sa, float* sb) {
+  constexpr int KP = 16 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  PanelStage<64> pa;
+  PanelStage<KP> pb;
+  const int npan = (kdim + 63) >> 6;
+  pa.load(A, lda, 0, kdim, tid);
+  pb.load(B, ldb, 0, kdim, tid);
+  for (int p = 0; p < npan; ++p) {
+    float* ca = sa + (p & 1) * (64 * 64);
+    float* cb = sb + (p & 1) * (KP * 64);
+    pa.store(ca, tid);
+    pb.store(cb, tid);
+    __syncthreads();
+    if (p + 1 < npan) {
+      pa.load(A, lda, 64 * (p + 1), kdim, tid);
+      pb.load(B, ldb, 64 * (p + 1), kdim, tid);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int chunk = 4 * t + kq;
+      const f32x4 a4 = lds_read4(ca, 16 * wv + i, chunk);
+      f32x4 b4[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(cb, 16 * nt + i, chunk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a4[e], b4[nt][e], acc[nt]);
+    }
+  }
+}
+
+template <int NT>
+constexpr size_t rowgemm_smem_bytes() { return (size_t)(2 * 64 * 64 + 2 * 16 * NT * 64) * sizeof(float); }
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, int64_t lda, int kdimA,
+                                                 const float* __restrict__ B, int64_t ldb,
+                                                 float* __restrict__ W, const float* __restrict__ G,
+                                                 float* __restrict__ C) {
+  constexpr int KP = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sa = smem;
+  float* sb = smem + 2 * 64 * 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+
+  f32x4 num[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) num[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb);
+
+  const int64_t rbase = row0 + 16 * wv + 4 * kq;   // + reg index j
+  if (EPI == EPI_NMF_W) {
+    f32x4 den[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    tile_gemm_nt<NT>(den, W + row0 * KP, KP, G, KP, KP, sa, sb);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* p = W + (rbase + j) * KP + 16 * nt + i;
+        const float w = *p;
+        *p = (w * num[nt][j]) / (den[nt][j] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:131-132)
+      }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+  }
+}
+
+// Partials of P = W^T V and S = W^T W over one chunk of rows.
+// grid = (nchunks, ceil(np/256)); wave w of a block owns columns [256*by + 64*w, +64).
+// slab[chunk][KP][np + KP]: P in columns [0,np), S in [np, np+KP) (written by by == 0).
+template <int NT>
+__global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, int64_t ldv, int np,
+                                                 const float* __restrict__ W, int64_t mp,
+                                                 int rows_per_chunk, float* __restrict__ slab) {
+  constexpr int KP = 16 * NT;
+  constexpr int ST = (NT + 3) / 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
+  int64_t r_end = r_begin + rows_per_chunk;
+  if (r_end > mp) r_end = mp;
+  const int c0 = blockIdx.y * 256 + 64 * wv;
+  const bool pact = c0 < np;
+  const bool sact = blockIdx.y == 0;
+
+  f32x4 P[NT][4];
+  f32x4 S[NT][ST];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) P[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < ST; ++st) S[mt][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int64_t r = r_begin; r < r_end; r += 16) {
+    float af[NT][4], bf[4][4], sf[ST][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = r + 4 * kq + j;   // k index of MFMA step j for this lane group
+      const float* wr = W + row * KP + i;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) af[mt][j] = wr[16 * mt];
+#pragma unroll
+      for (int st = 0; st < ST; ++st) {
+        const int nt = wv + 4 * st;
+        sf[st][j] = (sact && nt < NT) ? wr[16 * nt] : 0.f;
+      }
+      const float* vr = V + row * ldv + c0 + i;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bf[nt][j] = pact ? vr[16 * nt] : 0.f;
+    }
+    if (pact) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) P[mt][nt] = mfma16(af[mt][j], bf[nt][j], P[mt][nt]);
+    }
+    if (sact) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int st = 0; st < ST; ++st) S[mt][st] = mfma16(af[mt][j], sf[st][j], S[mt][st]);
+    }
+  }
+
+  const int64_t ldp = (int64_t)np + KP;
+  float* base = slab + (int64_t)blockIdx.x * KP * ldp;
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float* rowp = base + (int64_t)(16 * mt + 4 * kq + jj) * ldp;
+      if (pact) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) rowp[c0 + 16 * nt + i] = P[mt][nt][jj];
+      }
+      if (sact) {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+          const int nt = wv + 4 * st;
+          if (nt < NT) rowp[np + 16 * nt + i] = S[mt][st][jj];
+        }
+      }
+    }
+}
+
+// out[e] = sum over chunks of slab[c][e], fixed order, float64 accumulation.
+__global__ void k_reduce_slabs(const float* __restrict__ slab, int nchunks, int64_t E,
+                               float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += (double)slab[(int64_t)c * E + e];
+  out[e] = (float)s;
+}
+
+// Partial sums of (V - W H)^2 for 64 rows per block; part[block] in float64.
+template <int NT>
+__global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int64_t ldv, int np,
+                                               const float* __restrict__ W,
+                                               const float* __restrict__ H, int64_t ldh,
+                                               double* __restrict__ part) {
+  constexpr int KP = 16 * NT;
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 64 + 16 * wv;
+  // A fragments of this wave's 16 rows of W: step s covers bases 4s + kq.
+  float af[4 * NT];
+#pragma unroll
+  for (int s = 0; s < 4 * NT; ++s) af[s] = W[(row0 + i) * KP + 4 * s + kq];
+  double tot = 0.0;
+  for (int cp = 0; cp < np; cp += 64) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4 * NT; ++s) {
+      const float* hr = H + (int64_t)(4 * s + kq) * ldh + cp + i;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(af[s], hr[16 * nt], acc[nt]);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = V[(row0 + 4 * kq + j) * ldv + cp + 16 * nt + i] - acc[nt][j];
+        ss += d * d;
+      }
+    tot += (double)ss;
+  }
+  tot = wave_sum_f64(tot);
+  if (lane == 0) wsum[wv] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}

@@ -1,0 +1,174 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle and the reference's goldens.
+
+Tolerances (float32 device arithmetic vs the float64-default reference):
+  ||X_gpu - X_ref||_F / ||X_ref||_F <= 2e-5 for X in {W, H};  |ferr_gpu - ferr_ref|/ferr_ref <= 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+TOL_X = 2e-5
+TOL_F = 1e-5
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import pymf_amd
+    from pymf_amd import _lib
+    assert _lib.device_count() >= 1, "no HIP device: the GPU tests need an MI355X"
+    return pymf_amd
+
+
+def _run(cls, V, k, niter, W0, H0, **flags):
+    mdl = cls(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=niter, **flags)
+    return mdl
+
+
+NMF_GOLD = ["nmf_cfg1_f64", "nmf_cfg1_f32", "nmf_512x128_k16", "nmf_cfg4s", "nmf_cfg2s",
+            "nmf_cfg5s_dense", "nmf_37x29_k5", "nmf_reftest"]
+
+
+@pytest.mark.parametrize("name", NMF_GOLD)
+def test_nmf_vs_reference_golden(pm, name):
+    g = load_golden(name)
+    mdl = _run(pm.NMF, g["V"], int(g["k"]), int(g["niter"]), g["W0"], g["H0"])
+    assert mdl.W.dtype == g["W"].dtype and mdl.H.dtype == g["H"].dtype
+    assert len(mdl.ferr) == len(g["ferr"])
+    assert rel_fro(mdl.W, g["W"]) < TOL_X
+    assert rel_fro(mdl.H, g["H"]) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=TOL_F)
+
+
+SNMF_GOLD = ["snmf_cfg1_f64", "snmf_cfg1_f32", "snmf_512x128_k16", "snmf_cfg4s", "snmf_cfg2s",
+             "snmf_sparse1pct", "snmf_37x29_k5", "snmf_reftest"]
+
+
+@pytest.mark.parametrize("name", SNMF_GOLD)
+def test_snmf_vs_reference_golden(pm, name):
+    g = load_golden(name)
+    W_before = g["W0"].copy()
+    mdl = pm.SNMF(g["V"], num_bases=int(g["k"]))
+    mdl.W, mdl.H = W_before, g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert mdl.W is not W_before                     # snmf.py:70 rebinds self.W
+    assert len(mdl.ferr) == len(g["ferr"])
+    # W crosses zero: Frobenius-relative only
+    assert rel_fro(mdl.W, g["W"]) < 5e-5
+    assert rel_fro(mdl.H, g["H"]) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (100, 70, 3), (257, 130, 33), (1000, 256, 64),
+                                   (513, 320, 100), (4096, 256, 64), (130, 1100, 20)])
+def test_nmf_vs_oracle_shapes(pm, m, n, k):
+    from oracle import NMFOracle
+    rs = np.random.RandomState(m + n + k)
+    V = rs.random_sample((m, n)).astype(np.float32)
+    W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
+    mdl = _run(pm.NMF, V, k, 6, W0, H0)
+    ref = NMFOracle(V, num_bases=k)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=6)
+    assert rel_fro(mdl.W, ref.W) < TOL_X
+    assert rel_fro(mdl.H, ref.H) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+
+
+def test_single_hooks_match_oracle(pm):
+    """update_w() / update_h() / frobenius_norm() callable singly, one C call each."""
+    from oracle import nmf_update_w, nmf_update_h, frobenius_norm
+    rs = np.random.RandomState(11)
+    V = rs.random_sample((333, 200)).astype(np.float32)
+    W, H = rs.random_sample((333, 24)), rs.random_sample((24, 200))
+    mdl = pm.NMF(V, num_bases=24)
+    mdl.W, mdl.H = W.copy(), H.copy()
+    assert abs(mdl.frobenius_norm() - frobenius_norm(V, W, H)) / frobenius_norm(V, W, H) < TOL_F
+    mdl.update_w()
+    nmf_update_w(V, W, H)
+    assert rel_fro(mdl.W, W) < 2e-6
+    mdl.update_h()
+    nmf_update_h(V, W, H)
+    assert rel_fro(mdl.H, H) < 2e-6
+    assert abs(mdl.frobenius_norm() - frobenius_norm(V, W, H)) / frobenius_norm(V, W, H) < TOL_F
+
+
+def test_flag_sequence_and_resume(pm):
+    """tests/test_pymf.py:92-95 -- repeated factorize() with flags; golden from the reference."""
+    g = load_golden("nmf_flagseq")
+    np.random.seed(int(g["seed"]))
+    mdl = pm.NMF(g["V"], num_bases=int(g["k"]))
+    mdl.factorize(niter=5)
+    assert rel_fro(mdl.W, g["W_a"]) < TOL_X and rel_fro(mdl.H, g["H_a"]) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, g["ferr_a"], rtol=TOL_F)
+    mdl.factorize(niter=5, compute_h=False)
+    assert rel_fro(mdl.W, g["W_b"]) < TOL_X and rel_fro(mdl.H, g["H_b"]) < TOL_X
+    mdl.factorize(niter=5, compute_w=False)
+    assert rel_fro(mdl.W, g["W_c"]) < TOL_X and rel_fro(mdl.H, g["H_c"]) < TOL_X
+    before = mdl.ferr.copy()
+    mdl.factorize(niter=5, compute_err=False)
+    assert rel_fro(mdl.W, g["W_d"]) < TOL_X and rel_fro(mdl.H, g["H_d"]) < TOL_X
+    np.testing.assert_array_equal(mdl.ferr, before)          # nmf.py:179-180
+    np.testing.assert_allclose(mdl.ferr, g["ferr_d"], rtol=TOL_F)
+
+
+def test_early_exit_truncates_ferr(pm):
+    """nmf.py:198-202 -- exact data, compute_w=False: reference stops with len(ferr)==2."""
+    g = load_golden("nmf_earlyexit")
+    mdl = pm.NMF(g["V"], num_bases=2)
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=20, compute_w=False)
+    assert len(mdl.ferr) == len(g["ferr"]) == 2
+    np.testing.assert_allclose(mdl.H, g["H"], rtol=1e-5, atol=1e-6)
+
+
+def test_sentinel_and_errors(pm):
+    mdl = pm.NMF(np.ones((5, 4), dtype=np.float32), num_bases=2)
+    assert mdl.frobenius_norm() == -123456                   # nmf.py:112
+    with pytest.raises(TypeError):
+        pm.NMF(np.ones((5, 4)), num_bases=2, niter=3)        # stale docstring ctor
+    mdl.W = np.ones((5, 2), dtype=np.int64)
+    mdl.H = np.ones((2, 4))
+    with pytest.raises(TypeError):
+        mdl.factorize(niter=1)                               # integer W fails in the reference too
+
+
+def test_user_assigned_factors_are_reuploaded(pm):
+    from oracle import NMFOracle
+    rs = np.random.RandomState(2)
+    V = rs.random_sample((80, 64)).astype(np.float32)
+    mdl = pm.NMF(V, num_bases=8)
+    np.random.seed(1)
+    mdl.factorize(niter=2)
+    W1, H1 = rs.random_sample((80, 8)), rs.random_sample((8, 64))
+    mdl.W, mdl.H = W1.copy(), H1.copy()
+    mdl.factorize(niter=3)
+    ref = NMFOracle(V, num_bases=8)
+    ref.W, ref.H = W1.copy(), H1.copy()
+    ref.factorize(niter=3)
+    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+    mdl.H *= 0.5                                             # in-place edit must be noticed
+    ref.H *= 0.5
+    mdl.factorize(niter=1)
+    ref.factorize(niter=1)
+    assert rel_fro(mdl.H, ref.H) < TOL_X
+
+
+def test_linearity_property_large(pm):
+    """Size-independent property at a larger size: one update_w is homogeneous of
+    degree 0 in H scaling pairs: W(V, W0, c*H) * c == W(V, W0, H) (up to the 1e-9 eps)."""
+    rs = np.random.RandomState(4)
+    m, n, k = 65536, 256, 64
+    V = rs.random_sample((m, n)).astype(np.float32)
+    W0, H0 = rs.random_sample((m, k)).astype(np.float32), rs.random_sample((k, n)).astype(np.float32)
+    a = pm.NMF(V, num_bases=k)
+    a.W, a.H = W0.copy(), H0.copy()
+    a.update_w()
+    b = pm.NMF(V, num_bases=k)
+    b.W, b.H = W0.copy(), (2.0 * H0)
+    b.update_w()
+    assert rel_fro(2.0 * b.W, a.W) < 1e-6
