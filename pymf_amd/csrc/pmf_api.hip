@@ -32,7 +32,7 @@ namespace {
 std::string g_create_error;
 
 struct KernelStat {
-  const char* name = "none";
+  std::string name = "none";
   double flops = 0.0, bytes = 0.0;
   std::vector<hipEvent_t> ev;   // pairs
   size_t used = 0;              // events recorded since reset
@@ -238,8 +238,9 @@ int nmf_update_h(pmf_ctx* c) {
 int nmf_fused_iteration(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
-  PMFCHK(launch_fused(c->stream, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab));
+  const int lrc = launch_fused(c->stream, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab);
   stat_end(c);
+  if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
   PMFCHK(reduce_slabs(c, c->fused_wgs));
   return h_step_from_ps(c);
@@ -638,7 +639,7 @@ int pmf_kernel_stats(pmf_ctx* c, const char** name, int64_t* launches, double* m
     HIPCHK(c, hipEventElapsedTime(&ms, c->stat.ev[2 * q], c->stat.ev[2 * q + 1]));
     tot += ms;
   }
-  if (name) *name = c->stat.name;
+  if (name) *name = c->stat.name.c_str();
   if (launches) *launches = (int64_t)pairs;
   if (mean_ms) *mean_ms = pairs ? tot / (double)pairs : 0.0;
   if (flops_per_launch) *flops_per_launch = c->stat.flops;
