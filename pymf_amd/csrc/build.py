@@ -26,7 +26,10 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result", SRC, "-o", OUT, "-lrccl"]
+           "-Wno-unused-result",
+           # keep MFMA accumulators selectable from the whole 512-entry VGPR/AGPR file: the fused
+           # kernel holds 352 accumulator registers, more than the 256 AGPRs alone
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1", SRC, "-o", OUT, "-lrccl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=HERE)

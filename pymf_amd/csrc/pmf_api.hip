@@ -170,10 +170,10 @@ int colgemm(pmf_ctx* c) {
 
 int64_t ps_elems(const pmf_ctx* c) { return (int64_t)c->KP * (c->np + c->KP); }
 
-int reduce_slabs(pmf_ctx* c, int nslabs) {
+int reduce_slabs(pmf_ctx* c, int nslabs, int sym) {
   const int64_t E = ps_elems(c);
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream,
-                     c->dSlab, nslabs, E, c->dPS);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, c->stream,
+                     c->dSlab, nslabs, c->KP, c->np, sym, c->dPS);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -226,7 +226,7 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
 int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
   if (c->v_csr) return csr_ps(c);
   PMFCHK(colgemm(c));
-  return reduce_slabs(c, c->nchunks);
+  return reduce_slabs(c, c->nchunks, 0);
 }
 
 int nmf_update_h(pmf_ctx* c) {
@@ -242,7 +242,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
-  PMFCHK(reduce_slabs(c, c->fused_wgs));
+  PMFCHK(reduce_slabs(c, c->fused_wgs, 1));
   return h_step_from_ps(c);
 }
 

@@ -20,6 +20,18 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// a / b for a >= 0 and b a positive NORMAL float (b = den + 1e-9 here): v_rcp_f32 (1 ulp)
+// refined by one Newton step on the quotient, q = q0 + r * fma(-b, q0, a).  The result is
+// the correctly rounded quotient except for rare last-bit ties -- the same class of
+// difference as a different BLAS summation order -- at 4 VALU ops instead of the 10 of the
+// IEEE div expansion (which only adds scaling for denormal / overflowing operands).
+__device__ __forceinline__ float pmf_div(float a, float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q0 = a * r;
+  const float e = fmaf(-b, q0, a);
+  return fmaf(e, r, q0);
+}
+
 // LDS image of a [rows][64] f32 panel: 256-byte rows (exactly the 64 banks),
 // 16-byte chunk c of row r stored at chunk (c ^ (r & 15)).  A fragment read --
 // 16 lanes on 16 different rows, 4 k-groups on chunks 4t..4t+3 -- is then

@@ -30,6 +30,19 @@
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), \
                                    (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
 
+// Diagnostic build only (-DPMF_STAMPS): per-section cycle sums of one wave (guide section 7,
+// "In-kernel stamps").  Never compiled into the shipped library.
+#ifdef PMF_STAMPS
+#define PMF_STAMP(var)                                                           \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#else
+#define PMF_STAMP(var) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt range");
@@ -41,15 +54,24 @@ constexpr size_t fused_smem_bytes() {
   return (size_t)64 * (NPANEL * 16 * NT + 16 * NT + 4 * 16 * NPANEL + 4 * 16) * sizeof(float);
 }
 
+// blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
+// more; computed on the host so every loop bound and base address is scalar (SGPR).
 template <int NT, int NPANEL>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
                                                        float* __restrict__ W,
                                                        const float* __restrict__ H,
-                                                       const float* __restrict__ G, int64_t mp,
-                                                       float* __restrict__ slab) {
+                                                       const float* __restrict__ G, int blk_per,
+                                                       int blk_extra, float* __restrict__ slab
+#ifdef PMF_STAMPS
+                                                       , unsigned long long* __restrict__ dbg
+#endif
+                                                       ) {
   constexpr int KP = 16 * NT;
   constexpr int NP = 64 * NPANEL;
   constexpr int NTP = 4 * NPANEL;   // column tiles of P
+  // DMA of the next block's V panel p is spread over phase B's panel p+1 steps and the last
+  // panel over the next phase A's first steps (one LDS-DMA per 16 MFMAs) -- needs 4 panels.
+  constexpr bool SPREAD = (NPANEL == 4);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                             // [NPANEL][KP][64]   swizzled rows
   float* sG = sH + NPANEL * KP * 64;            // [KP][64]
@@ -76,39 +98,33 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   }
   __syncthreads();
 
-  // ---- this wave's contiguous range of 16-row blocks ----
-  const int64_t nblk = mp >> 4;
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
-  const int64_t per = nblk / nw, extra = nblk % nw;
-  const int64_t b0 = gw * per + (gw < extra ? gw : extra);
-  const int64_t nb = per + (gw < extra ? 1 : 0);
+  // ---- this wave's contiguous range of 16-row blocks (all scalar) ----
+  const int gw = blockIdx.x * 4 + wv;
+  const int b0 = gw * blk_per + (gw < blk_extra ? gw : blk_extra);
+  const int nb = blk_per + (gw < blk_extra ? 1 : 0);
 
-  // LDS-DMA geometry: one instruction = 4 rows x 256 B; lane L fills physical chunk
-  // (L & 15) of row 4q + (L >> 4), so it fetches logical chunk (L & 15) ^ (row & 15).
-  const int drow = lane >> 4;        // + 4q
-  const int dchunk = lane & 15;
-
-  auto issue_v_panel = [&](int64_t r0, int p) {
+  // LDS-DMA geometry: one instruction = 4 rows x 256 B; lane L fills physical chunk (L & 15)
+  // of row 4q + (L >> 4), so it fetches logical chunk (L & 15) ^ row.  Per-lane BYTE offsets
+  // (32-bit) relative to a scalar row base: the source address is SGPR base + VGPR offset.
+  unsigned voff[4], woff[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = 4 * q + drow;
-      const float* src = V + (r0 + row) * NP + 64 * p + 4 * (dchunk ^ (row & 15));
-      PMF_GLDS16(src, sV + p * 1024 + q * 256);
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int row = 4 * q + (lane >> 4);
+    const int c = (lane & 15) ^ row;
+    voff[q] = (unsigned)(row * NP * 4 + 16 * c);
+    woff[q] = (unsigned)(row * KP * 4 + 16 * (4 * c < KP ? c : 0));   // beyond k: valid, never read
+  }
+  const char* Vb = reinterpret_cast<const char*>(V);
+  const char* Wb = reinterpret_cast<const char*>(W);
+  auto issue_v = [&](int blk, int p, int q) {      // V rows of block blk, panel p, DMA q
+    PMF_GLDS16(Vb + ((size_t)blk * (16 * NP * 4) + p * 256) + voff[q], sV + p * 1024 + q * 256);
   };
-  auto issue_w = [&](int64_t r0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = 4 * q + drow;
-      int c = dchunk ^ (row & 15);
-      if (4 * c >= KP) c = 0;        // beyond the k columns: any valid address, never read
-      const float* src = W + (r0 + row) * KP + 4 * c;
-      PMF_GLDS16(src, sW + q * 256);
-    }
+  auto issue_w = [&](int blk, int q) {
+    PMF_GLDS16(Wb + (size_t)blk * (16 * KP * 4) + woff[q], sW + q * 256);
   };
 
   f32x4 P[NT][NTP];
-  f32x4 S[NT][NT];
+  f32x4 S[NT][NT];       // only nt >= mt is accumulated (S is symmetric)
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) {
 #pragma unroll
@@ -118,102 +134,202 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   }
 
   if (nb > 0) {
-    issue_w(b0 * 16);
 #pragma unroll
-    for (int p = 0; p < NPANEL; ++p) issue_v_panel(b0 * 16, p);
+    for (int q = 0; q < 4; ++q) issue_w(b0, q);
+#pragma unroll
+    for (int p = 0; p < (SPREAD ? NPANEL - 1 : NPANEL); ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) issue_v(b0, p, q);
   }
 
-  for (int64_t b = 0; b < nb; ++b) {
-    const int64_t r0 = (b0 + b) * 16;
-    const bool more = (b + 1 < nb);
+  // Fragment double buffers: step s+1's LDS reads are issued before step s's MFMAs.
+  f32x4 fa[2];
+  f32x4 fb[2][NT];
+  float bf[2][4];
+  f32x4 wp[NT];          // previous block's new W rows: its S MFMAs run under this block's epilogue
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---------------- phase A: Num = V_b H^T ----------------
+  constexpr int NSN = 4 * NPANEL;      // Num steps (one 16-byte k-group each)
+  constexpr int NSA = NSN + NT;        // + Den steps
+
+#ifdef PMF_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+  unsigned long long acc_wait = 0, acc_a = 0, acc_dma = 0, acc_epi = 0, acc_b = 0;
+#endif
+  for (int b = 0; b < nb; ++b) {
+    const int blk = b0 + b;
+    const bool more = (b + 1 < nb);
+    PMF_STAMP(ts0);
+
     f32x4 num[NT], den[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       num[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // step s < NSN: Num k-group (panel s/4, t = s%4); s >= NSN: Den k-group t = s - NSN
+    auto load_step = [&](int s, int buf) {
+      if (s < NSN) {
+        const int p = s >> 2, chunk = 4 * (s & 3) + kq;
+        fa[buf] = lds_read4(sV + p * 1024, i, chunk);
 #pragma unroll
-    for (int p = 0; p < NPANEL; ++p) {
-      // panels p+1.. of this block (4 DMA each) may still be in flight
-      if (p == 0) wait_vmcnt<4 * (NPANEL - 1)>();
-      else if (p == 1) wait_vmcnt<(NPANEL > 1 ? 4 * (NPANEL - 2) : 0)>();
-      else if (p == 2) wait_vmcnt<(NPANEL > 2 ? 4 * (NPANEL - 3) : 0)>();
-      else wait_vmcnt<0>();
-      const float* vp = sV + p * 1024;
-      const float* hp = sH + p * (KP * 64);
+        for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sH + p * (KP * 64), 16 * nt + i, chunk);
+      } else {
+        const int chunk = 4 * (s - NSN) + kq;
+        fa[buf] = lds_read4(sW, i, chunk);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int chunk = 4 * t + kq;
-        const f32x4 a4 = lds_read4(vp, i, chunk);
-        f32x4 b4[NT];
+        for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sG, 16 * nt + i, chunk);
+      }
+    };
+    // V panel p of this block has landed.  vmcnt counts every later VMEM op in issue order.
+    //  clumped:  panels p+1.. (4 DMA each) may still be in flight.
+    //  SPREAD :  order per block is [last panel x4 under phase A steps 0..3][W' x4][stores]
+    //            [V' p0 x4][V' p1 x4][V' p2 x4]; see the wait at each use below.
+    auto wait_panel = [&](int p) {
+      if (SPREAD) {
+        if (p == 0) wait_vmcnt<8>();        // V p1, p2 of this block still allowed in flight
+        else if (p == 1) wait_vmcnt<7>();   // p2 (4) + last-panel DMAs issued after steps 0,1,2
+        else if (p == 2) wait_vmcnt<4>();   // the 4 last-panel DMAs
+        else wait_vmcnt<0>();
+      } else {
+        if (p == 0) wait_vmcnt<4 * (NPANEL - 1)>();
+        else if (p == 1) wait_vmcnt<(NPANEL > 1 ? 4 * (NPANEL - 2) : 0)>();
+        else if (p == 2) wait_vmcnt<(NPANEL > 2 ? 4 * (NPANEL - 3) : 0)>();
+        else wait_vmcnt<0>();
+      }
+    };
+
+    // ---------------- phase A: Num = V_b H^T, Den = W_b G ----------------
+    wait_panel(0);               // also covers the (older) W image
+    PMF_STAMP(ts1);
+    load_step(0, 0);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(hp, 16 * nt + i, chunk);
+    for (int s = 0; s < NSA; ++s) {
+      if (s + 1 < NSA) {
+        if (s + 1 < NSN && ((s + 1) & 3) == 0) wait_panel((s + 1) >> 2);
+        load_step(s + 1, (s + 1) & 1);
+      }
+      const int buf = s & 1;
+      if (s < NSN) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) num[nt] = mfma16(a4[e], b4[nt][e], num[nt]);
+          for (int nt = 0; nt < NT; ++nt) num[nt] = mfma16(fa[buf][e], fb[buf][nt][e], num[nt]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) den[nt] = mfma16(fa[buf][e], fb[buf][nt][e], den[nt]);
       }
+      if (SPREAD && s < 4) issue_v(blk, NPANEL - 1, s);   // this block's last panel, 1 DMA/step
+      // issue order inside the step: one LDS read (of step s+1) per 3 MFMAs (of step s), so a
+      // read's issue slot hides under an executing MFMA; the DMA goes last
+      if (s + 1 < NSA) {
+#pragma unroll
+        for (int g = 0; g < NT + 1; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (NT + 1), 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                     // remaining MFMAs
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---------------- Den = W_b G ----------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int chunk = 4 * t + kq;
-      const f32x4 a4 = lds_read4(sW, i, chunk);
-      f32x4 b4[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(sG, 16 * nt + i, chunk);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) den[nt] = mfma16(a4[e], b4[nt][e], den[nt]);
-    }
-    // ---------------- epilogue: W_b <- (W_b * Num) / (Den + eps) ----------------
-    f32x4 wn[NT];
+    PMF_STAMP(ts2);
+    // old W rows in the accumulator (C) layout, then the W image is free: prefetch the next block's
+    float wold[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = 4 * kq + j, col = 16 * nt + i;
-        const float wold = sW[swz_off(row, col >> 2) + (col & 3)];
-        const float w = (wold * num[nt][j]) / (den[nt][j] + PMF_EPS_DEN);
-        wn[nt][j] = w;
-        W[(r0 + row) * KP + col] = w;
+        wold[nt][j] = sW[swz_off(row, col >> 2) + (col & 3)];
       }
-    // the W image is free again: prefetch the next block's rows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (more) issue_w(r0 + 16);
-
-    // ---------------- phase B: P += W_b^T V_b, S += W_b^T W_b ----------------
+    if (more) {
 #pragma unroll
-    for (int p = 0; p < NPANEL; ++p) {
-      const float* vp = sV + p * 1024;
+      for (int q = 0; q < 4; ++q) issue_w(blk + 1, q);
+    }
+    PMF_STAMP(ts3);
+
+    // ------- epilogue W_b <- (W_b * Num) / (Den + eps), interleaved with S += of the previous block -------
+    f32x4 wn[NT];
+    float* wdst = W + (size_t)blk * (16 * KP) + (4 * kq) * KP + i;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = 4 * kq + j;
-        float bf[4];
+        const float w = pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);
+        wn[nt][j] = w;
+        wdst[j * KP + 16 * nt] = w;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bf[nt] = vp[swz_off(row, 4 * nt + (i >> 2)) + (i & 3)];
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            P[mt][4 * p + nt] = mfma16(wn[mt][j], bf[nt], P[mt][4 * p + nt]);
+        for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
       }
-      // every read of panel p has returned: refill it for the next block
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (more) issue_v_panel(r0 + 16, p);
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int nt = 0; nt < NT; ++nt) wp[nt] = wn[nt];
+
+    PMF_STAMP(ts4);
+    // ---------------- phase B: P += W_b^T V_b ----------------
+    auto load_bf = [&](int s, int buf) {
+      const int p = s >> 2, row = 4 * kq + (s & 3);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        bf[buf][nt] = (sV + p * 1024)[swz_off(row, 4 * nt + (i >> 2)) + (i & 3)];
+    };
+    load_bf(0, 0);
+#pragma unroll
+    for (int s = 0; s < NSN; ++s) {
+      if (s + 1 < NSN) load_bf(s + 1, (s + 1) & 1);
+      const int p = s >> 2, j = s & 3, buf = s & 1;
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) S[mt][nt] = mfma16(wn[mt][j], wn[nt][j], S[mt][nt]);
+        for (int nt = 0; nt < 4; ++nt)
+          P[mt][4 * p + nt] = mfma16(wn[mt][j], bf[buf][nt], P[mt][4 * p + nt]);
+      if (SPREAD) {
+        // panel p-1 was fully read one panel ago (its last reads fed step 4p-1's MFMAs)
+        if (p >= 1 && more) issue_v(blk + 1, p - 1, j);
+      }
+      if (s + 1 < NSN) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);    // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!SPREAD && j == 3) {
+        // every read of panel p has returned: refill it for the next block
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) issue_v(blk + 1, p, q);
+        }
+      }
+    }
+    if (SPREAD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last panel's reads returned
+#ifdef PMF_STAMPS
+    PMF_STAMP(ts5);
+    acc_wait += ts1 - ts0; acc_a += ts2 - ts1; acc_dma += ts3 - ts2; acc_epi += ts4 - ts3; acc_b += ts5 - ts4;
+#endif
   }
+#ifdef PMF_STAMPS
+  if (dbg && lane == 0) {
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+    d[0] = acc_wait; d[1] = acc_a; d[2] = acc_dma; d[3] = acc_epi; d[4] = acc_b; d[5] = (unsigned long long)nb;
+  }
+#endif
+  // S of the last block
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
 
   // ---- sum the 4 waves' accumulators through LDS (tree), wave 0 writes the slab ----
+  // Slab tiles: P (NT x NTP) then the upper-triangular S tiles (nt >= mt); tiles below the
+  // diagonal of S are never written -- k_reduce_slabs mirrors them (sym = 1).
   constexpr int NTILE = NT * (NTP + NT);
   __syncthreads();
   f32x4* ex = reinterpret_cast<f32x4*>(smem);   // two regions of NTILE*64 f32x4
@@ -225,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
       for (int nt = 0; nt < NTP; ++nt) dst[(mt * (NTP + NT) + nt) * 64] = P[mt][nt];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dst[(mt * (NTP + NT) + NTP + nt) * 64] = S[mt][nt];
+      for (int nt = mt; nt < NT; ++nt) dst[(mt * (NTP + NT) + NTP + nt) * 64] = S[mt][nt];
     }
   };
   auto add = [&](int region) {
@@ -235,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
       for (int nt = 0; nt < NTP; ++nt) P[mt][nt] += src[(mt * (NTP + NT) + nt) * 64];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) S[mt][nt] += src[(mt * (NTP + NT) + NTP + nt) * 64];
+      for (int nt = mt; nt < NT; ++nt) S[mt][nt] += src[(mt * (NTP + NT) + NTP + nt) * 64];
     }
   };
   if (wv & 1) put(wv >> 1);
@@ -256,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) rowp[16 * nt + i] = P[mt][nt][j];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) rowp[NP + 16 * nt + i] = S[mt][nt][j];
+        for (int nt = mt; nt < NT; ++nt) rowp[NP + 16 * nt + i] = S[mt][nt][j];
       }
   }
 }
@@ -290,6 +406,8 @@ static inline const char* fused_kernel_name(int NT, int np) {
 template <int NT, int NPANEL>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
                           int64_t mp, int wgs, float* slab) {
+  const int nblk = (int)(mp / 16), nw = wgs * 4;
+  const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL>();
   static bool attr_done = false;
   if (!attr_done) {
@@ -298,7 +416,8 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
       return PMF_EHIP;
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL>), dim3(wgs), dim3(256), smem, s, V, W, H, G, mp, slab);
+  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
+                     blk_extra, slab);
   return PMF_OK;
 }
 

@@ -210,14 +210,32 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
     }
 }
 
-// out[e] = sum over chunks of slab[c][e], fixed order, float64 accumulation.
-__global__ void k_reduce_slabs(const float* __restrict__ slab, int nchunks, int64_t E,
-                               float* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+// out[e] = sum over slabs of slab[c][e], fixed order, float64 accumulation.
+// One block = 64 consecutive elements; wave w sums slabs w, w+4, ... (coalesced 256-B
+// reads), the four partials are combined in wave order.  sym != 0: the S part holds only
+// the tiles on/above the diagonal (fused kernel) -- an element below reads its mirror.
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab, int nslabs,
+                                                      int KP, int np, int sym,
+                                                      float* __restrict__ out) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ldp = (int64_t)np + KP;
+  const int64_t E = (int64_t)KP * ldp;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
   double s = 0.0;
-  for (int c = 0; c < nchunks; ++c) s += (double)slab[(int64_t)c * E + e];
-  out[e] = (float)s;
+  if (e < E) {
+    int64_t src = e;
+    if (sym) {
+      const int r = (int)(e / ldp), c = (int)(e % ldp) - np;
+      if (c >= 0 && (r >> 4) > (c >> 4)) src = (int64_t)c * ldp + np + r;   // S[r][c] = S[c][r]
+    }
+    const float* p = slab + src;
+#pragma unroll 8
+    for (int c = wv; c < nslabs; c += 4) s += (double)p[(int64_t)c * E];
+  }
+  part[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && e < E) out[e] = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
 }
 
 // Partial sums of (V - W H)^2 for 64 rows per block; part[block] in float64.

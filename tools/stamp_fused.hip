@@ -1,0 +1,31 @@
+// diagnostic: per-section cycle shares of k_nmf_fused<4,4> (cfg4)
+#define PMF_STAMPS
+#define PMF_FUSED_KERNEL_ONLY
+#include "/root/repo/pymf_amd/csrc/pmf_fused.h"
+#include <vector>
+#include <cstdio>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); return 1;}}while(0)
+__global__ void fillk(float* p, size_t n, unsigned seed){ size_t i=blockIdx.x*(size_t)blockDim.x+threadIdx.x; if(i<n) p[i]=u01_from(seed,i); }
+int main(){
+  const int64_t mp=1048576; const int NP=256, KP=64; const int wgs=256;
+  float *V,*W,*H,*G,*slab; unsigned long long* dbg;
+  CK(hipMalloc(&V,mp*NP*4)); CK(hipMalloc(&W,mp*KP*4)); CK(hipMalloc(&H,KP*NP*4)); CK(hipMalloc(&G,KP*KP*4));
+  CK(hipMalloc(&slab,(size_t)wgs*KP*(NP+KP)*4)); CK(hipMalloc(&dbg,wgs*4*8*8));
+  fillk<<<(mp*NP+255)/256,256>>>(V,mp*NP,1); fillk<<<(mp*KP+255)/256,256>>>(W,mp*KP,2);
+  fillk<<<(KP*NP+255)/256,256>>>(H,KP*NP,3); fillk<<<(KP*KP+255)/256,256>>>(G,KP*KP,4);
+  size_t smem=fused_smem_bytes<4,4>();
+  CK(hipFuncSetAttribute((const void*)&k_nmf_fused<4,4>, hipFuncAttributeMaxDynamicSharedMemorySize,(int)smem));
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int it=0; it<5; ++it){
+    hipEventRecord(e0);
+    k_nmf_fused<4,4><<<wgs,256,smem>>>(V,W,H,G,(int)(mp/16/(wgs*4)),(int)((mp/16)%(wgs*4)),slab,dbg);
+    hipEventRecord(e1); CK(hipDeviceSynchronize());
+    float ms; hipEventElapsedTime(&ms,e0,e1);
+    std::vector<unsigned long long> h(wgs*4*8); CK(hipMemcpy(h.data(),dbg,h.size()*8,hipMemcpyDeviceToHost));
+    double s[5]={0,0,0,0,0}; double nb=0;
+    for(int w=0; w<wgs*4; ++w){ for(int q=0;q<5;++q) s[q]+=h[w*8+q]; nb+=h[w*8+5]; }
+    double tot=s[0]+s[1]+s[2]+s[3]+s[4];
+    printf("it %d: %.3f ms; per block cycles: wait %.0f phaseA %.0f dmaW %.0f epi+S %.0f phaseB %.0f total %.0f (stamp units)\n", it, ms, s[0]/nb,s[1]/nb,s[2]/nb,s[3]/nb,s[4]/nb,tot/nb);
+  }
+  return 0;
+}
