@@ -26,6 +26,7 @@
 #include "pmf_tiled.h"
 #include "pmf_fused.h"
 #include "pmf_nnls.h"
+#include "pmf_csr.h"
 
 namespace {
 
@@ -95,8 +96,8 @@ int fail(pmf_ctx* c, int code, const std::string& msg) {
 
 int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-int csr_ps(pmf_ctx* c) { return fail(c, PMF_EINVAL, "CSR path not built yet"); }
-int csr_vht(pmf_ctx* c) { return fail(c, PMF_EINVAL, "CSR path not built yet"); }
+int csr_ps(pmf_ctx* c);
+int csr_w(pmf_ctx* c);
 
 template <typename T>
 int dalloc(pmf_ctx* c, T** p, size_t count) {
@@ -155,13 +156,14 @@ int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, 
   return fail(c, PMF_EINVAL, "bad NT");
 }
 
-int colgemm(pmf_ctx* c) {
-  dim3 grid((unsigned)c->nchunks, (unsigned)((c->np + 255) / 256));
+int colgemm(pmf_ctx* c, bool with_v = true) {
+  dim3 grid((unsigned)c->nchunks, with_v ? (unsigned)((c->np + 255) / 256) : 1u);
+  const float* Vp = with_v ? c->dV : nullptr;
   switch (c->NT) {
-    case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 8: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 8: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
     default: return fail(c, PMF_EINVAL, "bad NT");
   }
   HIPCHK(c, hipGetLastError());
@@ -182,6 +184,43 @@ int allreduce_ps(pmf_ctx* c) {
   if (c->nranks > 1)
     NCCLCHK(c, ncclAllReduce(c->dPS, c->dPS, (size_t)ps_elems(c), ncclFloat, ncclSum, c->comm, c->stream));
   return PMF_OK;
+}
+
+// ---- CSR (SNMF) ----------------------------------------------------------------------------
+int csr_w(pmf_ctx* c) {   // W = V (H^T inv(H H^T)); dGinvT is ready, dW1 holds M (np x KP)
+  const int E = c->np * c->KP;
+  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dH,
+                     (int64_t)c->np, c->np, c->KP, c->dGinvT, c->dW1);
+  HIPCHK(c, hipGetLastError());
+  const unsigned blocks = (unsigned)std::min<int64_t>((c->mp + 3) / 4, 256 * 16);
+  if (c->KP <= 64)
+    hipLaunchKernelGGL((k_csr_w<1>), dim3(blocks), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,
+                       c->dVals, c->mp, c->KP, c->dW1, c->dW);
+  else
+    hipLaunchKernelGGL((k_csr_w<2>), dim3(blocks), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,
+                       c->dVals, c->mp, c->KP, c->dW1, c->dW);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by the CSR scatter
+  const size_t smem = (size_t)c->np * c->KP * sizeof(float);
+  if (smem > 160 * 1024) return fail(c, PMF_EINVAL, "CSR path: n * num_bases too large for the LDS accumulator");
+  PMFCHK(colgemm(c, /*with_v=*/false));
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  if (c->KP <= 64)
+    hipLaunchKernelGGL((k_csr_p<1>), dim3((unsigned)c->nchunks), dim3(256), smem, c->stream, c->dIndptr,
+                       c->dIndices, c->dVals, c->mp, c->rows_per_chunk, c->KP, c->np, c->dW, c->dSlab);
+  else
+    hipLaunchKernelGGL((k_csr_p<2>), dim3((unsigned)c->nchunks), dim3(256), smem, c->stream, c->dIndptr,
+                       c->dIndices, c->dVals, c->mp, c->rows_per_chunk, c->KP, c->np, c->dW, c->dSlab);
+  HIPCHK(c, hipGetLastError());
+  return reduce_slabs(c, c->nchunks, 0);
 }
 
 int ensure_gram(pmf_ctx* c, double pad_diag) {
@@ -258,8 +297,8 @@ int snmf_update_w(pmf_ctx* c) {
   }
   hipLaunchKernelGGL(k_inverse, dim3(1), dim3(256), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
   HIPCHK(c, hipGetLastError());
-  if (c->v_csr) PMFCHK(csr_vht(c));
-  else PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
+  if (c->v_csr) return csr_w(c);
+  PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
   return rowgemm<EPI_STORE>(c, c->dW1, c->KP, c->KP, c->dGinvT, c->KP, nullptr, nullptr, c->dW);
 }
 
@@ -274,7 +313,7 @@ int als_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
   stat_begin(c);
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, c->KP, 1, c->dW, c->KP, 1, c->mp);
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m);
   stat_end(c);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (W) failed");
   HIPCHK(c, hipGetLastError());
@@ -290,7 +329,7 @@ int als_update_h(pmf_ctx* c) {
                      c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
   HIPCHK(c, hipGetLastError());
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, 1, ldp, c->dH, 1, c->np, c->np);
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
@@ -397,6 +436,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   if (algo < 0 || algo > 2) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS) or 2 (SNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
   if (k > 128) return fail(nullptr, PMF_EINVAL, "num_bases > 128 is not supported by this build");
+  if (algo == PMF_ALGO_NMFALS && k > 64)
+    return fail(nullptr, PMF_EINVAL, "NMFALS: num_bases > 64 is not supported by this build");
   if (n > (1 << 24)) return fail(nullptr, PMF_EINVAL, "n too large");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, PMF_EINVAL, "bad rank/nranks");
   if (nranks > 1 && !nccl_id) return fail(nullptr, PMF_EINVAL, "nccl_id required when nranks > 1");
@@ -436,7 +477,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dPart, (size_t)(c->mp / 64)));
     PMFCHK(dalloc(c, &c->dScal, 8));
     if (algo != PMF_ALGO_NMF) {
-      PMFCHK(dalloc(c, &c->dW1, (size_t)c->mp * c->KP));
+      PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dGinvT, (size_t)c->KP * c->KP));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1,8 +1,24 @@
-// pmf_nnls.h -- batched non-negative QP solver for NMFALS (placeholder until built).
+// pmf_nnls.h -- batched non-negative QP for NMFALS (pymf/nmfals.py:70-97).
+//
+// Every column of H (resp. row of W) solves
+//     minimise 1/2 x' HA x - f' x   subject to x >= 0,      HA = W^T W (resp. H H^T)
+// which is the QP the reference hands to cvxopt.solvers.qp(HA, FA = -f, -I, 0)
+// (nmfals.py:74,89).  HA is shared by all problems of a half step, only f differs.
+//
+// One wave per problem, lane t <-> variable t (k <= 64), everything in float64 as the
+// reference forces (nmfals.py:73,78).  Exact active set (Lawson-Hanson on the Gram
+// matrix): the inverse of HA restricted to the passive set is kept explicitly, row t in
+// lane t's registers (A[c] = inv[t][c]), and is bordered / down-dated by rank-1 updates
+// when a variable enters / leaves -- O(|P|) wave steps per change, no triangular solves,
+// no cross-lane reductions except one arg-max, one sum and one min per outer iteration.
+// HA sits read-only in LDS; its symmetry makes every access a conflict-free row read.
 #pragma once
 #include "pmf_dev.h"
 #include "../../include/pymf_hip.h"
-__global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int np, int KP, int k, double* __restrict__ Gd) {
+
+// HA (float64, padded: identity on rows/cols >= k) from the reduced (P | S) buffer: HA = S.
+__global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int np, int KP, int k,
+                                  double* __restrict__ Gd) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= KP * KP) return;
   const int r = q / KP, c = q % KP;
@@ -10,4 +26,156 @@ __global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int
   if (r >= k || c >= k) v = (r == c) ? 1.0 : 0.0;
   Gd[q] = v;
 }
-static inline int launch_nnqp(hipStream_t, int, int, const double*, const float*, int64_t, int64_t, float*, int64_t, int64_t, int64_t) { return PMF_EINVAL; }
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int KR>   // variable slots per problem: 16, 32 or 64 (k <= KR)
+__global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int KP, int k,
+                                              const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
+                                              float* __restrict__ X, int64_t x_sk, int64_t x_sp,
+                                              int64_t nprob) {
+  extern __shared__ __attribute__((aligned(16))) double sH[];   // [KR][KR], + 1 double: tol
+  const int tid = threadIdx.x, t = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int q = tid; q < KR * KR; q += 256) {
+    const int r = q / KR, c = q % KR;
+    sH[q] = (r < k && c < k) ? Hd[(int64_t)r * KP + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  // stopping tolerance on the dual: 10 eps k max|HA| (same scale as the float64 oracle)
+  double hmax = 0.0;
+  if (t < k) hmax = sH[t * KR + t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hmax = fmax(hmax, __shfl_xor(hmax, o, 64));
+  const double tol = 2.220446049250313e-15 * (double)k * hmax;
+  const bool active = t < k;
+  const unsigned long long tbit = 1ull << t;
+
+  for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
+    const double f = active ? (double)F[(int64_t)t * f_sk + prob * f_sp] : 0.0;
+    double x = 0.0, w = f;
+    double A[KR];
+#pragma unroll
+    for (int c = 0; c < KR; ++c) A[c] = 0.0;
+    unsigned long long pm = 0ull, ban = 0ull;   // passive set / numerically rejected (wave-uniform)
+
+    for (int outer = 0; outer < 3 * k + 3; ++outer) {
+      // ---- most violated dual: j = argmax w over the active (zero) set ----
+      double best = (active && !((pm | ban) & tbit)) ? w : -1.0e300;
+      int bi = t;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (!(best > tol)) break;
+      const int j = __builtin_amdgcn_readfirstlane(bi);
+
+      // ---- border the inverse with variable j: u = A h_P, sigma = HA[j][j] - h_P' u ----
+      const double h = sH[j * KR + (t < KR ? t : 0)];   // HA[j][t] = HA[t][j]
+      double u = 0.0;
+#pragma unroll
+      for (int c = 0; c < KR; ++c)
+        if ((pm >> c) & 1ull) u = fma(A[c], readlane_f64(h, c), u);
+      const bool pas = (pm & tbit) != 0ull;
+      const double hjj = readlane_f64(h, j);
+      const double sig = hjj - wave_sum_f64(pas ? h * u : 0.0);
+      if (!(sig > 1e-13 * hjj)) { ban |= 1ull << j; continue; }   // numerically dependent column
+      const double inv = 1.0 / sig;
+#pragma unroll
+      for (int c = 0; c < KR; ++c) {
+        if ((pm >> c) & 1ull) {
+          const double uc = readlane_f64(u, c);
+          if (pas) A[c] = fma(u * inv, uc, A[c]);
+          if (t == j) A[c] = -uc * inv;
+        } else if (c == j) {
+          if (pas) A[c] = -u * inv;
+          if (t == j) A[c] = inv;
+        }
+      }
+      pm |= 1ull << j;
+
+      // ---- inner loop: unconstrained optimum on the passive set, step back if infeasible ----
+      for (int inner = 0; inner < k + 2; ++inner) {
+        const bool pin = (pm & tbit) != 0ull;
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < KR; ++c)
+          if ((pm >> c) & 1ull) s = fma(A[c], readlane_f64(f, c), s);
+        if (!pin) s = 0.0;
+        const bool bad = pin && !(s > 0.0);
+        if (__ballot(bad) == 0ull) { x = s; break; }
+        const double ratio = bad ? x / (x - s) : 1.0e300;
+        double alpha = wave_min_f64(ratio);
+        if (!(alpha >= 0.0)) alpha = 0.0;
+        if (alpha > 1.0) alpha = 1.0;
+        x = pin ? fma(alpha, s - x, x) : 0.0;
+        double xmax = x;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o, 64));
+        const double tiny = 1e-15 * fmax(1.0, xmax);
+        // leave: everything that hit zero (at least the variable that defined alpha)
+        unsigned long long rm = __ballot(pin && (x <= tiny || (bad && ratio == alpha)));
+        while (rm) {
+          const int r = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rm));
+          rm &= rm - 1ull;
+          double colr = 0.0;                     // inv[t][r]
+#pragma unroll
+          for (int c = 0; c < KR; ++c)
+            if (c == r) colr = A[c];
+          const double arr = readlane_f64(colr, r);
+          const double scale = colr / arr;
+          const bool pt = (pm & tbit) != 0ull;
+#pragma unroll
+          for (int c = 0; c < KR; ++c) {
+            if ((pm >> c) & 1ull) {
+              const double arc = readlane_f64(A[c], r);   // inv[r][c]
+              if (pt && t != r && c != r) A[c] = fma(-scale, arc, A[c]);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < KR; ++c) {
+            if (c == r || t == r) A[c] = 0.0;
+          }
+          pm &= ~(1ull << r);
+          if (t == r) x = 0.0;
+        }
+      }
+
+      // ---- dual w = f - HA x over the passive set ----
+      w = f;
+#pragma unroll
+      for (int c = 0; c < KR; ++c)
+        if ((pm >> c) & 1ull) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
+    }
+    if (active) X[(int64_t)t * x_sk + prob * x_sp] = (float)((pm & tbit) ? x : 0.0);
+  }
+}
+
+// F(var, prob) = F[var * f_sk + prob * f_sp]; X likewise.  Hd: [KP][KP] float64.
+static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, const float* F, int64_t f_sk,
+                              int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob) {
+  if (k > 64) return PMF_EINVAL;
+  const int KR = k <= 16 ? 16 : k <= 32 ? 32 : 64;
+  const size_t smem = (size_t)KR * KR * sizeof(double);
+  int64_t blocks = (nprob + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  switch (KR) {
+    case 16: hipLaunchKernelGGL((k_nnqp<16>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob); break;
+    case 32: hipLaunchKernelGGL((k_nnqp<32>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob); break;
+    default: hipLaunchKernelGGL((k_nnqp<64>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob); break;
+  }
+  return PMF_OK;
+}

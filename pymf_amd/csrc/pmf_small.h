@@ -22,10 +22,8 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
       hb[r][c] = H[(int64_t)(rb + r) * ldh + c0 + c];
     }
     __syncthreads();
-    float s = 0.f;   // 64-term f32 chain per panel, panels summed in f64
 #pragma unroll 16
-    for (int c = 0; c < 64; ++c) s = fmaf(ha[a][c], hb[b][c], s);
-    acc += (double)s;
+    for (int c = 0; c < 64; ++c) acc = fma((double)ha[a][c], (double)hb[b][c], acc);
     __syncthreads();
   }
   const int ga = ra + a, gb = rb + b;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
   int64_t r_end = r_begin + rows_per_chunk;
   if (r_end > mp) r_end = mp;
   const int c0 = blockIdx.y * 256 + 64 * wv;
-  const bool pact = c0 < np;
+  const bool pact = (V != nullptr) && c0 < np;   // V == nullptr: S only (CSR path)
   const bool sact = blockIdx.y == 0;
 
   f32x4 P[NT][4];

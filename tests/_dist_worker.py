@@ -1,0 +1,52 @@
+"""world_size-2 worker (gloo, CPU): the rendezvous plumbing of pymf_amd.dist and the
+row-sharded formulation of one NMF iteration: rows of V/W are independent
+given H; update_h needs only the SUM over ranks of (W_r^T V_r | W_r^T W_r)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pymf_amd import dist          # noqa: E402
+from oracle import NMFOracle, nmf_update_w      # noqa: E402
+
+
+def main():
+    fake_id = bytes((7 * i + 3) % 251 for i in range(128))
+    w = dist.init_from_env(make_nccl_id=lambda: fake_id)
+    assert w.size == int(os.environ["WORLD_SIZE"]) and w.rank == int(os.environ["RANK"])
+    assert w.nccl_id == fake_id, "rank 0's unique id must reach every rank unchanged"
+    m, n, k = 203, 40, 6
+    lo, hi = w.row_range(m)
+    covered = dist.allreduce_sum_array(np.array([hi - lo], dtype=np.float64))
+    assert int(covered[0]) == m
+    V = np.random.RandomState(1).random_sample((m, n))
+    np.random.seed(2)
+    W0, H0 = np.random.random((m, k)), np.random.random((k, n))
+    # unsharded reference iteration
+    ref = NMFOracle(V, num_bases=k)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=1, compute_err=False)
+    # sharded: local update_w, all-reduce of the partials, identical H step on every rank
+    Vr, Wr, H = V[lo:hi], W0[lo:hi].copy(), H0.copy()
+    nmf_update_w(Vr, Wr, H)
+    ps = np.concatenate([Wr.T.dot(Vr), Wr.T.dot(Wr)], axis=1)
+    ps = dist.allreduce_sum_array(ps)
+    P, S = ps[:, :n], ps[:, n:]
+    H = (H * P) / (S.dot(H) + 1e-9)
+    assert np.allclose(Wr, ref.W[lo:hi], rtol=1e-12, atol=0)
+    assert np.allclose(H, ref.H, rtol=1e-10, atol=0)
+    # H must be bit-identical on all ranks (same reduced inputs + same arithmetic)
+    hsum = dist.allreduce_sum_array(H.copy())
+    assert np.array_equal(hsum, H * w.size) or np.allclose(hsum, H * w.size, rtol=1e-15)
+    dist.barrier()
+    t = dist.allreduce_max(float(w.rank + 1))
+    assert t == float(w.size)
+    dist.shutdown()
+    print("rank %d ok" % w.rank)
+
+
+if __name__ == "__main__":
+    main()
