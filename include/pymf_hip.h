@@ -65,6 +65,7 @@ int pmf_nccl_unique_id(void* out);
  *   n         columns of V (= columns of H), identical on all ranks
  *   k         num_bases
  *   rank,nranks,nccl_id   RCCL world; nranks==1 -> nccl_id may be NULL and RCCL is not touched
+ *                         (a non-NULL id with nranks==1 creates a 1-rank communicator)
  */
 int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int32_t k,
                    int32_t device, int32_t rank, int32_t nranks, const void* nccl_id);

@@ -181,7 +181,7 @@ int reduce_slabs(pmf_ctx* c, int nslabs, int sym) {
 }
 
 int allreduce_ps(pmf_ctx* c) {
-  if (c->nranks > 1)
+  if (c->comm)
     NCCLCHK(c, ncclAllReduce(c->dPS, c->dPS, (size_t)ps_elems(c), ncclFloat, ncclSum, c->comm, c->stream));
   return PMF_OK;
 }
@@ -366,7 +366,7 @@ int do_frobenius(pmf_ctx* c, double* out) {
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
   HIPCHK(c, hipGetLastError());
-  if (c->nranks > 1)
+  if (c->comm)
     NCCLCHK(c, ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream));
   double ss = 0.0;
   HIPCHK(c, hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -453,7 +453,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
-    if (nranks > 1) {
+    if (nccl_id) {   // nranks == 1 with an id: a 1-rank communicator (exercises the RCCL path)
       ncclUniqueId id;
       std::memcpy(&id, nccl_id, sizeof(id));
       NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));

@@ -172,3 +172,47 @@ def test_linearity_property_large(pm):
     b.W, b.H = W0.copy(), (2.0 * H0)
     b.update_w()
     assert rel_fro(2.0 * b.W, a.W) < 1e-6
+
+
+def test_rccl_path_single_rank_communicator(pm):
+    """The per-iteration ncclAllReduce of (W^T V | W^T W) and of the residual scalar, run through
+    a 1-rank RCCL communicator: results must equal the communicator-free context bit for bit."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(8)
+    m, n, k = 4096, 256, 64
+    V = rs.random_sample((m, n)).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    outs = []
+    for nid in (None, _lib.nccl_unique_id()):
+        ctx = _lib.Context(_lib.ALGO_NMF, m, n, k, device=0, rank=0, nranks=1, nccl_id=nid)
+        ctx.set_v_dense(V)
+        ctx.set_w(W0)
+        ctx.set_h(H0)
+        ferr, done, conv = ctx.factorize(4)
+        outs.append((ctx.get_w(), ctx.get_h(), ferr))
+        ctx.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+
+
+def test_fused_and_tiled_paths_agree(pm):
+    """The one-pass fused kernel and the two-pass tiled kernels implement the same iteration."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(12)
+    m, n, k = 8192, 256, 64
+    V = rs.random_sample((m, n)).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    a = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    assert a.path_name.startswith("k_nmf_fused")
+    a.set_v_dense(V); a.set_w(W0); a.set_h(H0)
+    a.factorize(3, compute_err=False)               # fused
+    b = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    b.set_v_dense(V); b.set_w(W0); b.set_h(H0)
+    for _ in range(3):                               # hooks -> tiled kernels
+        b.update_w()
+        b.update_h()
+    assert rel_fro(a.get_w(), b.get_w()) < 2e-6
+    assert rel_fro(a.get_h(), b.get_h()) < 2e-6
