@@ -59,6 +59,9 @@ struct pmf_ctx {
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
+  bool ps_valid = false;        // dPS = (W^T V | W^T W) of the CURRENT W, summed over all ranks
+  bool vnorm_valid = false;
+  double vnorm2 = 0.0;          // ||V||_F^2 over all ranks
   bool profile = false;
   double last_loop_ms = 0.0;
   KernelStat stat;
@@ -259,6 +262,7 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
                        (int64_t)c->np, c->np, c->KP, c->dPS);
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
+  c->ps_valid = true;    // dPS belongs to the current W (update_h never touches W)
   return PMF_OK;
 }
 
@@ -275,6 +279,7 @@ int nmf_update_h(pmf_ctx* c) {
 
 // One pass over V doing update_w AND the partials for update_h (pmf_fused.h).
 int nmf_fused_iteration(pmf_ctx* c) {
+  c->ps_valid = false;
   PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
   const int lrc = launch_fused(c->stream, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab);
@@ -333,10 +338,12 @@ int als_update_h(pmf_ctx* c) {
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
+  c->ps_valid = true;
   return PMF_OK;
 }
 
 int do_update_w(pmf_ctx* c) {
+  c->ps_valid = false;
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_w(c);
     case PMF_ALGO_SNMF: return snmf_update_w(c);
@@ -354,7 +361,7 @@ int do_update_h(pmf_ctx* c) {
   return fail(c, PMF_EINVAL, "bad algo");
 }
 
-int do_frobenius(pmf_ctx* c, double* out) {
+int frobenius_direct(pmf_ctx* c, double* out) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
   const int nb = (int)(c->mp / 64);
   switch (c->NT) {
@@ -372,6 +379,43 @@ int do_frobenius(pmf_ctx* c, double* out) {
   HIPCHK(c, hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = std::sqrt(ss);
+  return PMF_OK;
+}
+
+int ensure_vnorm(pmf_ctx* c) {
+  if (c->vnorm_valid) return PMF_OK;
+  const int nb = 1024;
+  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->mp * c->np, c->dPart);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+  HIPCHK(c, hipGetLastError());
+  if (c->comm) NCCLCHK(c, ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->vnorm2, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->vnorm_valid = true;
+  return PMF_OK;
+}
+
+// sqrt(sum((V - W H)^2)) (nmf.py:110).  When the partial sums P = W^T V, S = W^T W of the current
+// W are at hand (every iteration that ran update_h), the trace identity
+// ||V||^2 - 2<P,H> + <S H,H> gives the same number from k x n sized data in float64 -- no third
+// pass over V and, across ranks, no extra collective (P, S are already all-reduced).  The identity
+// cancels when the fit is nearly exact; below 1e-3 relative residual energy the direct pass runs.
+int do_frobenius(pmf_ctx* c, double* out) {
+  if (c->v_csr || !c->ps_valid) return frobenius_direct(c, out);
+  PMFCHK(ensure_vnorm(c));
+  const int nb = c->np / 16;
+  hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
+                     c->dH, (int64_t)c->np, c->np, c->KP, c->dPS, c->dPart);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+  HIPCHK(c, hipGetLastError());
+  double t[2] = {0.0, 0.0};
+  HIPCHK(c, hipMemcpyAsync(t, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const double e2 = c->vnorm2 - 2.0 * t[0] + t[1];
+  if (!(e2 > 1e-3 * c->vnorm2)) return frobenius_direct(c, out);
+  *out = std::sqrt(e2);
   return PMF_OK;
 }
 
@@ -474,7 +518,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dGd, (size_t)c->KP * c->KP));
     PMFCHK(dalloc(c, &c->dPS, (size_t)ps_elems(c)));
     PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
-    PMFCHK(dalloc(c, &c->dPart, (size_t)(c->mp / 64)));
+    PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
     PMFCHK(dalloc(c, &c->dScal, 8));
     if (algo != PMF_ALGO_NMF) {
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
@@ -518,7 +562,7 @@ int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
-  c->have_v = true; c->v_csr = false;
+  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false;
   return PMF_OK;
 }
 
@@ -541,7 +585,7 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
     HIPCHK(c, hipMemcpyAsync(c->dVals, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->nnz = nnz; c->have_v = true; c->v_csr = true;
+  c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->ps_valid = false;
   return PMF_OK;
 }
 
@@ -558,19 +602,19 @@ static int fill(pmf_ctx* c, float* X, int64_t ld, int64_t rows, int64_t cols, in
 int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
-  c->have_v = true; c->v_csr = false;
+  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false;
   return PMF_OK;
 }
 int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dW, c->KP, c->m, c->k, row0, seed));
-  c->have_w = true;
+  c->have_w = true; c->ps_valid = false;
   return PMF_OK;
 }
 int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dH, c->np, c->k, c->n, 0, seed));
-  c->have_h = true; c->g_valid = false;
+  c->have_h = true; c->g_valid = false; c->ps_valid = false;
   return PMF_OK;
 }
 
@@ -578,7 +622,7 @@ int pmf_set_w_f32(pmf_ctx* c, const float* W) {
   if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dW, c->KP, W, c->k, c->m, c->k));
-  c->have_w = true;
+  c->have_w = true; c->ps_valid = false;
   return PMF_OK;
 }
 int pmf_get_w_f32(pmf_ctx* c, float* W) {
@@ -590,7 +634,7 @@ int pmf_set_h_f32(pmf_ctx* c, const float* H) {
   if (!c || !H) return fail(c, PMF_EINVAL, "pmf_set_h_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false;
+  c->have_h = true; c->g_valid = false; c->ps_valid = false;
   return PMF_OK;
 }
 int pmf_get_h_f32(pmf_ctx* c, float* H) {

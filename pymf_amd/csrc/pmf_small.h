@@ -152,6 +152,71 @@ __global__ __launch_bounds__(256) void k_inverse(const double* __restrict__ Gd, 
   }
 }
 
+// Per-block float64 partials of sum(X^2) over a padded [rows][ld] buffer (padding is zero).
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ X, int64_t count,
+                                               double* __restrict__ part) {
+  __shared__ double ws[4];
+  double s = 0.0;
+  const int64_t n4 = count >> 2;
+  const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    const f32x4 v = X4[q];
+    s += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+  }
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// Trace identity for the residual: with P = W^T V, S = W^T W of the CURRENT W,
+//   ||V - W H||^2 = ||V||^2 - 2 <P, H> + <S H, H>.
+// One block per 16 columns of H; part[2*b] = sum P.H, part[2*b+1] = sum (S H).H, float64.
+__global__ __launch_bounds__(256) void k_trace_terms(const float* __restrict__ H, int64_t ldh, int np,
+                                                     int KP, const float* __restrict__ PS,
+                                                     double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
+  __shared__ double w1[4], w2[4];
+  const int tid = threadIdx.x;
+  const int c = tid & 15;
+  const int col = blockIdx.x * 16 + c;
+  const int64_t ldp = (int64_t)np + KP;
+  for (int kk = tid >> 4; kk < KP; kk += 16) hs[kk * 16 + c] = H[(int64_t)kk * ldh + col];
+  __syncthreads();
+  double t1 = 0.0, t2 = 0.0;
+  for (int kk = tid >> 4; kk < KP; kk += 16) {
+    const float* srow = PS + (int64_t)kk * ldp + np;
+    double sh = 0.0;
+    for (int j = 0; j < KP; ++j) sh = fma((double)srow[j], (double)hs[j * 16 + c], sh);
+    const double h = (double)hs[kk * 16 + c];
+    t1 = fma((double)PS[(int64_t)kk * ldp + col], h, t1);
+    t2 = fma(sh, h, t2);
+  }
+  t1 = wave_sum_f64(t1);
+  t2 = wave_sum_f64(t2);
+  if ((tid & 63) == 0) { w1[tid >> 6] = t1; w2[tid >> 6] = t2; }
+  __syncthreads();
+  if (tid == 0) {
+    part[2 * blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3];
+    part[2 * blockIdx.x + 1] = w2[0] + w2[1] + w2[2] + w2[3];
+  }
+}
+
+// out[0] = sum of part[0], part[2], ...; out[1] = sum of part[1], part[3], ... (n pairs)
+__global__ void k_sum_pairs_f64(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double ws[2][4];
+  double a = 0.0, b = 0.0;
+  for (int q = threadIdx.x; q < n; q += 256) { a += part[2 * q]; b += part[2 * q + 1]; }
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = a; ws[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
+    out[1] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+  }
+}
+
 // sum of part[0..n) in float64, fixed order; out[0] = sum.
 __global__ void k_sum_f64(const double* __restrict__ part, int n, double* __restrict__ out) {
   __shared__ double ws[4];
