@@ -175,10 +175,10 @@ int colgemm(pmf_ctx* c, bool with_v = true) {
 
 int64_t ps_elems(const pmf_ctx* c) { return (int64_t)c->KP * (c->np + c->KP); }
 
-int reduce_slabs(pmf_ctx* c, int nslabs, int sym) {
-  const int64_t E = ps_elems(c);
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, c->stream,
-                     c->dSlab, nslabs, c->KP, c->np, sym, c->dPS);
+int reduce_slabs(pmf_ctx* c, int nslabs) {
+  const int64_t E = ps_elems(c);      // multiple of 4 (KP and np are multiples of 16)
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E / 4 + 63) / 64)), dim3(1024), 0, c->stream,
+                     c->dSlab, nslabs, E, c->dPS);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -223,7 +223,7 @@ int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by
     hipLaunchKernelGGL((k_csr_p<2>), dim3((unsigned)c->nchunks), dim3(256), smem, c->stream, c->dIndptr,
                        c->dIndices, c->dVals, c->mp, c->rows_per_chunk, c->KP, c->np, c->dW, c->dSlab);
   HIPCHK(c, hipGetLastError());
-  return reduce_slabs(c, c->nchunks, 0);
+  return reduce_slabs(c, c->nchunks);
 }
 
 int ensure_gram(pmf_ctx* c, double pad_diag) {
@@ -251,8 +251,49 @@ int nmf_update_w(pmf_ctx* c) {
   return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
 }
 
+template <int NT, int NPANEL>
+int launch_h_gram(pmf_ctx* c) {
+  constexpr size_t smem = (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * (64 * NPANEL + 4)) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, NPANEL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
+                     c->dG, c->dGd);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+// NMF on the fused-kernel shapes: H step and G = H H^T in one launch.  false: shape not covered.
+bool nmf_h_gram(pmf_ctx* c, int* rc) {
+  if (c->algo != PMF_ALGO_NMF) return false;
+  const int key = c->NT * 10 + c->np / 64;
+  if (c->np % 64) return false;
+  switch (key) {
+    case 11: *rc = launch_h_gram<1, 1>(c); return true;
+    case 12: *rc = launch_h_gram<1, 2>(c); return true;
+    case 14: *rc = launch_h_gram<1, 4>(c); return true;
+    case 21: *rc = launch_h_gram<2, 1>(c); return true;
+    case 22: *rc = launch_h_gram<2, 2>(c); return true;
+    case 24: *rc = launch_h_gram<2, 4>(c); return true;
+    case 41: *rc = launch_h_gram<4, 1>(c); return true;
+    case 42: *rc = launch_h_gram<4, 2>(c); return true;
+    case 44: *rc = launch_h_gram<4, 4>(c); return true;
+  }
+  return false;
+}
+
 int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
   PMFCHK(allreduce_ps(c));
+  int hrc = PMF_OK;
+  if (nmf_h_gram(c, &hrc)) {
+    PMFCHK(hrc);
+    c->g_valid = true;     // G (pad rows/cols are zero because the padded H rows are zero)
+    c->ps_valid = true;
+    return PMF_OK;
+  }
   const size_t smem = (size_t)c->KP * 16 * sizeof(float);
   if (c->algo == PMF_ALGO_SNMF)
     hipLaunchKernelGGL(k_snmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
@@ -269,7 +310,7 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
 int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
   if (c->v_csr) return csr_ps(c);
   PMFCHK(colgemm(c));
-  return reduce_slabs(c, c->nchunks, 0);
+  return reduce_slabs(c, c->nchunks);
 }
 
 int nmf_update_h(pmf_ctx* c) {
@@ -286,7 +327,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
-  PMFCHK(reduce_slabs(c, c->fused_wgs, 1));
+  PMFCHK(reduce_slabs(c, c->fused_wgs));
   return h_step_from_ps(c);
 }
 

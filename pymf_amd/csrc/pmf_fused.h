@@ -83,21 +83,6 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   float* sV = sVall + wv * (NPANEL * 1024);
   float* sW = sWall + wv * 1024;
 
-  // ---- H and G into LDS (whole workgroup, once) ----
-  for (int q = tid; q < NPANEL * KP * 16; q += 256) {
-    const int p = q / (KP * 16), rem = q % (KP * 16);
-    const int row = rem >> 4, c = rem & 15;
-    lds_write4(sH + p * (KP * 64), row, c,
-               *reinterpret_cast<const f32x4*>(H + (int64_t)row * NP + 64 * p + 4 * c));
-  }
-  for (int q = tid; q < KP * 16; q += 256) {
-    const int row = q >> 4, c = q & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (4 * c < KP) v = *reinterpret_cast<const f32x4*>(G + row * KP + 4 * c);
-    lds_write4(sG, row, c, v);
-  }
-  __syncthreads();
-
   // ---- this wave's contiguous range of 16-row blocks (all scalar) ----
   const int gw = blockIdx.x * 4 + wv;
   const int b0 = gw * blk_per + (gw < blk_extra ? gw : blk_extra);
@@ -141,6 +126,23 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
       for (int q = 0; q < 4; ++q) issue_v(b0, p, q);
   }
+
+  // (the first block's DMA is already in flight while H and G are staged)
+  // ---- H and G into LDS (whole workgroup, once) ----
+  for (int q = tid; q < NPANEL * KP * 16; q += 256) {
+    const int p = q / (KP * 16), rem = q % (KP * 16);
+    const int row = rem >> 4, c = rem & 15;
+    lds_write4(sH + p * (KP * 64), row, c,
+               *reinterpret_cast<const f32x4*>(H + (int64_t)row * NP + 64 * p + 4 * c));
+  }
+  for (int q = tid; q < KP * 16; q += 256) {
+    const int row = q >> 4, c = q & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (4 * c < KP) v = *reinterpret_cast<const f32x4*>(G + row * KP + 4 * c);
+    lds_write4(sG, row, c, v);
+  }
+  __syncthreads();
+
 
   // Fragment double buffers: step s+1's LDS reads are issued before step s's MFMAs.
   f32x4 fa[2];
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
 
   // ---- sum the 4 waves' accumulators through LDS (tree), wave 0 writes the slab ----
-  // Slab tiles: P (NT x NTP) then the upper-triangular S tiles (nt >= mt); tiles below the
-  // diagonal of S are never written -- k_reduce_slabs mirrors them (sym = 1).
+  // S is accumulated on/above the diagonal only; wave 0 writes the mirrored tiles too, so the
+  // slab holds the full symmetric S.
   constexpr int NTILE = NT * (NTP + NT);
   __syncthreads();
   f32x4* ex = reinterpret_cast<f32x4*>(smem);   // two regions of NTILE*64 f32x4
@@ -374,6 +376,13 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
         for (int nt = mt; nt < NT; ++nt) rowp[NP + 16 * nt + i] = S[mt][nt][j];
       }
+    // mirror: element (16mt+4kq+j, 16nt+i) of tile (mt,nt), nt > mt, also is (16nt+i, 16mt+4kq+j):
+    // the lane's 4 registers are 4 consecutive floats of row 16nt+i
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = mt + 1; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(base + (int64_t)(16 * nt + i) * ldp + NP + 16 * mt + 4 * kq) = S[mt][nt];
   }
 }
 

@@ -53,6 +53,110 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
   }
 }
 
+// NMF H step AND the Gram matrix of the new H in ONE single-workgroup launch (16 waves, MFMA):
+//   H <- (H * P) / (S H + 1e-9)   (pymf/nmf.py:122-126),  then  G = H H^T  (operand of the next
+//   update_w, nmf.py:130 reassociated).  Both are k x k x n sized: one CU does them in a few
+// microseconds, and the iteration loses two kernel boundaries.  Wave w owns columns
+// [16w, 16w+16) of H for the H step (it reads and rewrites only those columns of the LDS image, so
+// no barrier is needed inside the step) and one 16x16 tile of G afterwards.
+// LDS rows are padded by 4 floats: fragment reads (16 lanes on 16 rows) are conflict-free b128.
+template <int NT, int NPANEL>
+__global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
+                                                     const float* __restrict__ PS,
+                                                     float* __restrict__ Gf, double* __restrict__ Gd) {
+  constexpr int KP = 16 * NT, NP = 64 * NPANEL, NCT = NP / 16;
+  constexpr int LDS_S = KP + 4, LDS_H = NP + 4;
+  constexpr int64_t ldp = NP + KP;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* ss = sm;                    // [KP][KP+4]
+  float* hs = sm + KP * LDS_S;       // [KP][NP+4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  // this wave's P values (accumulator layout) are fetched up front, in the same round trip as the
+  // LDS staging loads, so the H step never waits on global memory again
+  constexpr int NCTW = (NCT + 15) / 16;
+  float pv[NCTW][NT][4];
+#pragma unroll
+  for (int cw = 0; cw < NCTW; ++cw)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ct = wv + 16 * cw;
+        pv[cw][mt][r] = ct < NCT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + 16 * ct + i] : 0.f;
+      }
+  for (int q = tid; q < KP * (KP / 4); q += 1024) {
+    const int r = q / (KP / 4), c4 = q % (KP / 4);
+    *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) =
+        *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + NP + 4 * c4);
+  }
+  for (int q = tid; q < KP * (NP / 4); q += 1024) {
+    const int r = q / (NP / 4), c4 = q % (NP / 4);
+    *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) =
+        *reinterpret_cast<const f32x4*>(H + (int64_t)r * NP + 4 * c4);
+  }
+  __syncthreads();
+  // ---- H step: wave w <-> column tiles w, w+16, ... ----
+#pragma unroll
+  for (int cw = 0; cw < NCTW; ++cw) {
+    const int ct = wv + 16 * cw;
+    if (ct >= NCT) break;
+    float bfr[NT][4];                 // B[k = 16t+4kq+e][col = 16ct+i] = H[k][col]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bfr[t][e] = hs[(16 * t + 4 * kq + e) * LDS_H + 16 * ct + i];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      f32x4 den = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) den = mfma16(a4[e], bfr[t][e], den);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
+        const float h = hs[kk * LDS_H + col];
+        den[r] = (h * pv[cw][mt][r]) / (den[r] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:125-126)
+      }
+      // all of this wave's reads of its 16 columns for tile row mt happened above; rows of other
+      // mt are still needed as B fragments -> they were captured in bfr before the mt loop
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
+        H[(int64_t)kk * NP + col] = den[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
+        hs[kk * LDS_H + col] = den[r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- G = H H^T: wave w <-> tile (w / NT, w % NT) ----
+  if (wv < NT * NT) {
+    const int mt = wv / NT, nt = wv % NT;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = 0; t < NP / 16; ++t) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (16 * mt + i) * LDS_H + 16 * t + 4 * kq);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(hs + (16 * nt + i) * LDS_H + 16 * t + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g = mfma16(a4[e], b4[e], g);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * mt + 4 * kq + r, b = 16 * nt + i;
+      Gf[a * KP + b] = g[r];
+      if (Gd) Gd[a * KP + b] = (double)g[r];
+    }
+  }
+}
+
 // SNMF H step (pymf/snmf.py:72-91) with XW = P^T (P = W^T V) and WW = S = W^T W:
 //   H1 = pos(XW)^T + (H^T neg(WW))^T,  H2 = neg(XW)^T + (H^T pos(WW))^T + 1e-9,
 //   H *= sqrt(H1 / H2).

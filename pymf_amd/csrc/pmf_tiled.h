@@ -211,31 +211,31 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
 }
 
 // out[e] = sum over slabs of slab[c][e], fixed order, float64 accumulation.
-// One block = 64 consecutive elements; wave w sums slabs w, w+4, ... (coalesced 256-B
-// reads), the four partials are combined in wave order.  sym != 0: the S part holds only
-// the tiles on/above the diagonal (fused kernel) -- an element below reads its mirror.
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab, int nslabs,
-                                                      int KP, int np, int sym,
-                                                      float* __restrict__ out) {
-  __shared__ double part[4][64];
+// One block (1024 threads) = 256 consecutive elements as 64 float4; wave w sums slabs
+// w, w+16, ... (coalesced 1-KiB reads), the 16 partials are combined in wave order.
+__global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__ slab, int nslabs,
+                                                       int64_t E, float* __restrict__ out) {
+  __shared__ double part[16][64][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ldp = (int64_t)np + KP;
-  const int64_t E = (int64_t)KP * ldp;
-  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-  double s = 0.0;
-  if (e < E) {
-    int64_t src = e;
-    if (sym) {
-      const int r = (int)(e / ldp), c = (int)(e % ldp) - np;
-      if (c >= 0 && (r >> 4) > (c >> 4)) src = (int64_t)c * ldp + np + r;   // S[r][c] = S[c][r]
+  const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;      // float4 index
+  const int64_t E4 = E >> 2;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e4 < E4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e4;
+#pragma unroll 4
+    for (int c = wv; c < nslabs; c += 16) {
+      const f32x4 v = p[(int64_t)c * E4];
+      s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
     }
-    const float* p = slab + src;
-#pragma unroll 8
-    for (int c = wv; c < nslabs; c += 4) s += (double)p[(int64_t)c * E];
   }
-  part[wv][lane] = s;
+  part[wv][lane][0] = s0; part[wv][lane][1] = s1; part[wv][lane][2] = s2; part[wv][lane][3] = s3;
   __syncthreads();
-  if (wv == 0 && e < E) out[e] = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+  if (wv < 4 && e4 < E4) {        // wave q combines component q of the 64 float4
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane][wv];
+    out[4 * e4 + wv] = (float)t;
+  }
 }
 
 // Partial sums of (V - W H)^2 for 64 rows per block; part[block] in float64.
