@@ -327,7 +327,13 @@ int nmf_fused_iteration(pmf_ctx* c) {
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
-  PMFCHK(reduce_slabs(c, c->fused_wgs));
+  {
+    const int NTP = c->np / 16;
+    const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
+    hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS);
+    HIPCHK(c, hipGetLastError());
+  }
   return h_step_from_ps(c);
 }
 

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   // DMA of the next block's V panel p is spread over phase B's panel p+1 steps and the last
   // panel over the next phase A's first steps (one LDS-DMA per 16 MFMAs) -- needs 4 panels.
   constexpr bool SPREAD = (NPANEL == 4);
+#ifdef PMF_STAMPS
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+  PMF_STAMP(tk0);
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                             // [NPANEL][KP][64]   swizzled rows
   float* sG = sH + NPANEL * KP * 64;            // [KP][64]
@@ -127,22 +131,25 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       for (int q = 0; q < 4; ++q) issue_v(b0, p, q);
   }
 
-  // (the first block's DMA is already in flight while H and G are staged)
-  // ---- H and G into LDS (whole workgroup, once) ----
-  for (int q = tid; q < NPANEL * KP * 16; q += 256) {
-    const int p = q / (KP * 16), rem = q % (KP * 16);
-    const int row = rem >> 4, c = rem & 15;
-    lds_write4(sH + p * (KP * 64), row, c,
-               *reinterpret_cast<const f32x4*>(H + (int64_t)row * NP + 64 * p + 4 * c));
+  // ---- H and G into LDS by LDS-DMA as well (whole workgroup, once): 4 rows x 256 B per
+  // instruction, all in flight together with the first block's V/W tiles ----
+  {
+    const int drow = lane >> 4, dchunk = lane & 15;
+    for (int d = wv; d < NPANEL * (KP / 4); d += 4) {          // H: panel p, rows 4rg..4rg+3
+      const int p = d / (KP / 4), rg = d % (KP / 4);
+      const int row = 4 * rg + drow;
+      const float* src = H + (size_t)row * NP + 64 * p + 4 * (dchunk ^ (row & 15));
+      PMF_GLDS16(src, sH + p * (KP * 64) + rg * 256);
+    }
+    for (int rg = wv; rg < KP / 4; rg += 4) {                  // G: rows 4rg..4rg+3
+      const int row = 4 * rg + drow;
+      int c = dchunk ^ (row & 15);
+      if (4 * c >= KP) c = 0;                                  // beyond k: valid, never read
+      PMF_GLDS16(G + row * KP + 4 * c, sG + rg * 256);
+    }
   }
-  for (int q = tid; q < KP * 16; q += 256) {
-    const int row = q >> 4, c = q & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (4 * c < KP) v = *reinterpret_cast<const f32x4*>(G + row * KP + 4 * c);
-    lds_write4(sG, row, c, v);
-  }
+  wait_vmcnt<0>();
   __syncthreads();
-
 
   // Fragment double buffers: step s+1's LDS reads are issued before step s's MFMAs.
   f32x4 fa[2];
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   constexpr int NSA = NSN + NT;        // + Den steps
 
 #ifdef PMF_STAMPS
+  PMF_STAMP(tk1);
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
   unsigned long long acc_wait = 0, acc_a = 0, acc_dma = 0, acc_epi = 0, acc_b = 0;
 #endif
@@ -316,10 +324,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #endif
   }
 #ifdef PMF_STAMPS
-  if (dbg && lane == 0) {
-    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
-    d[0] = acc_wait; d[1] = acc_a; d[2] = acc_dma; d[3] = acc_epi; d[4] = acc_b; d[5] = (unsigned long long)nb;
-  }
+  PMF_STAMP(tk2);
 #endif
   // S of the last block
 #pragma unroll
@@ -329,61 +334,56 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
       for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
 
-  // ---- sum the 4 waves' accumulators through LDS (tree), wave 0 writes the slab ----
-  // S is accumulated on/above the diagonal only; wave 0 writes the mirrored tiles too, so the
-  // slab holds the full symmetric S.
-  constexpr int NTILE = NT * (NTP + NT);
+  // ---- sum the 4 waves' accumulators through LDS, write ONE tile-major slab per workgroup ----
+  // Slab = NTU tiles of 64 lanes x float4 in the accumulator layout (P tiles, then the S tiles
+  // on/above the diagonal): every store is a coalesced 1-KiB b128 wave store, spread over all 4
+  // waves.  k_reduce_slabs_tiles sums the slabs and scatters to the row-major (P | S) buffer,
+  // mirroring S.
+  constexpr int NTU = NT * NTP + NT * (NT + 1) / 2;
   __syncthreads();
-  f32x4* ex = reinterpret_cast<f32x4*>(smem);   // two regions of NTILE*64 f32x4
-  static_assert((size_t)2 * NTILE * 64 * 16 <= fused_smem_bytes<NT, NPANEL>(), "exchange fits");
+  f32x4* ex = reinterpret_cast<f32x4*>(smem);   // two regions of NTU*64 f32x4
+  static_assert((size_t)2 * NTU * 64 * 16 <= fused_smem_bytes<NT, NPANEL>(), "exchange fits");
   auto put = [&](int region) {
-    f32x4* dst = ex + (size_t)region * NTILE * 64 + lane;
+    f32x4* dst = ex + (size_t)region * NTU * 64 + lane;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < NTP; ++nt) dst[(mt * (NTP + NT) + nt) * 64] = P[mt][nt];
+      for (int nt = 0; nt < NTP; ++nt) dst[(mt * NTP + nt) * 64] = P[mt][nt];
 #pragma unroll
-      for (int nt = mt; nt < NT; ++nt) dst[(mt * (NTP + NT) + NTP + nt) * 64] = S[mt][nt];
+      for (int nt = mt; nt < NT; ++nt)
+        dst[(NT * NTP + mt * NT - (mt * (mt - 1)) / 2 + (nt - mt)) * 64] = S[mt][nt];
     }
   };
   auto add = [&](int region) {
-    const f32x4* src = ex + (size_t)region * NTILE * 64 + lane;
+    const f32x4* src = ex + (size_t)region * NTU * 64 + lane;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < NTP; ++nt) P[mt][nt] += src[(mt * (NTP + NT) + nt) * 64];
+      for (int nt = 0; nt < NTP; ++nt) P[mt][nt] += src[(mt * NTP + nt) * 64];
 #pragma unroll
-      for (int nt = mt; nt < NT; ++nt) S[mt][nt] += src[(mt * (NTP + NT) + NTP + nt) * 64];
+      for (int nt = mt; nt < NT; ++nt)
+        S[mt][nt] += src[(NT * NTP + mt * NT - (mt * (mt - 1)) / 2 + (nt - mt)) * 64];
     }
   };
-  if (wv & 1) put(wv >> 1);
+  if (wv >= 2) put(wv - 2);
   __syncthreads();
-  if (!(wv & 1)) add(wv >> 1);
+  if (wv < 2) add(wv);
   __syncthreads();
-  if (wv == 2) put(0);
+  if (wv < 2) put(wv);
   __syncthreads();
-  if (wv == 0) {
-    add(0);
-    const int64_t ldp = (int64_t)NP + KP;
-    float* base = slab + (int64_t)blockIdx.x * KP * ldp;
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float* rowp = base + (int64_t)(16 * mt + 4 * kq + j) * ldp;
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) rowp[16 * nt + i] = P[mt][nt][j];
-#pragma unroll
-        for (int nt = mt; nt < NT; ++nt) rowp[NP + 16 * nt + i] = S[mt][nt][j];
-      }
-    // mirror: element (16mt+4kq+j, 16nt+i) of tile (mt,nt), nt > mt, also is (16nt+i, 16mt+4kq+j):
-    // the lane's 4 registers are 4 consecutive floats of row 16nt+i
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int nt = mt + 1; nt < NT; ++nt)
-        *reinterpret_cast<f32x4*>(base + (int64_t)(16 * nt + i) * ldp + NP + 16 * mt + 4 * kq) = S[mt][nt];
+  {
+    f32x4* out = reinterpret_cast<f32x4*>(slab) + (size_t)blockIdx.x * NTU * 64 + lane;
+    for (int t = wv; t < NTU; t += 4)
+      out[t * 64] = ex[t * 64 + lane] + ex[(size_t)NTU * 64 + t * 64 + lane];
   }
+#ifdef PMF_STAMPS
+  PMF_STAMP(tk3);
+  if (dbg && lane == 0) {
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+    d[0] = acc_wait; d[1] = acc_a; d[2] = acc_dma; d[3] = acc_epi; d[4] = acc_b; d[5] = (unsigned long long)nb;
+    d[6] = tk1 - tk0; d[7] = tk3 - tk2;
+  }
+#endif
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------

@@ -238,6 +238,47 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__
   }
 }
 
+// Fused-kernel slabs are tile-major (pmf_fused.h): block b sums tile b of every slab (float64,
+// fixed order, wave w takes slabs w, w+16, ...) and scatters it into the row-major (P | S)
+// buffer; S tiles above the diagonal are mirrored.
+__global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __restrict__ slab, int nslabs,
+                                                             int NT, int NTP, int np,
+                                                             float* __restrict__ out) {
+  __shared__ double part[16][64][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int KP = 16 * NT;
+  const int NTU = NT * NTP + NT * (NT + 1) / 2;
+  const int tile = blockIdx.x;
+  const f32x4* p = reinterpret_cast<const f32x4*>(slab) + (size_t)tile * 64 + lane;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+  for (int c = wv; c < nslabs; c += 16) {
+    const f32x4 v = p[(size_t)c * NTU * 64];
+    s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+  }
+  part[wv][lane][0] = s0; part[wv][lane][1] = s1; part[wv][lane][2] = s2; part[wv][lane][3] = s3;
+  __syncthreads();
+  if (wv < 4) {                      // wave r combines register r of the tile
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane][wv];
+    const float v = (float)t;
+    const int i = lane & 15, kq = lane >> 4, r = wv;
+    const int64_t ldp = (int64_t)np + KP;
+    if (tile < NT * NTP) {
+      const int mt = tile / NTP, nt = tile % NTP;
+      out[(int64_t)(16 * mt + 4 * kq + r) * ldp + 16 * nt + i] = v;
+    } else {
+      int sidx = tile - NT * NTP, mt = 0;
+      while (sidx >= NT - mt) { sidx -= NT - mt; ++mt; }
+      const int nt = mt + sidx;
+      const int row = 16 * mt + 4 * kq + r, col = 16 * nt + i;
+      out[(int64_t)row * ldp + np + col] = v;
+      if (nt > mt) out[(int64_t)col * ldp + np + row] = v;
+    }
+  }
+}
+
 // Partial sums of (V - W H)^2 for 64 rows per block; part[block] in float64.
 template <int NT>
 __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int64_t ldv, int np,
