@@ -340,14 +340,14 @@ int nmf_fused_iteration(pmf_ctx* c) {
 // ---- SNMF -----------------------------------------------------------------------------------
 int snmf_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
-  const size_t smem = ((size_t)c->k * c->k) * sizeof(double) + ((size_t)c->k + 1) * sizeof(int);
+  const size_t smem = ((size_t)c->k * c->k + 2 * (size_t)c->k) * sizeof(double) + ((size_t)c->k + 2) * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_inverse, dim3(1), dim3(256), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
+  hipLaunchKernelGGL(k_inverse, dim3(1), dim3(1024), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
   HIPCHK(c, hipGetLastError());
   if (c->v_csr) return csr_w(c);
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
