@@ -216,3 +216,75 @@ def test_fused_and_tiled_paths_agree(pm):
         b.update_h()
     assert rel_fro(a.get_w(), b.get_w()) < 2e-6
     assert rel_fro(a.get_h(), b.get_h()) < 2e-6
+
+
+def test_full_size_properties_cfg4(pm):
+    """BASELINE cfg4 size (1,048,576 x 256, k = 64), size-independent properties only:
+    (1) the Lee-Seung objective never increases under the multiplicative updates,
+    (2) the fused one-pass kernel and the two-pass tiled kernels agree on the same inputs,
+    (3) the trace-identity residual equals the direct residual pass,
+    (4) W, H stay non-negative and finite."""
+    from pymf_amd import _lib
+    m, n, k = 1048576, 256, 64
+    a = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    a.fill_v_uniform(1234); a.fill_w_uniform(42); a.fill_h_uniform(43)
+    assert a.path_name == "k_nmf_fused<4,4>"
+    ferr, done, conv = a.factorize(6, compute_err=True)          # fused + trace identity
+    assert done == 6 and conv < 0
+    assert np.all(np.diff(ferr) <= 1e-6 * ferr[0]), ferr          # (1)
+    b = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    b.fill_v_uniform(1234); b.fill_w_uniform(42); b.fill_h_uniform(43)
+    fb = []
+    for _ in range(6):                                            # hooks: tiled kernels + direct residual
+        b.update_w()
+        b.update_h()
+        b.set_h(b.get_h())                                        # invalidates (W^T V | W^T W): forces the direct pass
+        fb.append(b.frobenius())
+    np.testing.assert_allclose(ferr, np.array(fb), rtol=2e-6)     # (2) + (3)
+    Ha, Hb = a.get_h(), b.get_h()                                 # H depends on every row of W
+    assert rel_fro(Ha, Hb) < 5e-6
+    assert np.isfinite(Ha).all() and Ha.min() >= 0                # (4)
+    Wa = a.get_w()
+    assert float(Wa.min()) >= 0.0 and np.isfinite(float(Wa.sum(dtype=np.float64)))
+    Wb = b.get_w()
+    sl = slice(0, m, 4097)
+    assert rel_fro(Wa[sl], Wb[sl]) < 5e-6
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (1, 7, 2), (5, 1, 3), (3, 50, 4), (17, 9, 12), (64, 64, 64),
+                                   (65, 257, 65), (33, 300, 128)])
+def test_ragged_and_tiny_shapes(pm, m, n, k):
+    """Edge shapes: single row/column, k > n, k > m, sizes straddling every padding boundary."""
+    from oracle import NMFOracle
+    rs = np.random.RandomState(100 + m + n + k)
+    V = rs.random_sample((m, n)).astype(np.float32) + 0.05
+    W0, H0 = rs.random_sample((m, k)) + 0.05, rs.random_sample((k, n)) + 0.05
+    mdl = _run(pm.NMF, V, k, 4, W0, H0)
+    ref = NMFOracle(V, num_bases=k)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=4)
+    assert mdl.W.shape == (m, k) and mdl.H.shape == (k, n)
+    assert rel_fro(mdl.W, ref.W) < 5e-5 and rel_fro(mdl.H, ref.H) < 5e-5
+    if ref.ferr[-1] > 1e-5 * np.linalg.norm(V):
+        np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=2e-4, atol=1e-6)
+    else:
+        # rank(V) <= k: the fit is exact and the residual is pure rounding noise (float32 here,
+        # float64 in the reference), so neither its digits nor the early-exit iteration are comparable
+        assert mdl.ferr[-1] < 1e-6 * max(1.0, np.linalg.norm(V))
+
+
+def test_zero_rows_and_columns(pm):
+    """All-zero rows/columns of V drive the matching W rows / H columns to exactly 0 (0*x/(d+1e-9))."""
+    from oracle import NMFOracle
+    rs = np.random.RandomState(5)
+    V = rs.random_sample((70, 40)).astype(np.float32)
+    V[10:20, :] = 0.0
+    V[:, 5] = 0.0
+    W0, H0 = rs.random_sample((70, 6)), rs.random_sample((6, 40))
+    mdl = _run(pm.NMF, V, 6, 5, W0, H0)
+    ref = NMFOracle(V, num_bases=6)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=5)
+    assert np.all(mdl.W[10:20] == 0.0) and np.all(mdl.H[:, 5] == 0.0)
+    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
