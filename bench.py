@@ -26,6 +26,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -109,6 +111,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fill", choices=["numpy", "device"], default="numpy",
                     help="numpy: BASELINE.md protocol; device: counter-based fill (fast start-up)")
+    ap.add_argument("--debug-share-gpu", action="store_true",
+                    help="plumbing check on a 1-GPU box: every rank uses device 0 and its own 1-rank RCCL "
+                         "communicator (rows still sharded, gloo barriers still used); NOT a measurement")
     args = ap.parse_args()
 
     from pymf_amd import _lib, dist
@@ -118,8 +123,12 @@ def main():
               file=sys.stderr)
     m, n, k = args.m, args.n, args.k
     lo, hi = w.row_range(m)
-    ctx = _lib.Context(_lib.ALGO_NMF, hi - lo, n, k, device=w.local_rank, rank=w.rank,
-                       nranks=w.size, nccl_id=w.nccl_id)
+    if args.debug_share_gpu:
+        ctx = _lib.Context(_lib.ALGO_NMF, hi - lo, n, k, device=0, rank=0, nranks=1,
+                           nccl_id=_lib.nccl_unique_id())
+    else:
+        ctx = _lib.Context(_lib.ALGO_NMF, hi - lo, n, k, device=w.local_rank, rank=w.rank,
+                           nranks=w.size, nccl_id=w.nccl_id)
     if args.fill == "numpy":
         V = gen_rows(np.random.RandomState(1234), m, n, lo, hi)
         ctx.set_v_dense(V)

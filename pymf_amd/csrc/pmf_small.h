@@ -107,47 +107,46 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) bfr[t][e] = hs[(16 * t + 4 * kq + e) * LDS_H + 16 * ct + i];
+    f32x4 den[NT];                    // the NT tile rows are independent MFMA chains
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      f32x4 den = {0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < NT; ++mt) den[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
+    for (int t = 0; t < NT; ++t) {
+      f32x4 a4[NT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) den = mfma16(a4[e], bfr[t][e], den);
-      }
+      for (int mt = 0; mt < NT; ++mt)
+        a4[mt] = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) den[mt] = mfma16(a4[mt][e], bfr[t][e], den[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
         const float h = hs[kk * LDS_H + col];
-        den[r] = (h * pv[cw][mt][r]) / (den[r] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:125-126)
+        const float hn = (h * pv[cw][mt][r]) / (den[mt][r] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:125-126)
+        H[(int64_t)kk * NP + col] = hn;
+        hs[kk * LDS_H + col] = hn;    // only this wave reads/writes these 16 columns in this step
       }
-      // all of this wave's reads of its 16 columns for tile row mt happened above; rows of other
-      // mt are still needed as B fragments -> they were captured in bfr before the mt loop
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
-        H[(int64_t)kk * NP + col] = den[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
-        hs[kk * LDS_H + col] = den[r];
-      }
-    }
   }
   __syncthreads();
   // ---- G = H H^T: wave w <-> tile (w / NT, w % NT) ----
   if (wv < NT * NT) {
     const int mt = wv / NT, nt = wv % NT;
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ge[4];                      // 4 independent chains (one per element of the 16-byte group)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ge[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int t = 0; t < NP / 16; ++t) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (16 * mt + i) * LDS_H + 16 * t + 4 * kq);
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(hs + (16 * nt + i) * LDS_H + 16 * t + 4 * kq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g = mfma16(a4[e], b4[e], g);
+      for (int e = 0; e < 4; ++e) ge[e] = mfma16(a4[e], b4[e], ge[e]);
     }
+    const f32x4 g = (ge[0] + ge[1]) + (ge[2] + ge[3]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int a = 16 * mt + 4 * kq + r, b = 16 * nt + i;
