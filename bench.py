@@ -105,9 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--m", type=int, default=M_FULL)
-    ap.add_argument("--n", type=int, default=N_FULL)
-    ap.add_argument("--k", type=int, default=K_FULL)
+    ap.add_argument("--rows", dest="m", type=int, default=M_FULL)
+    ap.add_argument("--cols", dest="n", type=int, default=N_FULL)
+    ap.add_argument("--bases", dest="k", type=int, default=K_FULL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fill", choices=["numpy", "device"], default="numpy",
                     help="numpy: BASELINE.md protocol; device: counter-based fill (fast start-up)")
