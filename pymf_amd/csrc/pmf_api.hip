@@ -323,7 +323,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
   PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
-  const int lrc = launch_fused(c->stream, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab);
+  const int lrc = launch_fused(c->stream, false, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -338,7 +338,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
 }
 
 // ---- SNMF -----------------------------------------------------------------------------------
-int snmf_update_w(pmf_ctx* c) {
+int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan), identity on the padding
   PMFCHK(ensure_gram(c, 1.0));
   const size_t smem = ((size_t)c->k * c->k + 2 * (size_t)c->k) * sizeof(double) + ((size_t)c->k + 2) * sizeof(int);
   static bool attr_done = false;
@@ -349,9 +349,35 @@ int snmf_update_w(pmf_ctx* c) {
   }
   hipLaunchKernelGGL(k_inverse, dim3(1), dim3(1024), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
   HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int snmf_update_w(pmf_ctx* c) {
+  PMFCHK(snmf_inverse(c));
   if (c->v_csr) return csr_w(c);
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
   return rowgemm<EPI_STORE>(c, c->dW1, c->KP, c->KP, c->dGinvT, c->KP, nullptr, nullptr, c->dW);
+}
+
+int snmf_inverse(pmf_ctx* c);
+
+// SNMF: update_w and the partials of update_h in ONE pass over V (dense data, fused shapes).
+int snmf_fused_iteration(pmf_ctx* c) {
+  c->ps_valid = false;
+  PMFCHK(snmf_inverse(c));
+  stat_begin(c);
+  const int lrc = launch_fused(c->stream, true, c->NT, c->np, c->dV, c->dW, c->dH, c->dGinvT, c->mp, c->fused_wgs, c->dSlab);
+  stat_end(c);
+  if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
+  HIPCHK(c, hipGetLastError());
+  {
+    const int NTP = c->np / 16;
+    const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
+    hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS);
+    HIPCHK(c, hipGetLastError());
+  }
+  return h_step_from_ps(c);
 }
 
 int snmf_update_h(pmf_ctx* c) {
@@ -491,6 +517,10 @@ void set_stat_model(pmf_ctx* c) {
     c->stat.name = fused_kernel_name(c->NT, c->np);
     c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;
     c->stat.bytes = 4.0 * (m * n + 2.0 * m * k);
+  } else if (c->algo == PMF_ALGO_SNMF && c->fused_wgs > 0) {
+    c->stat.name = fused_kernel_name(c->NT, c->np, true);
+    c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;   // V H^T, (.) inv, W^T V, W^T W
+    c->stat.bytes = 4.0 * (m * n + m * k);               // V read once, W written once
   } else if (c->algo == PMF_ALGO_NMFALS) {
     c->stat.name = "k_nnqp(update_w)";
     c->stat.flops = 0.0;
@@ -556,7 +586,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->nchunks = (int)std::min<int64_t>(want, blocks16);
     c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
-    c->fused_wgs = (algo == PMF_ALGO_NMF) ? fused_grid_for(c->NT, c->np, c->mp) : 0;
+    c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF) ? fused_grid_for(c->NT, c->np, c->mp) : 0;
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     PMFCHK(dalloc(c, &c->dV, (size_t)c->mp * c->np));
     PMFCHK(dalloc(c, &c->dW, (size_t)c->mp * c->KP));
@@ -579,7 +609,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     pmf_ctx_destroy(c);
     return rc;
   }
-  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np)) : std::string("tiled");
+  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF))
+                               : std::string("tiled");
   set_stat_model(c);
   *out = c;
   return PMF_OK;
@@ -715,12 +746,13 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   if (niter < 0 || (ce && !ferr)) return fail(c, PMF_EINVAL, "pmf_factorize: bad arguments");
   if (iters_done) *iters_done = 0;
   if (converged_at) *converged_at = -1;
-  const bool fused = cw && ch && c->algo == PMF_ALGO_NMF && c->fused_wgs > 0;
+  const bool fused = cw && ch && c->fused_wgs > 0 && !c->v_csr &&
+                     (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   int done = 0;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
-    if (fused) {
-      PMFCHK(nmf_fused_iteration(c));                     // update_w + update_h, one pass over V
+    if (fused) {                                          // update_w + update_h, one pass over V
+      PMFCHK(c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c));
     } else {
       if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184
       if (ch) PMFCHK(do_update_h(c));                     // nmf.py:186-187

@@ -19,6 +19,10 @@
 // NEXT block is DMA-issued the moment phase B has finished with panel p: a single
 // LDS buffer gives a full block of prefetch distance.
 //
+// SNMF = true builds the semi-NMF W step into the same pass (pymf/snmf.py:67-70): the second
+// small product is W_b = Num inv(H H^T) instead of Den = W_b G, Num goes through the wave's W
+// image (accumulator layout -> A-fragment layout), no old W is read at all, and G holds inv^T.
+//
 // Accumulators: P = NT x 4*NPANEL tiles and S = NT x NT tiles of 16x16 (4 VGPRs
 // each) stay in registers for the wave's whole row range; one wave per SIMD
 // (__launch_bounds__(256, 1)) so the 512-entry unified VGPR/AGPR file holds them.
@@ -56,7 +60,7 @@ constexpr size_t fused_smem_bytes() {
 
 // blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
-template <int NT, int NPANEL>
+template <int NT, int NPANEL, bool SNMF>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
                                                        float* __restrict__ W,
                                                        const float* __restrict__ H,
@@ -123,8 +127,10 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   }
 
   if (nb > 0) {
+    if (!SNMF) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_w(b0, q);
+      for (int q = 0; q < 4; ++q) issue_w(b0, q);
+    }
 #pragma unroll
     for (int p = 0; p < (SPREAD ? NPANEL - 1 : NPANEL); ++p)
 #pragma unroll
@@ -216,7 +222,19 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     load_step(0, 0);
 #pragma unroll
     for (int s = 0; s < NSA; ++s) {
-      if (s + 1 < NSA) {
+      if (SNMF && s == NSN) {
+        // Num is complete: accumulator layout -> the wave's W image, then read it back as A
+        // fragments (same wave, LDS executes a wave's accesses in order)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 4 * kq + j, col = 16 * nt + i;
+            sW[swz_off(row, col >> 2) + (col & 3)] = num[nt][j];
+          }
+        load_step(NSN, NSN & 1);
+      }
+      if (s + 1 < NSA && !(SNMF && s + 1 == NSN)) {
         if (s + 1 < NSN && ((s + 1) & 3) == 0) wait_panel((s + 1) >> 2);
         load_step(s + 1, (s + 1) & 1);
       }
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       if (SPREAD && s < 4) issue_v(blk, NPANEL - 1, s);   // this block's last panel, 1 DMA/step
       // issue order inside the step: one LDS read (of step s+1) per 3 MFMAs (of step s), so a
       // read's issue slot hides under an executing MFMA; the DMA goes last
-      if (s + 1 < NSA) {
+      if (s + 1 < NSA && !(SNMF && (s + 1 == NSN || s == NSN))) {
 #pragma unroll
         for (int g = 0; g < NT + 1; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (NT + 1), 0);   // MFMA
@@ -248,17 +266,19 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     PMF_STAMP(ts2);
     // old W rows in the accumulator (C) layout, then the W image is free: prefetch the next block's
     float wold[NT][4];
+    if (!SNMF) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 4 * kq + j, col = 16 * nt + i;
-        wold[nt][j] = sW[swz_off(row, col >> 2) + (col & 3)];
+        for (int j = 0; j < 4; ++j) {
+          const int row = 4 * kq + j, col = 16 * nt + i;
+          wold[nt][j] = sW[swz_off(row, col >> 2) + (col & 3)];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_w(blk + 1, q);
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_w(blk + 1, q);
     }
     PMF_STAMP(ts3);
 
@@ -269,7 +289,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float w = pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);
+        const float w = SNMF ? den[nt][j]      // W = (V H^T) inv(H H^T), snmf.py:70
+                             : pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);
         wn[nt][j] = w;
         wdst[j * KP + 16 * nt] = w;
 #pragma unroll
@@ -406,13 +427,13 @@ static inline int fused_grid_for(int NT, int np, int64_t mp) {
   return (int)wgs;
 }
 
-static inline const char* fused_kernel_name(int NT, int np) {
+static inline const char* fused_kernel_name(int NT, int np, bool snmf = false) {
   static char buf[64];
-  snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d>", NT, np / 64);
+  snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d%s>", NT, np / 64, snmf ? ",snmf" : "");
   return buf;
 }
 
-template <int NT, int NPANEL>
+template <int NT, int NPANEL, bool SNMF>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
                           int64_t mp, int wgs, float* slab) {
   const int nblk = (int)(mp / 16), nw = wgs * 4;
@@ -420,30 +441,36 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
   const size_t smem = fused_smem_bytes<NT, NPANEL>();
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL, SNMF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return PMF_EHIP;
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
+  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, SNMF>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
                      blk_extra, slab);
   return PMF_OK;
 }
 
-static inline int launch_fused(hipStream_t s, int NT, int np, const float* V, float* W, const float* H,
-                               const float* G, int64_t mp, int wgs, float* slab) {
+// G: H H^T (NMF) or inv(H H^T)^T (SNMF), [KP][KP] float32.
+static inline int launch_fused(hipStream_t s, bool snmf, int NT, int np, const float* V, float* W,
+                               const float* H, const float* G, int64_t mp, int wgs, float* slab) {
   const int key = NT * 10 + np / 64;
+#define PMF_FUSED_CASE(K, A, B)                                                     \
+  case K:                                                                           \
+    return snmf ? launch_fused_t<A, B, true>(s, V, W, H, G, mp, wgs, slab)          \
+                : launch_fused_t<A, B, false>(s, V, W, H, G, mp, wgs, slab);
   switch (key) {
-    case 11: return launch_fused_t<1, 1>(s, V, W, H, G, mp, wgs, slab);
-    case 12: return launch_fused_t<1, 2>(s, V, W, H, G, mp, wgs, slab);
-    case 14: return launch_fused_t<1, 4>(s, V, W, H, G, mp, wgs, slab);
-    case 21: return launch_fused_t<2, 1>(s, V, W, H, G, mp, wgs, slab);
-    case 22: return launch_fused_t<2, 2>(s, V, W, H, G, mp, wgs, slab);
-    case 24: return launch_fused_t<2, 4>(s, V, W, H, G, mp, wgs, slab);
-    case 41: return launch_fused_t<4, 1>(s, V, W, H, G, mp, wgs, slab);
-    case 42: return launch_fused_t<4, 2>(s, V, W, H, G, mp, wgs, slab);
-    case 44: return launch_fused_t<4, 4>(s, V, W, H, G, mp, wgs, slab);
+    PMF_FUSED_CASE(11, 1, 1)
+    PMF_FUSED_CASE(12, 1, 2)
+    PMF_FUSED_CASE(14, 1, 4)
+    PMF_FUSED_CASE(21, 2, 1)
+    PMF_FUSED_CASE(22, 2, 2)
+    PMF_FUSED_CASE(24, 2, 4)
+    PMF_FUSED_CASE(41, 4, 1)
+    PMF_FUSED_CASE(42, 4, 2)
+    PMF_FUSED_CASE(44, 4, 4)
   }
+#undef PMF_FUSED_CASE
   return PMF_EINVAL;
 }
 #endif  // PMF_FUSED_KERNEL_ONLY

@@ -288,3 +288,24 @@ def test_zero_rows_and_columns(pm):
     ref.factorize(niter=5)
     assert np.all(mdl.W[10:20] == 0.0) and np.all(mdl.H[:, 5] == 0.0)
     assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+
+
+def test_snmf_fused_and_tiled_paths_agree(pm):
+    """SNMF: one-pass fused kernel (factorize) vs the two-pass hooks on mixed-sign data."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(21)
+    m, n, k = 8192, 256, 48
+    V = (rs.random_sample((m, n)) - 0.3).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = (rs.random_sample((k, n)) + 0.1).astype(np.float32)
+    a = _lib.Context(_lib.ALGO_SNMF, m, n, k)
+    assert a.path_name.startswith("k_nmf_fused") and "snmf" in a.path_name
+    a.set_v_dense(V); a.set_w(W0); a.set_h(H0)
+    a.factorize(3, compute_err=False)
+    b = _lib.Context(_lib.ALGO_SNMF, m, n, k)
+    b.set_v_dense(V); b.set_w(W0); b.set_h(H0)
+    for _ in range(3):
+        b.update_w()
+        b.update_h()
+    assert rel_fro(a.get_w(), b.get_w()) < 1e-5
+    assert rel_fro(a.get_h(), b.get_h()) < 1e-5
