@@ -110,9 +110,15 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   const char* Vb = reinterpret_cast<const char*>(V);
   const char* Wb = reinterpret_cast<const char*>(W);
   auto issue_v = [&](int blk, int p, int q) {      // V rows of block blk, panel p, DMA q
+#ifdef PMF_ABLATE_DMA      // timing-only diagnostic build: outputs are wrong
+    if (blk != b0) return;
+#endif
     PMF_GLDS16(Vb + ((size_t)blk * (16 * NP * 4) + p * 256) + voff[q], sV + p * 1024 + q * 256);
   };
   auto issue_w = [&](int blk, int q) {
+#ifdef PMF_ABLATE_DMA
+    if (blk != b0) return;
+#endif
     PMF_GLDS16(Wb + (size_t)blk * (16 * KP * 4) + woff[q], sW + q * 256);
   };
 
@@ -251,13 +257,14 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           for (int nt = 0; nt < NT; ++nt) den[nt] = mfma16(fa[buf][e], fb[buf][nt][e], den[nt]);
       }
       if (SPREAD && s < 4) issue_v(blk, NPANEL - 1, s);   // this block's last panel, 1 DMA/step
-      // issue order inside the step: one LDS read (of step s+1) per 3 MFMAs (of step s), so a
-      // read's issue slot hides under an executing MFMA; the DMA goes last
+      // issue order inside the step: one LDS read (of step s+1) per 2 MFMAs (of step s), so a
+      // read's issue slot hides under an executing MFMA and the last read is >= 6 MFMAs old when
+      // the next step needs it; the DMA goes last
       if (s + 1 < NSA && !(SNMF && (s + 1 == NSN || s == NSN))) {
 #pragma unroll
         for (int g = 0; g < NT + 1; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (NT + 1), 0);   // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, NT >= 4 ? 2 : 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // DS read
         }
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                     // remaining MFMAs
@@ -324,8 +331,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       if (s + 1 < NSN) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);    // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, NT >= 2 ? 2 : 1, 0);    // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // DS read
         }
       }
       __builtin_amdgcn_sched_barrier(0);
