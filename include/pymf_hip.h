@@ -18,6 +18,7 @@
  *   pmf_update_h          NMF.update_h                 pymf/nmf.py:122-126
  *                         SNMF.update_h                pymf/snmf.py:72-91
  *                         NMFALS.update_h              pymf/nmfals.py:70-82
+ *                         BNMF.update_w / update_h     pymf/bnmf.py:79-90 (algo 3, 'next' row)
  *   pmf_frobenius         NMF.frobenius_norm           pymf/nmf.py:100-114
  *   pmf_factorize         NMF.factorize loop body      pymf/nmf.py:182-202
  *                         (incl. NMF.converged         pymf/nmf.py:134-139)
@@ -44,7 +45,7 @@ enum {
   PMF_ENOMEM = -4    /* device or host allocation failed */
 };
 
-enum { PMF_ALGO_NMF = 0, PMF_ALGO_NMFALS = 1, PMF_ALGO_SNMF = 2 };
+enum { PMF_ALGO_NMF = 0, PMF_ALGO_NMFALS = 1, PMF_ALGO_SNMF = 2, PMF_ALGO_BNMF = 3 };
 
 /* pmf_factorize flags (the reference's factorize() keyword arguments, nmf.py:141-142) */
 enum { PMF_COMPUTE_W = 1u, PMF_COMPUTE_H = 2u, PMF_COMPUTE_ERR = 4u };
@@ -104,6 +105,12 @@ int pmf_frobenius(pmf_ctx* ctx, double* out);   /* sqrt(sum((V - W H)^2)), all r
  */
 int pmf_factorize(pmf_ctx* ctx, int32_t niter, uint32_t flags, double conv_eps,
                   double* ferr, int32_t* iters_done, int32_t* converged_at);
+
+/* BNMF only (pymf/bnmf.py:79-90,118-119): the penalty weights _lamb_W/_lamb_H used by the next
+ * update_w/update_h; every update_h multiplies both by 1.1 (bnmf.py:84-85), as the reference does.
+ * The caller sets 1/niter before each factorize() like BNMF.factorize. */
+int pmf_set_lambda(pmf_ctx* ctx, double lamb_w, double lamb_h);
+int pmf_get_lambda(pmf_ctx* ctx, double* lamb_w, double* lamb_h);
 
 /* Device time (ms, HIP events on the library's stream) of the last pmf_factorize loop. */
 int pmf_last_loop_ms(pmf_ctx* ctx, double* ms);

@@ -6,7 +6,9 @@ Drop-in classes for the reference's `pymf.NMF`, `pymf.NMFALS`, `pymf.SNMF`
 from .nmf import NMF          # noqa: F401
 from .nmfals import NMFALS    # noqa: F401
 from .snmf import SNMF        # noqa: F401
+from .nmfnnls import NMFNNLS  # noqa: F401  (SURVEY 8(f) 'next' row 2)
+from .bnmf import BNMF        # noqa: F401  (SURVEY 8(f) 'next' row 1)
 from . import dist            # noqa: F401
 
-__all__ = ["NMF", "NMFALS", "SNMF", "dist"]
+__all__ = ["NMF", "NMFALS", "SNMF", "NMFNNLS", "BNMF", "dist"]
 __version__ = "0.1.0"

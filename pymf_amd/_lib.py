@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpymf_hip.so")
 
 PMF_OK = 0
-ALGO_NMF, ALGO_NMFALS, ALGO_SNMF = 0, 1, 2
+ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF = 0, 1, 2, 3
 COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
 NCCL_ID_BYTES = 128
 
@@ -42,6 +42,8 @@ SYMBOLS = [
     ("pmf_frobenius", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_factorize", _c.c_int, [_ctx, _c.c_int32, _c.c_uint32, _c.c_double, _c.c_void_p,
                                  _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32)]),
+    ("pmf_set_lambda", _c.c_int, [_ctx, _c.c_double, _c.c_double]),
+    ("pmf_get_lambda", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     ("pmf_last_loop_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_profile_enable", _c.c_int, [_ctx, _c.c_int32]),
     ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
@@ -196,6 +198,14 @@ class Context(object):
         if compute_err:
             ferr = ferr[:int(niter)]
         return ferr, int(done.value), int(conv.value)
+
+    def set_lambda(self, lamb_w, lamb_h):
+        self._chk(self._lib.pmf_set_lambda(self._h, float(lamb_w), float(lamb_h)))
+
+    def get_lambda(self):
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._chk(self._lib.pmf_get_lambda(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return float(a.value), float(b.value)
 
     def last_loop_ms(self):
         ms = ctypes.c_double(0.0)

@@ -62,6 +62,7 @@ struct pmf_ctx {
   bool ps_valid = false;        // dPS = (W^T V | W^T W) of the CURRENT W, summed over all ranks
   bool vnorm_valid = false;
   double vnorm2 = 0.0;          // ||V||_F^2 over all ranks
+  double lamb_w = 0.0, lamb_h = 0.0;   // BNMF penalty weights (bnmf.py:84-85,118-119)
   bool profile = false;
   double last_loop_ms = 0.0;
   KernelStat stat;
@@ -134,6 +135,7 @@ void stat_end(pmf_ctx* c) {
 template <int NT, int EPI>
 int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
                    float* W, const float* G, float* C) {
+  const float lamb = (float)c->lamb_w;
   const size_t smem = rowgemm_smem_bytes<NT>();
   static bool attr_done = false;
   if (!attr_done) {
@@ -142,7 +144,7 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
     attr_done = true;
   }
   hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)(c->mp / 64)), dim3(256), smem, c->stream,
-                     A, lda, kdimA, B, ldb, W, G, C);
+                     A, lda, kdimA, B, ldb, W, G, C, lamb);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -248,27 +250,48 @@ int need(pmf_ctx* c, bool v, bool w, bool h) {
 // ---- NMF (multiplicative update) ---------------------------------------------------------
 int nmf_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 0.0));
+  if (c->algo == PMF_ALGO_BNMF)
+    return rowgemm<EPI_BNMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
   return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
 }
 
 template <int NT, int NPANEL>
+int launch_h_gram_b(pmf_ctx* c);
+
+template <int NT, int NPANEL>
 int launch_h_gram(pmf_ctx* c) {
+  if (c->algo == PMF_ALGO_BNMF) return launch_h_gram_b<NT, NPANEL>(c);
   constexpr size_t smem = (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * (64 * NPANEL + 4)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, NPANEL>),
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, NPANEL, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
-                     c->dG, c->dGd);
+  hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL, false>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
+                     c->dG, c->dGd, 0.f);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+template <int NT, int NPANEL>
+int launch_h_gram_b(pmf_ctx* c) {
+  constexpr size_t smem = (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * (64 * NPANEL + 4)) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, NPANEL, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL, true>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
+                     c->dG, c->dGd, (float)c->lamb_h);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
 
 // NMF on the fused-kernel shapes: H step and G = H H^T in one launch.  false: shape not covered.
 bool nmf_h_gram(pmf_ctx* c, int* rc) {
-  if (c->algo != PMF_ALGO_NMF) return false;
+  if (c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) return false;
   const int key = c->NT * 10 + c->np / 64;
   if (c->np % 64) return false;
   switch (key) {
@@ -292,6 +315,7 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
     PMFCHK(hrc);
     c->g_valid = true;     // G (pad rows/cols are zero because the padded H rows are zero)
     c->ps_valid = true;
+    if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
     return PMF_OK;
   }
   const size_t smem = (size_t)c->KP * 16 * sizeof(float);
@@ -300,10 +324,12 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
                        (int64_t)c->np, c->np, c->KP, c->dPS);
   else
     hipLaunchKernelGGL(k_nmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
-                       (int64_t)c->np, c->np, c->KP, c->dPS);
+                       (int64_t)c->np, c->np, c->KP, c->dPS, c->algo == PMF_ALGO_BNMF ? 1 : 0,
+                       (float)c->lamb_h);
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
   c->ps_valid = true;    // dPS belongs to the current W (update_h never touches W)
+  if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
   return PMF_OK;
 }
 
@@ -323,7 +349,8 @@ int nmf_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
   PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
-  const int lrc = launch_fused(c->stream, false, c->NT, c->np, c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, c->dSlab);
+  const int lrc = launch_fused(c->stream, c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT, c->np, c->dV,
+                               c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -366,7 +393,8 @@ int snmf_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
   PMFCHK(snmf_inverse(c));
   stat_begin(c);
-  const int lrc = launch_fused(c->stream, true, c->NT, c->np, c->dV, c->dW, c->dH, c->dGinvT, c->mp, c->fused_wgs, c->dSlab);
+  const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dH, c->dGinvT, c->mp,
+                               c->fused_wgs, 0.f, c->dSlab);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -419,6 +447,7 @@ int do_update_w(pmf_ctx* c) {
   c->ps_valid = false;
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_w(c);
+    case PMF_ALGO_BNMF: return nmf_update_w(c);
     case PMF_ALGO_SNMF: return snmf_update_w(c);
     case PMF_ALGO_NMFALS: return als_update_w(c);
   }
@@ -428,6 +457,7 @@ int do_update_w(pmf_ctx* c) {
 int do_update_h(pmf_ctx* c) {
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_h(c);
+    case PMF_ALGO_BNMF: return nmf_update_h(c);
     case PMF_ALGO_SNMF: return snmf_update_h(c);
     case PMF_ALGO_NMFALS: return als_update_h(c);
   }
@@ -513,12 +543,12 @@ void set_stat_model(pmf_ctx* c) {
   // (SURVEY.md section 8(d)): the fused kernel does the four m-sized contractions of an
   // iteration in one pass over V: F = 4 m n k + 4 m k^2, B = 4 (m n + 2 m k).
   const double m = (double)c->m, n = (double)c->n, k = (double)c->k;
-  if (c->algo == PMF_ALGO_NMF && c->fused_wgs > 0) {
-    c->stat.name = fused_kernel_name(c->NT, c->np);
+  if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->fused_wgs > 0) {
+    c->stat.name = fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF);
     c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;
     c->stat.bytes = 4.0 * (m * n + 2.0 * m * k);
   } else if (c->algo == PMF_ALGO_SNMF && c->fused_wgs > 0) {
-    c->stat.name = fused_kernel_name(c->NT, c->np, true);
+    c->stat.name = fused_kernel_name(c->NT, c->np, FUSED_SNMF);
     c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;   // V H^T, (.) inv, W^T V, W^T W
     c->stat.bytes = 4.0 * (m * n + m * k);               // V read once, W written once
   } else if (c->algo == PMF_ALGO_NMFALS) {
@@ -554,7 +584,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
                    int32_t rank, int32_t nranks, const void* nccl_id) {
   if (!out) return fail(nullptr, PMF_EINVAL, "out is NULL");
   *out = nullptr;
-  if (algo < 0 || algo > 2) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS) or 2 (SNMF)");
+  if (algo < 0 || algo > 3) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF) or 3 (BNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
   if (k > 128) return fail(nullptr, PMF_EINVAL, "num_bases > 128 is not supported by this build");
   if (algo == PMF_ALGO_NMFALS && k > 64)
@@ -586,7 +616,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->nchunks = (int)std::min<int64_t>(want, blocks16);
     c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
-    c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF) ? fused_grid_for(c->NT, c->np, c->mp) : 0;
+    c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF)
+                       ? fused_grid_for(c->NT, c->np, c->mp) : 0;
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     PMFCHK(dalloc(c, &c->dV, (size_t)c->mp * c->np));
     PMFCHK(dalloc(c, &c->dW, (size_t)c->mp * c->KP));
@@ -609,7 +640,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     pmf_ctx_destroy(c);
     return rc;
   }
-  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF))
+  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF ? FUSED_SNMF
+                                                                           : algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF))
                                : std::string("tiled");
   set_stat_model(c);
   *out = c;
@@ -747,7 +779,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   if (iters_done) *iters_done = 0;
   if (converged_at) *converged_at = -1;
   const bool fused = cw && ch && c->fused_wgs > 0 && !c->v_csr &&
-                     (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF);
+                     (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   int done = 0;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
@@ -775,6 +807,19 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_loop_ms = ms;
   if (iters_done) *iters_done = done;
+  return PMF_OK;
+}
+
+int pmf_set_lambda(pmf_ctx* c, double lamb_w, double lamb_h) {
+  if (!c) return PMF_EINVAL;
+  if (c->algo != PMF_ALGO_BNMF) return fail(c, PMF_EINVAL, "pmf_set_lambda: only BNMF has penalty weights");
+  c->lamb_w = lamb_w; c->lamb_h = lamb_h;
+  return PMF_OK;
+}
+
+int pmf_get_lambda(pmf_ctx* c, double* lamb_w, double* lamb_h) {
+  if (!c || !lamb_w || !lamb_h) return PMF_EINVAL;
+  *lamb_w = c->lamb_w; *lamb_h = c->lamb_h;
   return PMF_OK;
 }
 

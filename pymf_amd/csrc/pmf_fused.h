@@ -60,12 +60,15 @@ constexpr size_t fused_smem_bytes() {
 
 // blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
-template <int NT, int NPANEL, bool SNMF>
+enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2 };
+
+template <int NT, int NPANEL, int MODE>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
                                                        float* __restrict__ W,
                                                        const float* __restrict__ H,
                                                        const float* __restrict__ G, int blk_per,
-                                                       int blk_extra, float* __restrict__ slab
+                                                       int blk_extra, float lamb,
+                                                       float* __restrict__ slab
 #ifdef PMF_STAMPS
                                                        , unsigned long long* __restrict__ dbg
 #endif
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   // DMA of the next block's V panel p is spread over phase B's panel p+1 steps and the last
   // panel over the next phase A's first steps (one LDS-DMA per 16 MFMAs) -- needs 4 panels.
   constexpr bool SPREAD = (NPANEL == 4);
+  constexpr bool SNMF = (MODE == FUSED_SNMF);
 #ifdef PMF_STAMPS
   unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
   PMF_STAMP(tk0);
@@ -296,8 +300,17 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float w = SNMF ? den[nt][j]      // W = (V H^T) inv(H H^T), snmf.py:70
-                             : pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);
+        float w;
+        if (MODE == FUSED_SNMF) {
+          w = den[nt][j];                                    // W = (V H^T) inv(H H^T), snmf.py:70
+        } else if (MODE == FUSED_BNMF) {                     // bnmf.py:87-90, W *= W1 / W2
+          const float w0 = wold[nt][j];
+          const float w1 = num[nt][j] + (3.0f * lamb) * (w0 * w0);
+          const float w2 = ((den[nt][j] + (2.0f * lamb) * (w0 * w0 * w0)) + lamb * w0) + PMF_EPS_DEN;
+          w = w0 * pmf_div(w1, w2);
+        } else {
+          w = pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);   // nmf.py:131-132
+        }
         wn[nt][j] = w;
         wdst[j * KP + 16 * nt] = w;
 #pragma unroll
@@ -434,38 +447,41 @@ static inline int fused_grid_for(int NT, int np, int64_t mp) {
   return (int)wgs;
 }
 
-static inline const char* fused_kernel_name(int NT, int np, bool snmf = false) {
+static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF) {
   static char buf[64];
-  snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d%s>", NT, np / 64, snmf ? ",snmf" : "");
+  snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d%s>", NT, np / 64,
+           mode == FUSED_SNMF ? ",snmf" : mode == FUSED_BNMF ? ",bnmf" : "");
   return buf;
 }
 
-template <int NT, int NPANEL, bool SNMF>
+template <int NT, int NPANEL, int MODE>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
-                          int64_t mp, int wgs, float* slab) {
+                          int64_t mp, int wgs, float lamb, float* slab) {
   const int nblk = (int)(mp / 16), nw = wgs * 4;
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL>();
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL, SNMF>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return PMF_EHIP;
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, SNMF>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
-                     blk_extra, slab);
+  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
+                     blk_extra, lamb, slab);
   return PMF_OK;
 }
 
 // G: H H^T (NMF) or inv(H H^T)^T (SNMF), [KP][KP] float32.
-static inline int launch_fused(hipStream_t s, bool snmf, int NT, int np, const float* V, float* W,
-                               const float* H, const float* G, int64_t mp, int wgs, float* slab) {
+static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
+                               const float* H, const float* G, int64_t mp, int wgs, float lamb,
+                               float* slab) {
   const int key = NT * 10 + np / 64;
-#define PMF_FUSED_CASE(K, A, B)                                                     \
-  case K:                                                                           \
-    return snmf ? launch_fused_t<A, B, true>(s, V, W, H, G, mp, wgs, slab)          \
-                : launch_fused_t<A, B, false>(s, V, W, H, G, mp, wgs, slab);
+#define PMF_FUSED_CASE(K, A, B)                                                                  \
+  case K:                                                                                        \
+    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab) \
+           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab) \
+                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab);
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
     PMF_FUSED_CASE(12, 1, 2)

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
 
 // NMF H step (pymf/nmf.py:122-126): H <- (H * P) / (S H + 1e-9), P = W^T V, S = W^T W.
 // PS: [KP][np + KP] (P | S).  One block per 16 columns of H; in place.
+// lamb > 0: BNMF rule (bnmf.py:79-82) H *= (P + 3 l H^2) / (S H + 2 l H^3 + l H + 1e-9).
 __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ldh, int np, int KP,
-                                               const float* __restrict__ PS) {
+                                               const float* __restrict__ PS, int bnmf, float lamb) {
   extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
   const int tid = threadIdx.x;
   const int c = tid & 15;
@@ -49,7 +50,13 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
     for (int j = 0; j < KP; ++j) den = fmaf(srow[j], hs[j * 16 + c], den);
     const float h = hs[kk * 16 + c];
     const float p = PS[(int64_t)kk * ldp + col];
-    H[(int64_t)kk * ldh + col] = (h * p) / (den + PMF_EPS_DEN);
+    if (bnmf) {
+      const float h1 = p + (3.0f * lamb) * (h * h);
+      const float h2 = ((den + (2.0f * lamb) * (h * h * h)) + lamb * h) + PMF_EPS_DEN;
+      H[(int64_t)kk * ldh + col] = h * (h1 / h2);
+    } else {
+      H[(int64_t)kk * ldh + col] = (h * p) / (den + PMF_EPS_DEN);
+    }
   }
 }
 
@@ -60,10 +67,11 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
 // [16w, 16w+16) of H for the H step (it reads and rewrites only those columns of the LDS image, so
 // no barrier is needed inside the step) and one 16x16 tile of G afterwards.
 // LDS rows are padded by 4 floats: fragment reads (16 lanes on 16 rows) are conflict-free b128.
-template <int NT, int NPANEL>
+template <int NT, int NPANEL, bool BNMF>
 __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
                                                      const float* __restrict__ PS,
-                                                     float* __restrict__ Gf, double* __restrict__ Gd) {
+                                                     float* __restrict__ Gf, double* __restrict__ Gd,
+                                                     float lamb) {
   constexpr int KP = 16 * NT, NP = 64 * NPANEL, NCT = NP / 16;
   constexpr int LDS_S = KP + 4, LDS_H = NP + 4;
   constexpr int64_t ldp = NP + KP;
@@ -127,7 +135,14 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
       for (int r = 0; r < 4; ++r) {
         const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
         const float h = hs[kk * LDS_H + col];
-        const float hn = (h * pv[cw][mt][r]) / (den[mt][r] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:125-126)
+        float hn;
+        if (BNMF) {                                             // bnmf.py:79-82, H *= H1 / H2
+          const float h1 = pv[cw][mt][r] + (3.0f * lamb) * (h * h);
+          const float h2 = ((den[mt][r] + (2.0f * lamb) * (h * h * h)) + lamb * h) + PMF_EPS_DEN;
+          hn = h * (h1 / h2);
+        } else {
+          hn = (h * pv[cw][mt][r]) / (den[mt][r] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:125-126)
+        }
         H[(int64_t)kk * NP + col] = hn;
         hs[kk * LDS_H + col] = hn;    // only this wave reads/writes these 16 columns in this step
       }

@@ -14,7 +14,7 @@
 #pragma once
 #include "pmf_dev.h"
 
-enum { EPI_STORE = 0, EPI_NMF_W = 1 };
+enum { EPI_STORE = 0, EPI_NMF_W = 1, EPI_BNMF_W = 2 };
 
 // A [R][64] f32 panel travelling global -> registers -> swizzled LDS, 256 threads.
 template <int R>
@@ -89,7 +89,7 @@ template <int NT, int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, int64_t lda, int kdimA,
                                                  const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ W, const float* __restrict__ G,
-                                                 float* __restrict__ C) {
+                                                 float* __restrict__ C, float lamb) {
   constexpr int KP = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sa = smem;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
   tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb);
 
   const int64_t rbase = row0 + 16 * wv + 4 * kq;   // + reg index j
-  if (EPI == EPI_NMF_W) {
+  if (EPI == EPI_NMF_W || EPI == EPI_BNMF_W) {
     f32x4 den[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -116,7 +116,13 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
       for (int j = 0; j < 4; ++j) {
         float* p = W + (rbase + j) * KP + 16 * nt + i;
         const float w = *p;
-        *p = (w * num[nt][j]) / (den[nt][j] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:131-132)
+        if (EPI == EPI_BNMF_W) {                              // bnmf.py:87-90
+          const float w1 = num[nt][j] + (3.0f * lamb) * (w * w);
+          const float w2 = ((den[nt][j] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
+          *p = w * (w1 / w2);
+        } else {
+          *p = (w * num[nt][j]) / (den[nt][j] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:131-132)
+        }
       }
   } else {
 #pragma unroll

@@ -19,7 +19,9 @@ def load_golden(name):
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     if "V" not in d and "V_seed" in d:
         m, n = (int(x) for x in d["V_shape"])
-        d["V"] = np.random.RandomState(int(d["V_seed"])).random_sample((m, n)).astype(np.float32)
+        u = np.random.RandomState(int(d["V_seed"])).random_sample((m, n))
+        # seed 5 is the binary BNMF matrix (gen_golden.py), every other seeded V is U[0,1)
+        d["V"] = (u < 0.2).astype(np.float32) if name.startswith("bnmf") else u.astype(np.float32)
     return d
 
 

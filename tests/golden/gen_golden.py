@@ -27,7 +27,7 @@ def load_reference():
     pkg.__path__ = [os.path.join(REF, "pymf")]
     sys.modules["pymf"] = pkg
     mods = {}
-    for name in ("nmf", "snmf", "nmfnnls"):
+    for name in ("nmf", "snmf", "nmfnnls", "bnmf"):
         mods[name] = importlib.import_module("pymf." + name)
     mods["nmfnnls"].map = lambda f, *a: list(builtins.map(f, *a))
     return mods
@@ -56,6 +56,7 @@ def run_case(cls, V, k, niter, seed, cast32, flags=None, w0=None, h0=None):
 def main():
     mods = load_reference()
     NMF, SNMF, NNLS = mods["nmf"].NMF, mods["snmf"].SNMF, mods["nmfnnls"].NMFNNLS
+    BNMF = mods["bnmf"].BNMF
     cases = {}
 
     def add(name, cls, V, vdesc, k, niter, seed, cast32, **kw):
@@ -128,6 +129,17 @@ def main():
     np.random.seed(400401)
     A = np.random.random((3, 50)) + 2.0
     add("nnls_reftest", NNLS, A, dict(V=A), 4, 10, 11, False)
+
+    # BNMF ("next" row 1): binary data, the reference test's own input (tests/test_pymf.py:80)
+    Vb = (np.random.RandomState(17).random_sample((96, 64)) < 0.3).astype(np.float32)
+    add("bnmf_96x64_k8", BNMF, Vb, dict(V=Vb), 8, 15, 42, False)
+    add("bnmf_96x64_k8_f32", BNMF, Vb, dict(V=Vb), 8, 15, 42, True)
+    np.random.seed(400401)
+    A = np.random.random((3, 50)) + 2.0
+    add("bnmf_reftest", BNMF, np.round(A - 2.0), dict(V=np.round(A - 2.0)), 4, 20, 11, False)
+    Vb2 = (np.random.RandomState(5).random_sample((1024, 256)) < 0.2).astype(np.float32)
+    add("bnmf_1024x256_k64", BNMF, Vb2, dict(V_seed=np.int64(5), V_shape=np.array([1024, 256], dtype=np.int64)),
+        64, 8, 42, True)
 
     for name, d in cases.items():
         d = {k: v for k, v in d.items() if v is not None}

@@ -38,6 +38,17 @@ def test_nmfals_vs_reference_nnls_golden(pm, name):
     np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=2e-4, atol=1e-6)
 
 
+def test_nmfnnls_class_matches_reference_golden(pm):
+    """pymf.NMFNNLS (nmfnnls.py:69-80) is served by the same kernel; golden = the reference itself."""
+    g = load_golden("nnls_24x18_k4")
+    mdl = pm.NMFNNLS(g["V"], num_bases=int(g["k"]))
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert np.max(np.abs(mdl.W - g["W"])) < 5e-5 * max(1.0, np.abs(g["W"]).max())
+    assert np.max(np.abs(mdl.H - g["H"])) < 5e-5 * max(1.0, np.abs(g["H"]).max())
+    np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("m,n,k", [(40, 30, 4), (70, 50, 16), (130, 90, 33), (96, 64, 64)])
 def test_nmfals_vs_oracle(pm, m, n, k):
     from oracle import NMFALSOracle
