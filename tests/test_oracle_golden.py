@@ -9,15 +9,16 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, rel_fro
-from oracle import NMFOracle, SNMFOracle, NMFALSOracle
+from oracle import NMFOracle, SNMFOracle, NMFALSOracle, BNMFOracle
 
-ORACLE = {"nmf": NMFOracle, "snmf": SNMFOracle, "nnls": NMFALSOracle}
+ORACLE = {"nmf": NMFOracle, "snmf": SNMFOracle, "nnls": NMFALSOracle, "bnmf": BNMFOracle}
 
 CASES = ["nmf_cfg1_f64", "nmf_cfg1_f32", "snmf_cfg1_f64", "snmf_cfg1_f32",
          "nmf_512x128_k16", "snmf_512x128_k16", "nmf_cfg4s", "snmf_cfg4s",
          "nmf_cfg2s", "snmf_cfg2s", "nmf_cfg5s_dense", "snmf_cfg5s_dense",
          "snmf_sparse1pct", "nmf_37x29_k5", "snmf_37x29_k5", "nmf_reftest",
-         "snmf_reftest", "nnls_24x18_k4", "nnls_reftest"]
+         "snmf_reftest", "nnls_24x18_k4", "nnls_reftest",
+         "bnmf_96x64_k8", "bnmf_96x64_k8_f32", "bnmf_reftest", "bnmf_1024x256_k64"]
 
 
 @pytest.mark.parametrize("name", CASES)
