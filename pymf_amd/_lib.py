@@ -9,6 +9,11 @@ import os
 
 import numpy as np
 
+# Single-node design (ranks of one xGMI node): keep RCCL's bootstrap off InfiniBand probing, which
+# can stall communicator creation for minutes on hosts without a fabric; users may override both.
+os.environ.setdefault("NCCL_IB_DISABLE", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpymf_hip.so")
 

@@ -408,6 +408,53 @@ int snmf_fused_iteration(pmf_ctx* c) {
   return h_step_from_ps(c);
 }
 
+// CSR SNMF: update_w and the (P | S) partials of update_h in one pass over the CSR rows.
+template <int NT>
+int launch_csr_fused(pmf_ctx* c, int wgs) {
+  const size_t smem = ((size_t)2 * c->np * c->KP + 4 * 16 * c->KP) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_csr_fused<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int nblk = (int)(c->mp / 16), nw = wgs * 4;
+  hipLaunchKernelGGL((k_snmf_csr_fused<NT>), dim3(wgs), dim3(256), smem, c->stream, c->dIndptr, c->dIndices,
+                     c->dVals, nblk / nw, nblk % nw, c->np, c->dW1, c->dW, c->dSlab);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+bool csr_fused_ok(const pmf_ctx* c) {
+  const size_t smem = ((size_t)2 * c->np * c->KP + 4 * 16 * c->KP) * sizeof(float);
+  return c->v_csr && smem <= 160 * 1024;
+}
+
+int snmf_csr_fused_iteration(pmf_ctx* c) {
+  c->ps_valid = false;
+  PMFCHK(snmf_inverse(c));
+  const int E = c->np * c->KP;
+  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dH,
+                     (int64_t)c->np, c->np, c->KP, c->dGinvT, c->dW1);
+  HIPCHK(c, hipGetLastError());
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  int wgs = (int)std::min<int64_t>((c->mp / 16 + 3) / 4, cus);
+  wgs = std::min(wgs, c->nchunks > 0 ? std::max(c->nchunks, 1) : wgs);   // slab capacity
+  stat_begin(c);
+  switch (c->NT) {
+    case 1: PMFCHK(launch_csr_fused<1>(c, wgs)); break;
+    case 2: PMFCHK(launch_csr_fused<2>(c, wgs)); break;
+    case 4: PMFCHK(launch_csr_fused<4>(c, wgs)); break;
+    case 8: PMFCHK(launch_csr_fused<8>(c, wgs)); break;
+    default: return fail(c, PMF_EINVAL, "bad NT");
+  }
+  stat_end(c);
+  PMFCHK(reduce_slabs(c, wgs));
+  return h_step_from_ps(c);
+}
+
 int snmf_update_h(pmf_ctx* c) {
   PMFCHK(ps_tiled(c));
   return h_step_from_ps(c);
@@ -783,7 +830,9 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   int done = 0;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
-    if (fused) {                                          // update_w + update_h, one pass over V
+    if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
+      PMFCHK(snmf_csr_fused_iteration(c));                // CSR: one pass over the rows
+    } else if (fused) {                                   // update_w + update_h, one pass over V
       PMFCHK(c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c));
     } else {
       if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184

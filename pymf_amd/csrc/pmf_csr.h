@@ -91,3 +91,184 @@ __global__ __launch_bounds__(256) void k_csr_p(const int64_t* __restrict__ indpt
     base[(int64_t)kk * ldp + col] = pt[col * KP + kk];
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// One pass over the CSR rows per SNMF iteration (cfg5): per 16-row block a wave
+//   (1) forms the new W rows  W[r][:] = sum_nz val * M[col][:]   (M = H^T inv(H H^T) in LDS),
+//       writes them to HBM once and into its LDS tile,
+//   (2) scatters  Pt[col][:] += val * W[r][:]   (P = W^T V, transposed LDS accumulator shared by
+//       the workgroup, LDS float atomics),
+//   (3) accumulates S += W_b^T W_b on MFMA from the LDS tile (tiles on/above the diagonal only).
+// W is never re-read: HBM traffic = CSR arrays once + W written once.  One workgroup per CU
+// (M 4*np*KP B + Pt 4*np*KP B + 4 tiles of 16 x KP floats of LDS).
+// Output: row-major slab[blockIdx] = (P | S) like k_colgemm, reduced by k_reduce_slabs.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_snmf_csr_fused(const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices,
+                                                           const float* __restrict__ vals,
+                                                           int blk_per, int blk_extra, int np,
+                                                           const float* __restrict__ M,
+                                                           float* __restrict__ W,
+                                                           float* __restrict__ slab) {
+  constexpr int KP = 16 * NT;
+  constexpr int VPL = (KP + 63) / 64;
+  constexpr int NS = NT * (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sM = sm;                          // [np][KP]
+  float* sPt = sM + (size_t)np * KP;       // [np][KP]
+  float* sWall = sPt + (size_t)np * KP;    // 4 x [16][KP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  float* sWt = sWall + wv * (16 * KP);
+  for (int q = tid; q < np * KP / 4; q += 256) {
+    reinterpret_cast<f32x4*>(sM)[q] = reinterpret_cast<const f32x4*>(M)[q];
+    reinterpret_cast<f32x4*>(sPt)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+
+  const int gw = blockIdx.x * 4 + wv;
+  const int b0 = gw * blk_per + (gw < blk_extra ? gw : blk_extra);
+  const int nb = blk_per + (gw < blk_extra ? 1 : 0);
+
+  f32x4 S[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Software pipeline over blocks: the row pointers of block b+1 are requested while block b's rows
+  // are processed, its column/value run while block b's MFMAs execute -- the two dependent HBM
+  // round trips per block are off the critical path.
+  auto load_ip = [&](int blk) -> long long {
+    return (long long)indptr[(int64_t)blk * 16 + (lane < 17 ? lane : 16)];
+  };
+  auto base_of = [&](long long ipv) -> long long {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(ipv & 0xffffffffll), 0);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(ipv >> 32), 0);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  long long ipv = nb > 0 ? load_ip(b0) : 0;
+  long long a = base_of(ipv);
+  int rel = (int)(ipv - a);
+  int nzb = __builtin_amdgcn_readlane(rel, 16);
+  int colv = 0;
+  float valv = 0.f;
+  if (lane < nzb) { colv = indices[a + lane]; valv = vals[a + lane]; }
+
+  for (int b = 0; b < nb; ++b) {
+    const int64_t r0 = (int64_t)(b0 + b) * 16;
+    const bool more = b + 1 < nb;
+    const long long ipv_n = more ? load_ip(b0 + b + 1) : 0;       // in flight during the row loop
+    auto fetch = [&](int e, int& col, float& val) {       // e wave-uniform
+      if (e < 64) {
+        col = __builtin_amdgcn_readlane(colv, e);
+        val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valv), e));
+      } else {
+        col = indices[a + e];
+        val = vals[a + e];
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ea_u = __builtin_amdgcn_readlane(rel, r), eb_u = __builtin_amdgcn_readlane(rel, r + 1);
+      float acc[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = 0.f;
+      for (int e = ea_u; e < eb_u; ++e) {
+        int col; float val;
+        fetch(e, col, val);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int kk = lane + 64 * v;
+          if (kk < KP) acc[v] = fmaf(val, sM[col * KP + kk], acc[v]);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int kk = lane + 64 * v;
+        if (kk < KP) {
+          W[(r0 + r) * KP + kk] = acc[v];
+          sWt[r * KP + kk] = acc[v];
+        }
+      }
+      for (int e = ea_u; e < eb_u; ++e) {          // P^T[col][:] += val * W[r][:]
+        int col; float val;
+        fetch(e, col, val);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int kk = lane + 64 * v;
+          if (kk < KP) atomicAdd(&sPt[col * KP + kk], val * acc[v]);
+        }
+      }
+    }
+    // next block's column/value run: requested now, lands under the MFMAs below
+    const long long a_n = base_of(ipv_n);
+    const int rel_n = (int)(ipv_n - a_n);
+    const int nzb_n = __builtin_amdgcn_readlane(rel_n, 16);
+    int colv_n = 0;
+    float valv_n = 0.f;
+    if (more && lane < nzb_n) { colv_n = indices[a_n + lane]; valv_n = vals[a_n + lane]; }
+    // S += W_b^T W_b: A[i = base][k = row]; MFMA step j contracts rows {4q + j}
+    float af[NT][4];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[mt][j] = sWt[(4 * kq + j) * KP + 16 * mt + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int t = 0;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = mt; nt < NT; ++nt, ++t) S[t] = mfma16(af[mt][j], af[nt][j], S[t]);
+    }
+    ipv = ipv_n; a = a_n; rel = rel_n; nzb = nzb_n; colv = colv_n; valv = valv_n;
+  }
+
+  // ---- S: sum the 4 waves through LDS (the M image is dead now), wave 0 writes it row-major ----
+  __syncthreads();
+  f32x4* ex = reinterpret_cast<f32x4*>(sM);     // NS*64 f32x4 = NS KiB per region, 2 regions <= 4*np*KP B
+  auto put = [&](int region) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t) ex[((size_t)region * NS + t) * 64 + lane] = S[t];
+  };
+  auto add = [&](int region) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t) S[t] += ex[((size_t)region * NS + t) * 64 + lane];
+  };
+  const bool two_regions = (size_t)2 * NS * 1024 <= (size_t)np * KP * 4;
+  if (two_regions) {
+    if (wv >= 2) put(wv - 2);
+    __syncthreads();
+    if (wv < 2) add(wv);
+    __syncthreads();
+    if (wv == 1) put(0);
+    __syncthreads();
+    if (wv == 0) add(0);
+  } else {                                        // tiny n*k: one region, three rounds
+    for (int src = 1; src < 4; ++src) {
+      if (wv == src) put(0);
+      __syncthreads();
+      if (wv == 0) add(0);
+      __syncthreads();
+    }
+  }
+  const int64_t ldp = (int64_t)np + KP;
+  float* base = slab + (int64_t)blockIdx.x * KP * ldp;
+  if (wv == 0) {
+    int t = 0;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = mt; nt < NT; ++nt, ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) base[(int64_t)(16 * mt + 4 * kq + j) * ldp + np + 16 * nt + i] = S[t][j];
+        if (nt > mt)
+          *reinterpret_cast<f32x4*>(base + (int64_t)(16 * nt + i) * ldp + np + 16 * mt + 4 * kq) = S[t];
+      }
+  }
+  // ---- P = Pt^T (all waves; Pt is complete since the barrier above) ----
+  for (int q = tid; q < np * KP; q += 256) {
+    const int kk = q / np, col = q % np;
+    base[(int64_t)kk * ldp + col] = sPt[col * KP + kk];
+  }
+}
