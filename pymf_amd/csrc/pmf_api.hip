@@ -367,14 +367,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
 // ---- SNMF -----------------------------------------------------------------------------------
 int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan), identity on the padding
   PMFCHK(ensure_gram(c, 1.0));
-  const size_t smem = ((size_t)c->k * c->k + 2 * (size_t)c->k) * sizeof(double) + ((size_t)c->k + 2) * sizeof(int);
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k_inverse, dim3(1), dim3(1024), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
+  hipLaunchKernelGGL(k_inverse_spd, dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -425,6 +418,37 @@ int launch_csr_fused(pmf_ctx* c, int wgs) {
   return PMF_OK;
 }
 
+template <int NT, int NTP>
+int launch_csr_mfma(pmf_ctx* c, int wgs) {
+  const size_t smem = ((size_t)16 * NTP * 16 * NT + 64 * 16 * NTP) * sizeof(float) + 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_csr_mfma<NT, NTP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  const int nblk = (int)(c->mp / 16), nw = wgs * 4;
+  hipLaunchKernelGGL((k_snmf_csr_mfma<NT, NTP>), dim3(wgs), dim3(256), smem, c->stream, c->dIndptr,
+                     c->dIndices, c->dVals, nblk / nw, nblk % nw, c->dW1, c->dW, c->dSlab);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+// MFMA variant for the register-resident P shapes; false: not covered (LDS-atomic kernel instead)
+bool csr_mfma(pmf_ctx* c, int wgs, int* rc) {
+  if (c->np % 16) return false;
+  const int key = c->NT * 100 + c->np / 16;
+  switch (key) {
+    case 808: *rc = launch_csr_mfma<8, 8>(c, wgs); return true;
+    case 408: *rc = launch_csr_mfma<4, 8>(c, wgs); return true;
+    case 404: *rc = launch_csr_mfma<4, 4>(c, wgs); return true;
+    case 208: *rc = launch_csr_mfma<2, 8>(c, wgs); return true;
+    case 108: *rc = launch_csr_mfma<1, 8>(c, wgs); return true;
+    case 104: *rc = launch_csr_mfma<1, 4>(c, wgs); return true;
+  }
+  return false;
+}
+
 bool csr_fused_ok(const pmf_ctx* c) {
   const size_t smem = ((size_t)2 * c->np * c->KP + 4 * 16 * c->KP) * sizeof(float);
   return c->v_csr && smem <= 160 * 1024;
@@ -443,6 +467,13 @@ int snmf_csr_fused_iteration(pmf_ctx* c) {
   int wgs = (int)std::min<int64_t>((c->mp / 16 + 3) / 4, cus);
   wgs = std::min(wgs, c->nchunks > 0 ? std::max(c->nchunks, 1) : wgs);   // slab capacity
   stat_begin(c);
+  int mrc = PMF_OK;
+  if (csr_mfma(c, wgs, &mrc)) {
+    stat_end(c);
+    PMFCHK(mrc);
+    PMFCHK(reduce_slabs(c, wgs));
+    return h_step_from_ps(c);
+  }
   switch (c->NT) {
     case 1: PMFCHK(launch_csr_fused<1>(c, wgs)); break;
     case 2: PMFCHK(launch_csr_fused<2>(c, wgs)); break;

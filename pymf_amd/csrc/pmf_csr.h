@@ -272,3 +272,221 @@ __global__ __launch_bounds__(256, 1) void k_snmf_csr_fused(const int64_t* __rest
     base[(int64_t)kk * ldp + col] = sPt[col * KP + kk];
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_snmf_csr_mfma<NT,NTP>: the one-pass CSR iteration with P = W^T V on MFMA as well.
+// Per 16-row block a wave
+//   (1) scatters the block's non-zeros into its private, otherwise all-zero, dense 16 x np LDS tile
+//       (one ds_add per non-zero, all lanes at once) and ORs a bit per occupied (row%4, column
+//       tile) into a 32-bit occupancy mask;
+//   (2) forms the new W rows directly in the MFMA A-fragment layout: lane (i, q) accumulates
+//       W[4q + j][16*mt + i], j = 0..3, from M = H^T inv(H H^T) in LDS -- 4 rows in flight per step;
+//   (3) S += W_b^T W_b (upper tiles) and, only for occupied (j, column tile) pairs,
+//       P[:, tile] += W_b^T V_b on MFMA from the dense tile; about half of the pairs are empty at 1 %;
+//   (4) writes zeros back over the scattered entries (the tile is all-zero again).
+// No float atomics on P, fixed summation order => reproducible.  P (NT x NTP tiles) and S stay
+// in registers for the wave's row range; one workgroup per CU.
+template <int NT, int NTP>
+__global__ __launch_bounds__(256, 1) void k_snmf_csr_mfma(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ vals,
+                                                          int blk_per, int blk_extra,
+                                                          const float* __restrict__ M,
+                                                          float* __restrict__ W,
+                                                          float* __restrict__ slab) {
+  constexpr int KP = 16 * NT, NP = 16 * NTP;
+  constexpr int NS = NT * (NT + 1) / 2;
+  static_assert(4 * NTP <= 32, "occupancy mask is 32 bits");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sM = sm;                                   // [NP][KP]
+  float* sVall = sM + NP * KP;                      // 4 x [16][NP]
+  unsigned* sMask = reinterpret_cast<unsigned*>(sVall + 4 * 16 * NP);   // [4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  float* sV = sVall + wv * (16 * NP);
+  for (int q = tid; q < NP * KP / 4; q += 256) reinterpret_cast<f32x4*>(sM)[q] = reinterpret_cast<const f32x4*>(M)[q];
+  for (int q = tid; q < 4 * 16 * NP / 4; q += 256) reinterpret_cast<f32x4*>(sVall)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 4) sMask[tid] = 0u;
+  __syncthreads();
+
+  const int gw = blockIdx.x * 4 + wv;
+  const int b0 = gw * blk_per + (gw < blk_extra ? gw : blk_extra);
+  const int nb = blk_per + (gw < blk_extra ? 1 : 0);
+
+  f32x4 P[NT][NTP];
+  f32x4 S[NS];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) P[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NS; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_ip = [&](int blk) -> long long {
+    return (long long)indptr[(int64_t)blk * 16 + (lane < 17 ? lane : 16)];
+  };
+  auto base_of = [&](long long ipv) -> long long {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(ipv & 0xffffffffll), 0);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(ipv >> 32), 0);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  long long ipv = nb > 0 ? load_ip(b0) : 0;
+  long long a = base_of(ipv);
+  int rel = (int)(ipv - a);
+  int nzb = __builtin_amdgcn_readlane(rel, 16);
+  int colv = 0;
+  float valv = 0.f;
+  if (lane < nzb) { colv = indices[a + lane]; valv = vals[a + lane]; }
+
+  for (int b = 0; b < nb; ++b) {
+    const int64_t r0 = (int64_t)(b0 + b) * 16;
+    const bool more = b + 1 < nb;
+    const long long ipv_n = more ? load_ip(b0 + b + 1) : 0;       // lands during this block
+
+    int rb[17];                                   // row boundaries (scalar)
+#pragma unroll
+    for (int r = 0; r < 17; ++r) rb[r] = __builtin_amdgcn_readlane(rel, r);
+
+    // ---- (1) scatter into the dense tile + occupancy mask ----
+    for (int base_e = 0; base_e < nzb; base_e += 64) {
+      const int e = base_e + lane;
+      int col = colv;
+      float val = valv;
+      if (base_e > 0 && e < nzb) { col = indices[a + e]; val = vals[a + e]; }
+      if (e < nzb) {
+        int row = 0;
+#pragma unroll
+        for (int r = 1; r < 16; ++r) row += (e >= rb[r]) ? 1 : 0;
+        atomicAdd(&sV[row * NP + col], val);                        // duplicates add up
+        atomicOr(&sMask[wv], 1u << ((row & 3) * NTP + (col >> 4)));
+      }
+    }
+    // ---- (2) new W rows in A-fragment layout: lane (i, kq) <-> rows 4kq + j ----
+    float af[NT][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // this lane group's row 4kq + j spans non-zeros [ea, eb)
+      const int ea = kq == 0 ? rb[j] : kq == 1 ? rb[4 + j] : kq == 2 ? rb[8 + j] : rb[12 + j];
+      const int eb = kq == 0 ? rb[j + 1] : kq == 1 ? rb[5 + j] : kq == 2 ? rb[9 + j] : rb[13 + j];
+      int cmax = rb[j + 1] - rb[j];
+      cmax = max(cmax, rb[5 + j] - rb[4 + j]);
+      cmax = max(cmax, rb[9 + j] - rb[8 + j]);
+      cmax = max(cmax, rb[13 + j] - rb[12 + j]);
+      float acc[NT];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) acc[mt] = 0.f;
+      for (int it = 0; it < cmax; ++it) {
+        const int e = ea + it;
+        const bool on = e < eb;
+        int col = __shfl(colv, e & 63, 64);
+        float val = __shfl(valv, e & 63, 64);
+        if (on && e >= 64) { col = indices[a + e]; val = vals[a + e]; }
+        if (!on) { col = 0; val = 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) acc[mt] = fmaf(val, sM[col * KP + 16 * mt + i], acc[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        af[mt][j] = acc[mt];
+        W[(r0 + 4 * kq + j) * KP + 16 * mt + i] = acc[mt];
+      }
+    }
+    // next block's column/value run: requested now, lands under the MFMAs below
+    const long long a_n = base_of(ipv_n);
+    const int rel_n = (int)(ipv_n - a_n);
+    const int nzb_n = __builtin_amdgcn_readlane(rel_n, 16);
+    int colv_n = 0;
+    float valv_n = 0.f;
+    if (more && lane < nzb_n) { colv_n = indices[a_n + lane]; valv_n = vals[a_n + lane]; }
+
+    // ---- (3) S += W_b^T W_b;  P += W_b^T V_b for the occupied (j, column tile) pairs ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int t = 0;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = mt; nt < NT; ++nt, ++t) S[t] = mfma16(af[mt][j], af[nt][j], S[t]);
+    }
+    const unsigned occ = __builtin_amdgcn_readfirstlane(sMask[wv]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NTP; ++nt)
+        if ((occ >> (j * NTP + nt)) & 1u) {
+          const float bf = sV[(4 * kq + j) * NP + 16 * nt + i];
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) P[mt][nt] = mfma16(af[mt][j], bf, P[mt][nt]);
+        }
+    // ---- (4) restore the all-zero tile and mask ----
+    for (int base_e = 0; base_e < nzb; base_e += 64) {
+      const int e = base_e + lane;
+      int col = colv;
+      if (base_e > 0 && e < nzb) col = indices[a + e];
+      if (e < nzb) {
+        int row = 0;
+#pragma unroll
+        for (int r = 1; r < 16; ++r) row += (e >= rb[r]) ? 1 : 0;
+        sV[row * NP + col] = 0.f;
+      }
+    }
+    if (lane == 0) sMask[wv] = 0u;
+    ipv = ipv_n; a = a_n; rel = rel_n; nzb = nzb_n; colv = colv_n; valv = valv_n;
+  }
+
+  // ---- sum the 4 waves (serially through LDS: once per launch), wave 0 writes the row-major slab ----
+  __syncthreads();
+  f32x4* ex = reinterpret_cast<f32x4*>(sm);       // the M image is dead: NT*NTP KiB = its size
+  static_assert(NS <= NT * NTP, "S exchange fits into the M image");
+  for (int src = 1; src < 4; ++src) {             // P
+    if (wv == src) {
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) ex[(mt * NTP + nt) * 64 + lane] = P[mt][nt];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) P[mt][nt] += ex[(mt * NTP + nt) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  for (int src = 1; src < 4; ++src) {             // S
+    if (wv == src) {
+#pragma unroll
+      for (int t = 0; t < NS; ++t) ex[t * 64 + lane] = S[t];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int t = 0; t < NS; ++t) S[t] += ex[t * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+    const int64_t ldp = (int64_t)NP + KP;
+    float* base = slab + (int64_t)blockIdx.x * KP * ldp;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* rowp = base + (int64_t)(16 * mt + 4 * kq + j) * ldp;
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) rowp[16 * nt + i] = P[mt][nt][j];
+      }
+    int t = 0;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = mt; nt < NT; ++nt, ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) base[(int64_t)(16 * mt + 4 * kq + j) * ldp + NP + 16 * nt + i] = S[t][j];
+        if (nt > mt)
+          *reinterpret_cast<f32x4*>(base + (int64_t)(16 * nt + i) * ldp + NP + 16 * mt + 4 * kq) = S[t];
+      }
+  }
+}
