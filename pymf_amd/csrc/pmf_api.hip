@@ -365,7 +365,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
 }
 
 // ---- SNMF -----------------------------------------------------------------------------------
-int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan), identity on the padding
+int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan in registers), identity on the padding
   PMFCHK(ensure_gram(c, 1.0));
   hipLaunchKernelGGL(k_inverse_spd, dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
   HIPCHK(c, hipGetLastError());

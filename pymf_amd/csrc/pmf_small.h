@@ -200,86 +200,13 @@ __global__ __launch_bounds__(256) void k_snmf_h(float* __restrict__ H, int64_t l
   }
 }
 
-// In-place float64 Gauss-Jordan inverse with partial pivoting of the leading k x k block of Gd
-// (ld = KP), whole matrix in LDS; writes float32 inv(G)^T into GinvT[KP][KP] (identity on the
-// padding) so that k_rowgemm's B[n][k] operand reads inv[k][n].  One block of 1024 threads;
-// thread t owns column j0 = t % kc of rows r0, r0 + rs, ... (kc = k rounded up to a power-of-two
-// friendly stride is not needed: rs = 1024 / k rows per sweep), so the elimination sweep has no
-// integer division.  Mirrors np.linalg.inv (snmf.py:70): no singularity handling beyond LAPACK's.
-__global__ __launch_bounds__(1024) void k_inverse(const double* __restrict__ Gd, int KP, int k,
-                                                  float* __restrict__ GinvT) {
-  extern __shared__ __attribute__((aligned(16))) double a[];   // [k][k], prow[k], pcol[k], int piv[k+1]
-  double* prow = a + (size_t)k * k;
-  double* pcol = prow + k;
-  int* ipiv = reinterpret_cast<int*>(pcol + k);
-  int& s_piv = ipiv[k];
-  const int tid = threadIdx.x;
-  const int j0 = tid % k, r0 = tid / k;          // one division per thread, outside the loops
-  const int rs = 1024 / k;                       // rows covered per sweep (k <= 128 -> rs >= 8)
-  const bool owner = r0 < rs;                    // threads beyond rs*k idle in the sweeps
-  for (int q = tid; q < k * k; q += 1024) a[q] = Gd[(int64_t)(q / k) * KP + (q % k)];
-  __syncthreads();
-  for (int p = 0; p < k; ++p) {
-    if (tid < 64) {   // wave 0: argmax |a[r][p]|, r >= p
-      double best = -1.0;
-      int bi = p;
-      for (int r = p + tid; r < k; r += 64) {
-        const double v = fabs(a[r * k + p]);
-        if (v > best) { best = v; bi = r; }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      }
-      if (tid == 0) { s_piv = bi; ipiv[p] = bi; }
-    }
-    __syncthreads();
-    const int piv = s_piv;
-    if (tid < k) {                                // swap rows p <-> piv, publish the pivot row
-      const double top = a[piv * k + tid];
-      if (piv != p) { a[piv * k + tid] = a[p * k + tid]; }
-      prow[tid] = top;
-    }
-    __syncthreads();
-    const double d = 1.0 / prow[p];
-    if (tid < k) {                                // pivot column (after the swap), scaled pivot row
-      pcol[tid] = (tid == p) ? 0.0 : a[tid * k + p];
-      a[p * k + tid] = (tid == p) ? d : prow[tid] * d;
-    }
-    __syncthreads();
-    if (owner) {
-      const double pr = (j0 == p) ? 0.0 : prow[j0] * d;   // scaled pivot row element of my column
-      for (int r = r0; r < k; r += rs) {
-        if (r == p) continue;
-        const double f = pcol[r];
-        a[r * k + j0] = (j0 == p) ? -f * d : fma(-f, pr, a[r * k + j0]);
-      }
-    }
-    __syncthreads();
-  }
-  for (int p = k - 1; p >= 0; --p) {   // undo the row swaps as column swaps
-    const int piv = ipiv[p];
-    if (piv != p && tid < k) {
-      const double t = a[tid * k + p]; a[tid * k + p] = a[tid * k + piv]; a[tid * k + piv] = t;
-    }
-    __syncthreads();
-  }
-  for (int q = tid; q < KP * KP; q += 1024) {
-    const int r = q / KP, c = q % KP;   // GinvT[r][c] = inv[c][r]
-    float v = (r == c) ? 1.f : 0.f;
-    if (r < k && c < k) v = (float)a[c * k + r];
-    GinvT[q] = v;
-  }
-}
-
 // inv(G) for the Gram matrix G = H H^T (symmetric positive definite when H has full row rank, which
 // snmf.py:69-70 needs anyway): in-place float64 Gauss-Jordan WITHOUT pivoting -- on an SPD matrix
 // every pivot is a positive Schur complement and the elimination is as stable as Cholesky.
 // The 128 x 128 (identity-padded) matrix lives in REGISTERS: thread (ty, tx) of 32 x 32 owns rows
 // {ty + 32u} x columns {tx + 32v}, u, v < 4.  Per pivot only the pivot row and column go through
-// LDS (double buffered => ONE barrier per pivot).  ~0.05 ms at k = 128 vs 0.43 ms for k_inverse.
+// LDS (double buffered => ONE barrier per pivot).  Writes float32 inv(G)^T into GinvT[KP][KP]
+// (identity on the padding) so that a B[n][k] MFMA operand reads inv[k][n].
 __global__ __launch_bounds__(1024) void k_inverse_spd(const double* __restrict__ Gd, int KP, int k,
                                                       float* __restrict__ GinvT) {
   __shared__ double prow[2][128];
