@@ -15,7 +15,7 @@ os.environ.setdefault("NCCL_IB_DISABLE", "1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpymf_hip.so")
+LIB_PATH = os.environ.get("PMF_LIB") or os.path.join(_HERE, "csrc", "libpymf_hip.so")   # PMF_LIB: A/B builds
 
 PMF_OK = 0
 ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF = 0, 1, 2, 3
