@@ -60,14 +60,8 @@ def gen_rows(seed_state, m_total, ncols, lo, hi, chunk=65536):
     return out
 
 
-def cpu_baseline(m, n, k, budget_s=20.0):
-    """The oracle (NumPy restatement of pymf/nmf.py:122-132) on a bounded row sample."""
+def _time_oracle(V, W, H, budget_s):
     from oracle import nmf_update_w, nmf_update_h
-    ms = min(m, 32768)
-    V = np.random.RandomState(1234).random_sample((ms, n)).astype(np.float32)
-    np.random.seed(42)
-    W = np.random.random((ms, k))             # float64, the reference's default init
-    H = np.random.random((k, n))
     nmf_update_w(V, W, H)
     nmf_update_h(V, W, H)                     # warm-up iteration
     t0 = time.time()
@@ -79,6 +73,20 @@ def cpu_baseline(m, n, k, budget_s=20.0):
         dt = time.time() - t0
         if (it >= 3 and dt > budget_s * 0.5) or dt > budget_s or it >= 50:
             break
+    return it, dt
+
+
+def cpu_baseline(m, n, k, budget_s=20.0):
+    """The oracle (NumPy restatement of pymf/nmf.py:122-132) on a bounded row sample, in the two
+    variants BASELINE.md section 3 asks for: reference-default (float64 W/H, float32 V) = `value`,
+    and all-float32."""
+    ms = min(m, 32768)
+    V = np.random.RandomState(1234).random_sample((ms, n)).astype(np.float32)
+    np.random.seed(42)
+    W = np.random.random((ms, k))             # float64, the reference's default init
+    H = np.random.random((k, n))
+    it, dt = _time_oracle(V, W.copy(), H.copy(), budget_s * 0.7)
+    it32, dt32 = _time_oracle(V, W.astype(np.float32), H.astype(np.float32), budget_s * 0.3)
     rate_sample = it / dt
     threads = os.cpu_count() or 1
     try:
@@ -93,10 +101,12 @@ def cpu_baseline(m, n, k, budget_s=20.0):
         "unit": "iter/s",
         "cores": threads,
         "kind": "port",
+        "value_all_fp32": (it32 / dt32) * ms / float(m),
         "sample": "oracle NMF (reference op order, float64 W/H, float32 V) on the first %d of %d rows, "
                   "n=%d k=%d: %d iterations in %.2f s = %.3f iter/s on the sample, scaled by %d/%d "
-                  "(cost is linear in rows); numpy %s, host cpu_count=%d" %
-                  (ms, m, n, k, it, dt, rate_sample, ms, m, np.__version__, os.cpu_count() or 1),
+                  "(cost is linear in rows); all-float32 variant: %d iterations in %.2f s; numpy %s, "
+                  "host cpu_count=%d" %
+                  (ms, m, n, k, it, dt, rate_sample, ms, m, it32, dt32, np.__version__, os.cpu_count() or 1),
     }
 
 

@@ -309,3 +309,27 @@ def test_snmf_fused_and_tiled_paths_agree(pm):
         b.update_h()
     assert rel_fro(a.get_w(), b.get_w()) < 1e-5
     assert rel_fro(a.get_h(), b.get_h()) < 1e-5
+
+
+def test_bitwise_reproducible(pm):
+    """Fixed-order partial sums everywhere on the dense paths: two runs give identical bits."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(77)
+    m, n, k = 20000, 256, 64
+    V = rs.random_sample((m, n)).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        for algo in (_lib.ALGO_NMF, _lib.ALGO_SNMF, _lib.ALGO_BNMF):
+            ctx = _lib.Context(algo, m, n, k)
+            ctx.set_v_dense(V); ctx.set_w(W0); ctx.set_h(H0)
+            if algo == _lib.ALGO_BNMF:
+                ctx.set_lambda(0.2, 0.2)
+            ferr, _, _ = ctx.factorize(5)
+            outs.append((ctx.get_w(), ctx.get_h(), ferr))
+            ctx.close()
+    for a, b in zip(outs[:3], outs[3:]):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
