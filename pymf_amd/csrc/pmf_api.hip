@@ -60,6 +60,8 @@ struct pmf_ctx {
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
   bool ps_valid = false;        // dPS = (W^T V | W^T W) of the CURRENT W, summed over all ranks
+  bool want_trace = false;      // pmf_factorize with PMF_COMPUTE_ERR: let the H-step kernel emit the trace terms
+  bool trace_ready = false;     // dScal[2..3] already hold <P,H>, <S,HH^T> for the current W, H
   bool vnorm_valid = false;
   double vnorm2 = 0.0;          // ||V||_F^2 over all ranks
   double lamb_w = 0.0, lamb_h = 0.0;   // BNMF penalty weights (bnmf.py:84-85,118-119)
@@ -269,7 +271,7 @@ int launch_h_gram(pmf_ctx* c) {
     attr_done = true;
   }
   hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL, false>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
-                     c->dG, c->dGd, 0.f);
+                     c->dG, c->dGd, 0.f, c->want_trace ? c->dScal + 2 : nullptr);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -284,7 +286,7 @@ int launch_h_gram_b(pmf_ctx* c) {
     attr_done = true;
   }
   hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL, true>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
-                     c->dG, c->dGd, (float)c->lamb_h);
+                     c->dG, c->dGd, (float)c->lamb_h, c->want_trace ? c->dScal + 2 : nullptr);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -315,6 +317,7 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
     PMFCHK(hrc);
     c->g_valid = true;     // G (pad rows/cols are zero because the padded H rows are zero)
     c->ps_valid = true;
+    c->trace_ready = c->want_trace;
     if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
     return PMF_OK;
   }
@@ -329,6 +332,7 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
   c->ps_valid = true;    // dPS belongs to the current W (update_h never touches W)
+  c->trace_ready = false;
   if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
   return PMF_OK;
 }
@@ -518,6 +522,7 @@ int als_update_h(pmf_ctx* c) {
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
   c->ps_valid = true;
+  c->trace_ready = false;
   return PMF_OK;
 }
 
@@ -585,14 +590,18 @@ int ensure_vnorm(pmf_ctx* c) {
 int do_frobenius(pmf_ctx* c, double* out) {
   if (c->v_csr || !c->ps_valid) return frobenius_direct(c, out);
   PMFCHK(ensure_vnorm(c));
-  const int nb = c->np / 16;
-  hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
-                     c->dH, (int64_t)c->np, c->np, c->KP, c->dPS, c->dPart);
-  HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
-  HIPCHK(c, hipGetLastError());
   double t[2] = {0.0, 0.0};
-  HIPCHK(c, hipMemcpyAsync(t, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (c->trace_ready && c->ps_valid) {   // the H-step kernel already produced both terms
+    HIPCHK(c, hipMemcpyAsync(t, c->dScal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  } else {
+    const int nb = c->np / 16;
+    hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
+                       c->dH, (int64_t)c->np, c->np, c->KP, c->dPS, c->dPart);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(t, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const double e2 = c->vnorm2 - 2.0 * t[0] + t[1];
   if (!(e2 > 1e-3 * c->vnorm2)) return frobenius_direct(c, out);
@@ -856,6 +865,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   if (niter < 0 || (ce && !ferr)) return fail(c, PMF_EINVAL, "pmf_factorize: bad arguments");
   if (iters_done) *iters_done = 0;
   if (converged_at) *converged_at = -1;
+  c->want_trace = ce;
   const bool fused = cw && ch && c->fused_wgs > 0 && !c->v_csr &&
                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -881,6 +891,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       }
     }
   }
+  c->want_trace = false;
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;

@@ -71,7 +71,11 @@ template <int NT, int NPANEL, bool BNMF>
 __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
                                                      const float* __restrict__ PS,
                                                      float* __restrict__ Gf, double* __restrict__ Gd,
-                                                     float lamb) {
+                                                     float lamb, double* __restrict__ tout) {
+  // tout (optional): the two data-dependent terms of the trace identity for the residual,
+  //   tout[0] = <P, H_new>,  tout[1] = <S H_new, H_new> = <S, H_new H_new^T> = <S, G>,
+  // both fall out of values this kernel holds anyway (float64 sums).
+  __shared__ double red[2][16];
   constexpr int KP = 16 * NT, NP = 64 * NPANEL, NCT = NP / 16;
   constexpr int LDS_S = KP + 4, LDS_H = NP + 4;
   constexpr int64_t ldp = NP + KP;
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
         *reinterpret_cast<const f32x4*>(H + (int64_t)r * NP + 4 * c4);
   }
   __syncthreads();
+  double t1 = 0.0, t2 = 0.0;
   // ---- H step: wave w <-> column tiles w, w+16, ... ----
 #pragma unroll
   for (int cw = 0; cw < NCTW; ++cw) {
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
         }
         H[(int64_t)kk * NP + col] = hn;
         hs[kk * LDS_H + col] = hn;    // only this wave reads/writes these 16 columns in this step
+        t1 = fma((double)pv[cw][mt][r], (double)hn, t1);
       }
   }
   __syncthreads();
@@ -167,6 +173,20 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
       const int a = 16 * mt + 4 * kq + r, b = 16 * nt + i;
       Gf[a * KP + b] = g[r];
       if (Gd) Gd[a * KP + b] = (double)g[r];
+      t2 = fma((double)ss[a * LDS_S + b], (double)g[r], t2);
+    }
+  }
+  if (tout) {
+    t1 = wave_sum_f64(t1);
+    t2 = wave_sum_f64(t2);
+    if (lane == 0) { red[0][wv] = t1; red[1][wv] = t2; }
+    __syncthreads();
+    if (tid == 0) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { a1 += red[0][w]; a2 += red[1][w]; }
+      tout[0] = a1;
+      tout[1] = a2;
     }
   }
 }
