@@ -294,18 +294,23 @@ int launch_h_gram_b(pmf_ctx* c) {
 // NMF on the fused-kernel shapes: H step and G = H H^T in one launch.  false: shape not covered.
 bool nmf_h_gram(pmf_ctx* c, int* rc) {
   if (c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) return false;
-  const int key = c->NT * 10 + c->np / 64;
   if (c->np % 64) return false;
+  const int key = c->NT * 100 + c->np / 64;
   switch (key) {
-    case 11: *rc = launch_h_gram<1, 1>(c); return true;
-    case 12: *rc = launch_h_gram<1, 2>(c); return true;
-    case 14: *rc = launch_h_gram<1, 4>(c); return true;
-    case 21: *rc = launch_h_gram<2, 1>(c); return true;
-    case 22: *rc = launch_h_gram<2, 2>(c); return true;
-    case 24: *rc = launch_h_gram<2, 4>(c); return true;
-    case 41: *rc = launch_h_gram<4, 1>(c); return true;
-    case 42: *rc = launch_h_gram<4, 2>(c); return true;
-    case 44: *rc = launch_h_gram<4, 4>(c); return true;
+    case 101: *rc = launch_h_gram<1, 1>(c); return true;
+    case 102: *rc = launch_h_gram<1, 2>(c); return true;
+    case 104: *rc = launch_h_gram<1, 4>(c); return true;
+    case 108: *rc = launch_h_gram<1, 8>(c); return true;
+    case 116: *rc = launch_h_gram<1, 16>(c); return true;
+    case 201: *rc = launch_h_gram<2, 1>(c); return true;
+    case 202: *rc = launch_h_gram<2, 2>(c); return true;
+    case 204: *rc = launch_h_gram<2, 4>(c); return true;
+    case 208: *rc = launch_h_gram<2, 8>(c); return true;
+    case 216: *rc = launch_h_gram<2, 16>(c); return true;
+    case 401: *rc = launch_h_gram<4, 1>(c); return true;
+    case 402: *rc = launch_h_gram<4, 2>(c); return true;
+    case 404: *rc = launch_h_gram<4, 4>(c); return true;
+    case 408: *rc = launch_h_gram<4, 8>(c); return true;
   }
   return false;
 }
