@@ -333,3 +333,40 @@ def test_bitwise_reproducible(pm):
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_array_equal(a[2], b[2])
+
+
+def test_fused_vs_tiled_random_shapes(pm):
+    """Randomised sweep of (m, n, k) over the fused-kernel shape space, including row counts where
+    waves get 0, 1 or uneven numbers of 16-row blocks: fused factorize == tiled hooks."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(2024)
+    shapes = [(16, 64, 16), (15, 33, 7), (4096 * 16 + 16, 256, 64), (16400, 192, 48), (1023 * 16, 128, 64),
+              (1024 * 16, 64, 32), (1025 * 16 + 3, 256, 17), (70000, 250, 60), (33, 256, 64)]
+    for _ in range(10):
+        shapes.append((int(rs.randint(1, 40000)), int(rs.randint(1, 257)), int(rs.randint(1, 65))))
+    for (m, n, k) in shapes:
+        V = rs.random_sample((m, n)).astype(np.float32)
+        W0 = rs.random_sample((m, k)).astype(np.float32)
+        H0 = rs.random_sample((k, n)).astype(np.float32)
+        for algo in (_lib.ALGO_NMF, _lib.ALGO_SNMF):
+            if algo == _lib.ALGO_SNMF and 2 * k > n:
+                continue              # H H^T (k x k, rank <= n) is singular or nearly so: inv() is noise
+            a = _lib.Context(algo, m, n, k)
+            if not a.path_name.startswith("k_nmf_fused"):
+                a.close()
+                continue
+            a.set_v_dense(V); a.set_w(W0); a.set_h(H0)
+            fa, _, _ = a.factorize(2, compute_err=True)
+            b = _lib.Context(algo, m, n, k)
+            b.set_v_dense(V); b.set_w(W0); b.set_h(H0)
+            fb = []
+            for _ in range(2):
+                b.update_w(); b.update_h()
+                b.set_h(b.get_h())
+                fb.append(b.frobenius())
+            tol = 2e-5 if algo == _lib.ALGO_NMF else 5e-4     # SNMF: inv(H H^T) amplifies for k ~ n
+            assert rel_fro(a.get_h(), b.get_h()) < tol, (algo, m, n, k)
+            assert rel_fro(a.get_w(), b.get_w()) < tol, (algo, m, n, k)
+            if fb[-1] > 1e-3 * np.linalg.norm(V):
+                np.testing.assert_allclose(fa, np.array(fb), rtol=1e-4, err_msg=str((algo, m, n, k)))
+            a.close(); b.close()
