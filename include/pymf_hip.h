@@ -45,7 +45,7 @@ enum {
   PMF_ENOMEM = -4    /* device or host allocation failed */
 };
 
-enum { PMF_ALGO_NMF = 0, PMF_ALGO_NMFALS = 1, PMF_ALGO_SNMF = 2, PMF_ALGO_BNMF = 3 };
+enum { PMF_ALGO_NMF = 0, PMF_ALGO_NMFALS = 1, PMF_ALGO_SNMF = 2, PMF_ALGO_BNMF = 3, PMF_ALGO_RNMF = 4 };
 
 /* pmf_factorize flags (the reference's factorize() keyword arguments, nmf.py:141-142) */
 enum { PMF_COMPUTE_W = 1u, PMF_COMPUTE_H = 2u, PMF_COMPUTE_ERR = 4u };
@@ -111,6 +111,13 @@ int pmf_factorize(pmf_ctx* ctx, int32_t niter, uint32_t flags, double conv_eps,
  * The caller sets 1/niter before each factorize() like BNMF.factorize. */
 int pmf_set_lambda(pmf_ctx* ctx, double lamb_w, double lamb_h);
 int pmf_get_lambda(pmf_ctx* ctx, double* lamb_w, double* lamb_h);
+
+/* RNMF only (pymf/rnmf.py, algo 4; pmf_set_lambda(ctx, lamb, 0) sets the soft threshold _lamb):
+ * pmf_rnmf_update_s = RNMF.update_s (rnmf.py:96-98), S = soft_thresholding(data - W H, lamb);
+ * update_h runs it itself afterwards as the reference does (rnmf.py:107).  pmf_rnmf_get_s_f32
+ * copies S (m_local x n, row-major) to the host. */
+int pmf_rnmf_update_s(pmf_ctx* ctx);
+int pmf_rnmf_get_s_f32(pmf_ctx* ctx, float* S);
 
 /* Device time (ms, HIP events on the library's stream) of the last pmf_factorize loop. */
 int pmf_last_loop_ms(pmf_ctx* ctx, double* ms);

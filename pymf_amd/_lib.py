@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PMF_LIB") or os.path.join(_HERE, "csrc", "libpymf_hip.so")   # PMF_LIB: A/B builds
 
 PMF_OK = 0
-ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF = 0, 1, 2, 3
+ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF, ALGO_RNMF = 0, 1, 2, 3, 4
 COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
 NCCL_ID_BYTES = 128
 
@@ -49,6 +49,8 @@ SYMBOLS = [
                                  _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32)]),
     ("pmf_set_lambda", _c.c_int, [_ctx, _c.c_double, _c.c_double]),
     ("pmf_get_lambda", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
+    ("pmf_rnmf_update_s", _c.c_int, [_ctx]),
+    ("pmf_rnmf_get_s_f32", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_last_loop_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_profile_enable", _c.c_int, [_ctx, _c.c_int32]),
     ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
@@ -211,6 +213,14 @@ class Context(object):
         a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
         self._chk(self._lib.pmf_get_lambda(self._h, ctypes.byref(a), ctypes.byref(b)))
         return float(a.value), float(b.value)
+
+    def rnmf_update_s(self):
+        self._chk(self._lib.pmf_rnmf_update_s(self._h))
+
+    def rnmf_get_s(self):
+        S = np.empty((self.m, self.n), dtype=np.float32)
+        self._chk(self._lib.pmf_rnmf_get_s_f32(self._h, S.ctypes.data))
+        return S
 
     def last_loop_ms(self):
         ms = ctypes.c_double(0.0)

@@ -52,6 +52,9 @@ struct pmf_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float *dV = nullptr, *dW = nullptr, *dH = nullptr, *dG = nullptr, *dPS = nullptr;
   float *dSlab = nullptr, *dW1 = nullptr, *dGinvT = nullptr;
+  float* dD = nullptr;          // RNMF: D = S - V (rnmf.py:102,111), [mp][np]
+  bool s_valid = false;         // RNMF: D has been formed (update_s ran)
+  double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
   double *dGd = nullptr, *dPart = nullptr, *dScal = nullptr;
   // CSR V (SNMF sparse path)
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
@@ -146,7 +149,7 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
     attr_done = true;
   }
   hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)(c->mp / 64)), dim3(256), smem, c->stream,
-                     A, lda, kdimA, B, ldb, W, G, C, lamb);
+                     A, lda, kdimA, B, ldb, W, G, C, lamb, c->m, c->k);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -165,7 +168,7 @@ int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, 
 
 int colgemm(pmf_ctx* c, bool with_v = true) {
   dim3 grid((unsigned)c->nchunks, with_v ? (unsigned)((c->np + 255) / 256) : 1u);
-  const float* Vp = with_v ? c->dV : nullptr;
+  const float* Vp = with_v ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : nullptr;
   switch (c->NT) {
     case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
     case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
@@ -250,8 +253,30 @@ int need(pmf_ctx* c, bool v, bool w, bool h) {
 }
 
 // ---- NMF (multiplicative update) ---------------------------------------------------------
+int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2) in c->rnmf_err2
+  const int nb = (int)(c->mp / 64);
+  const float lamb = (float)c->lamb_w;
+  switch (c->NT) {
+    case 1: hipLaunchKernelGGL((k_rnmf_s<1>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
+    case 2: hipLaunchKernelGGL((k_rnmf_s<2>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
+    case 4: hipLaunchKernelGGL((k_rnmf_s<4>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
+    case 8: hipLaunchKernelGGL((k_rnmf_s<8>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 4);
+  HIPCHK(c, hipGetLastError());
+  if (c->comm) NCCLCHK(c, ncclAllReduce(c->dScal + 4, c->dScal + 4, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->rnmf_err2, c->dScal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  c->s_valid = true;
+  return PMF_OK;
+}
+
 int nmf_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 0.0));
+  if (c->algo == PMF_ALGO_RNMF) {
+    if (!c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+    return rowgemm<EPI_RNMF_W>(c, c->dD, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
+  }
   if (c->algo == PMF_ALGO_BNMF)
     return rowgemm<EPI_BNMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
   return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
@@ -293,7 +318,7 @@ int launch_h_gram_b(pmf_ctx* c) {
 
 // NMF on the fused-kernel shapes: H step and G = H H^T in one launch.  false: shape not covered.
 bool nmf_h_gram(pmf_ctx* c, int* rc) {
-  if (c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) return false;
+  if (c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) return false;   // RNMF: generic k_nmf_h
   if (c->np % 64) return false;
   const int key = c->NT * 100 + c->np / 64;
   switch (key) {
@@ -332,8 +357,9 @@ int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
                        (int64_t)c->np, c->np, c->KP, c->dPS);
   else
     hipLaunchKernelGGL(k_nmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
-                       (int64_t)c->np, c->np, c->KP, c->dPS, c->algo == PMF_ALGO_BNMF ? 1 : 0,
-                       (float)c->lamb_h);
+                       (int64_t)c->np, c->np, c->KP, c->dPS,
+                       c->algo == PMF_ALGO_BNMF ? 1 : c->algo == PMF_ALGO_RNMF ? 2 : 0, (float)c->lamb_h,
+                       c->k, (int)c->n);
   HIPCHK(c, hipGetLastError());
   c->g_valid = false;
   c->ps_valid = true;    // dPS belongs to the current W (update_h never touches W)
@@ -349,6 +375,13 @@ int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
 }
 
 int nmf_update_h(pmf_ctx* c) {
+  if (c->algo == PMF_ALGO_RNMF) {                // rnmf.py:100-107: H step on D = S - data, then update_s
+    if (!c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+    PMFCHK(ps_tiled(c));
+    PMFCHK(h_step_from_ps(c));
+    c->ps_valid = false;                         // (P | S) were built from D, not from V
+    return rnmf_update_s(c);
+  }
   PMFCHK(ps_tiled(c));
   return h_step_from_ps(c);
 }
@@ -536,6 +569,7 @@ int do_update_w(pmf_ctx* c) {
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_w(c);
     case PMF_ALGO_BNMF: return nmf_update_w(c);
+    case PMF_ALGO_RNMF: return nmf_update_w(c);
     case PMF_ALGO_SNMF: return snmf_update_w(c);
     case PMF_ALGO_NMFALS: return als_update_w(c);
   }
@@ -546,6 +580,7 @@ int do_update_h(pmf_ctx* c) {
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_h(c);
     case PMF_ALGO_BNMF: return nmf_update_h(c);
+    case PMF_ALGO_RNMF: return nmf_update_h(c);
     case PMF_ALGO_SNMF: return snmf_update_h(c);
     case PMF_ALGO_NMFALS: return als_update_h(c);
   }
@@ -676,7 +711,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
                    int32_t rank, int32_t nranks, const void* nccl_id) {
   if (!out) return fail(nullptr, PMF_EINVAL, "out is NULL");
   *out = nullptr;
-  if (algo < 0 || algo > 3) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF) or 3 (BNMF)");
+  if (algo < 0 || algo > 4) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF), 3 (BNMF) or 4 (RNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
   if (k > 128) return fail(nullptr, PMF_EINVAL, "num_bases > 128 is not supported by this build");
   if (algo == PMF_ALGO_NMFALS && k > 64)
@@ -720,6 +755,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
     PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
     PMFCHK(dalloc(c, &c->dScal, 8));
+    if (algo == PMF_ALGO_RNMF) PMFCHK(dalloc(c, &c->dD, (size_t)c->mp * c->np));
     if (algo != PMF_ALGO_NMF) {
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dGinvT, (size_t)c->KP * c->KP));
@@ -746,7 +782,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   for (void* p : {(void*)c->dV, (void*)c->dW, (void*)c->dH, (void*)c->dG, (void*)c->dPS, (void*)c->dSlab,
-                  (void*)c->dW1, (void*)c->dGinvT, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
+                  (void*)c->dW1, (void*)c->dGinvT, (void*)c->dD, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
   for (hipEvent_t e : c->stat.ev) hipEventDestroy(e);
@@ -885,8 +921,13 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       if (ch) PMFCHK(do_update_h(c));                     // nmf.py:186-187
     }
     ++done;
-    if (ce) {
+    if (ce && c->algo == PMF_ALGO_RNMF && ch) {           // update_s already summed (V - W H)^2
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      ferr[i] = std::sqrt(c->rnmf_err2);
+    } else if (ce) {
       PMFCHK(do_frobenius(c, &ferr[i]));                  // nmf.py:189-190
+    }
+    if (ce) {
       if (i > 1) {                                        // nmf.py:198
         const double derr = std::fabs(ferr[i] - ferr[i - 1]) / (double)c->n;   // nmf.py:135
         if (derr < conv_eps) {                            // nmf.py:136
@@ -908,7 +949,8 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
 
 int pmf_set_lambda(pmf_ctx* c, double lamb_w, double lamb_h) {
   if (!c) return PMF_EINVAL;
-  if (c->algo != PMF_ALGO_BNMF) return fail(c, PMF_EINVAL, "pmf_set_lambda: only BNMF has penalty weights");
+  if (c->algo != PMF_ALGO_BNMF && c->algo != PMF_ALGO_RNMF)
+    return fail(c, PMF_EINVAL, "pmf_set_lambda: only BNMF (penalty weights) and RNMF (threshold) take it");
   c->lamb_w = lamb_w; c->lamb_h = lamb_h;
   return PMF_OK;
 }
@@ -916,6 +958,26 @@ int pmf_set_lambda(pmf_ctx* c, double lamb_w, double lamb_h) {
 int pmf_get_lambda(pmf_ctx* c, double* lamb_w, double* lamb_h) {
   if (!c || !lamb_w || !lamb_h) return PMF_EINVAL;
   *lamb_w = c->lamb_w; *lamb_h = c->lamb_h;
+  return PMF_OK;
+}
+
+int pmf_rnmf_update_s(pmf_ctx* c) {
+  PMFCHK(need(c, true, true, true));
+  if (c->algo != PMF_ALGO_RNMF) return fail(c, PMF_EINVAL, "pmf_rnmf_update_s: RNMF only");
+  PMFCHK(rnmf_update_s(c));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
+}
+
+int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
+  PMFCHK(need(c, true, false, false));
+  if (c->algo != PMF_ALGO_RNMF || !c->s_valid || !S) return fail(c, PMF_EINVAL, "pmf_rnmf_get_s_f32: no S");
+  // S = D + V, formed row block by row block on the host from the two device images
+  std::vector<float> d((size_t)c->n), v((size_t)c->n);
+  std::vector<float> Dh((size_t)c->m * c->n), Vh((size_t)c->m * c->n);
+  PMFCHK(download_padded(c, Dh.data(), c->n, c->dD, c->np, c->m, c->n));
+  PMFCHK(download_padded(c, Vh.data(), c->n, c->dV, c->np, c->m, c->n));
+  for (size_t q = 0; q < Dh.size(); ++q) S[q] = Dh[q] + Vh[q];
   return PMF_OK;
 }
 

@@ -34,9 +34,12 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
 
 // NMF H step (pymf/nmf.py:122-126): H <- (H * P) / (S H + 1e-9), P = W^T V, S = W^T W.
 // PS: [KP][np + KP] (P | S).  One block per 16 columns of H; in place.
-// lamb > 0: BNMF rule (bnmf.py:79-82) H *= (P + 3 l H^2) / (S H + 2 l H^3 + l H + 1e-9).
+// mode 1: BNMF rule (bnmf.py:79-82) H *= (P + 3 l H^2) / (S H + 2 l H^3 + l H + 1e-9).
+// mode 2: RNMF rule (rnmf.py:100-105) with P = W^T (S - data): H *= (|P| - P) / (2 (W^T W) H),
+//         no epsilon; kvalid / nvalid mask the zero padding (0/0 there).
 __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ldh, int np, int KP,
-                                               const float* __restrict__ PS, int bnmf, float lamb) {
+                                               const float* __restrict__ PS, int bnmf, float lamb,
+                                               int kvalid, int nvalid) {
   extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
   const int tid = threadIdx.x;
   const int c = tid & 15;
@@ -50,7 +53,10 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
     for (int j = 0; j < KP; ++j) den = fmaf(srow[j], hs[j * 16 + c], den);
     const float h = hs[kk * 16 + c];
     const float p = PS[(int64_t)kk * ldp + col];
-    if (bnmf) {
+    if (bnmf == 2) {
+      const float r = h * ((fabsf(p) - p) / (2.0f * den));
+      H[(int64_t)kk * ldh + col] = (kk < kvalid && col < nvalid) ? r : 0.f;
+    } else if (bnmf) {
       const float h1 = p + (3.0f * lamb) * (h * h);
       const float h2 = ((den + (2.0f * lamb) * (h * h * h)) + lamb * h) + PMF_EPS_DEN;
       H[(int64_t)kk * ldh + col] = h * (h1 / h2);

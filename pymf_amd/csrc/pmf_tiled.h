@@ -14,7 +14,7 @@
 #pragma once
 #include "pmf_dev.h"
 
-enum { EPI_STORE = 0, EPI_NMF_W = 1, EPI_BNMF_W = 2 };
+enum { EPI_STORE = 0, EPI_NMF_W = 1, EPI_BNMF_W = 2, EPI_RNMF_W = 3 };
 
 // A [R][64] f32 panel travelling global -> registers -> swizzled LDS, 256 threads.
 template <int R>
@@ -89,7 +89,8 @@ template <int NT, int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, int64_t lda, int kdimA,
                                                  const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ W, const float* __restrict__ G,
-                                                 float* __restrict__ C, float lamb) {
+                                                 float* __restrict__ C, float lamb,
+                                                 int64_t mvalid, int kvalid) {
   constexpr int KP = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sa = smem;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
   tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb);
 
   const int64_t rbase = row0 + 16 * wv + 4 * kq;   // + reg index j
-  if (EPI == EPI_NMF_W || EPI == EPI_BNMF_W) {
+  if (EPI == EPI_NMF_W || EPI == EPI_BNMF_W || EPI == EPI_RNMF_W) {
     f32x4 den[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -116,7 +117,11 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
       for (int j = 0; j < 4; ++j) {
         float* p = W + (rbase + j) * KP + 16 * nt + i;
         const float w = *p;
-        if (EPI == EPI_BNMF_W) {                              // bnmf.py:87-90
+        if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
+          const float x = num[nt][j];
+          const float r = w * ((fabsf(x) - x) / (2.0f * den[nt][j]));
+          *p = ((rbase + j) < mvalid && (16 * nt + i) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
+        } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
           const float w1 = num[nt][j] + (3.0f * lamb) * (w * w);
           const float w2 = ((den[nt][j] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
           *p = w * (w1 / w2);
@@ -283,6 +288,55 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __rest
       if (nt > mt) out[(int64_t)col * ldp + np + row] = v;
     }
   }
+}
+
+// RNMF update_s (rnmf.py:96-98) for 64 rows per block: R = V - W H on MFMA, S = soft(R, lamb);
+// stores D = S - V (the matrix both RNMF contractions actually use, rnmf.py:102,111) and the
+// float64 partial of sum(R^2) -- the Frobenius error comes for free.
+template <int NT>
+__global__ __launch_bounds__(256) void k_rnmf_s(const float* __restrict__ V, int64_t ldv, int np,
+                                                const float* __restrict__ W,
+                                                const float* __restrict__ H, int64_t ldh, float lamb,
+                                                float* __restrict__ D, double* __restrict__ part) {
+  constexpr int KP = 16 * NT;
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 64 + 16 * wv;
+  float af[4 * NT];
+#pragma unroll
+  for (int s = 0; s < 4 * NT; ++s) af[s] = W[(row0 + i) * KP + 4 * s + kq];
+  double tot = 0.0;
+  for (int cp = 0; cp < np; cp += 64) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4 * NT; ++s) {
+      const float* hr = H + (int64_t)(4 * s + kq) * ldh + cp + i;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(af[s], hr[16 * nt], acc[nt]);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t off = (row0 + 4 * kq + j) * ldv + cp + 16 * nt + i;
+        const float v = V[off];
+        const float r = v - acc[nt][j];
+        ss += r * r;
+        float sv = 0.f;                           // soft thresholding, rnmf.py:75-79
+        if (r > lamb) sv = r - lamb;
+        else if (r < -lamb) sv = r + lamb;
+        D[off] = sv - v;
+      }
+    tot += (double)ss;
+  }
+  tot = wave_sum_f64(tot);
+  if (lane == 0) wsum[wv] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // Partial sums of (V - W H)^2 for 64 rows per block; part[block] in float64.

@@ -27,7 +27,7 @@ def load_reference():
     pkg.__path__ = [os.path.join(REF, "pymf")]
     sys.modules["pymf"] = pkg
     mods = {}
-    for name in ("nmf", "snmf", "nmfnnls", "bnmf"):
+    for name in ("nmf", "snmf", "nmfnnls", "bnmf", "rnmf"):
         mods[name] = importlib.import_module("pymf." + name)
     mods["nmfnnls"].map = lambda f, *a: list(builtins.map(f, *a))
     return mods
@@ -140,6 +140,23 @@ def main():
     Vb2 = (np.random.RandomState(5).random_sample((1024, 256)) < 0.2).astype(np.float32)
     add("bnmf_1024x256_k64", BNMF, Vb2, dict(V_seed=np.int64(5), V_shape=np.array([1024, 256], dtype=np.int64)),
         64, 8, 42, True)
+
+    # RNMF ("next" row 3): lazy init is part of the behaviour (rnmf.py:81-94), so the goldens are
+    # generated the way users call it: seed, construct, factorize; W/H/S come out of init_w/init_h
+    RNMF = mods["rnmf"].RNMF
+    for tag, (m_, n_, k_, lamb_, it_) in {"rnmf_60x40_k4": (60, 40, 4, 0.3, 12),
+                                          "rnmf_300x256_k32": (300, 256, 32, 2.0, 10),
+                                          "rnmf_300x256_k8": (300, 256, 8, 1.0, 10)}.items():
+        rs_ = np.random.RandomState(31)
+        Vr = rs_.random_sample((m_, n_))
+        out_idx = rs_.randint(0, m_ * n_, size=max(3, m_ * n_ // 200))
+        Vr.flat[out_idx] += 4.0 * rs_.random_sample(out_idx.shape[0]) + 1.0      # sparse outliers
+        Vr = Vr.astype(np.float32)
+        np.random.seed(7)
+        mdl = RNMF(Vr, num_bases=k_, lamb=lamb_)
+        mdl.factorize(niter=it_)
+        cases[tag] = dict(V=Vr, W=mdl.W, H=mdl.H, S=mdl.S, ferr=np.asarray(mdl.ferr, dtype=np.float64),
+                          k=np.int64(k_), niter=np.int64(it_), seed=np.int64(7), lamb=np.float64(lamb_))
 
     for name, d in cases.items():
         d = {k: v for k, v in d.items() if v is not None}

@@ -42,6 +42,18 @@ def test_oracle_matches_reference_golden(name):
     assert o.W.dtype == g["W"].dtype and o.H.dtype == g["H"].dtype
 
 
+@pytest.mark.parametrize("name", ["rnmf_60x40_k4", "rnmf_300x256_k32", "rnmf_300x256_k8"])
+def test_rnmf_oracle_matches_reference_golden(name):
+    """RNMF goldens come from the reference's own lazy init path (seed -> init_w -> init_h -> S)."""
+    from oracle import RNMFOracle
+    g = load_golden(name)
+    np.random.seed(int(g["seed"]))
+    o = RNMFOracle(g["V"], num_bases=int(g["k"]), lamb=float(g["lamb"]))
+    o.factorize(niter=int(g["niter"]))
+    assert rel_fro(o.W, g["W"]) < 1e-12 and rel_fro(o.H, g["H"]) < 1e-12 and rel_fro(o.S, g["S"]) < 1e-12
+    np.testing.assert_allclose(o.ferr, g["ferr"], rtol=1e-12)
+
+
 def test_known_answers_from_survey():
     """SURVEY.md section 8(c) 'known answers' measured on the reference."""
     g = load_golden("nmf_cfg1_f64")
