@@ -370,3 +370,21 @@ def test_fused_vs_tiled_random_shapes(pm):
             if fb[-1] > 1e-3 * np.linalg.norm(V):
                 np.testing.assert_allclose(fa, np.array(fb), rtol=1e-4, err_msg=str((algo, m, n, k)))
             a.close(); b.close()
+
+
+def test_fifty_iterations_drift(pm):
+    """SURVEY 8(d) tolerance statement: after 50 iterations against the float64-default reference
+    path, ||X - X_ref||_F / ||X_ref||_F <= 2e-5 and |ferr - ferr_ref| / ferr_ref <= 1e-5 (8192 x 256, k = 64)."""
+    from oracle import NMFOracle
+    rs = np.random.RandomState(1234)
+    V = rs.random_sample((8192, 256)).astype(np.float32)
+    np.random.seed(42)
+    W0, H0 = np.random.random((8192, 64)), np.random.random((64, 256))
+    mdl = _run(pm.NMF, V, 64, 50, W0, H0)
+    ref = NMFOracle(V, num_bases=64)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=50)
+    assert len(mdl.ferr) == len(ref.ferr) == 50
+    assert rel_fro(mdl.W, ref.W) < TOL_X
+    assert rel_fro(mdl.H, ref.H) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
