@@ -253,16 +253,35 @@ int need(pmf_ctx* c, bool v, bool w, bool h) {
 }
 
 // ---- NMF (multiplicative update) ---------------------------------------------------------
+template <int NT, bool RNMF>
+int launch_resid_t(pmf_ctx* c, float lamb) {
+  const size_t smem = resid_smem_bytes<NT>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resid<NT, RNMF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_resid<NT, RNMF>), dim3((unsigned)(c->mp / 64)), dim3(256), smem, c->stream, c->dV,
+                     (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int launch_resid(pmf_ctx* c, bool rnmf, float lamb) {
+  switch (c->NT) {
+    case 1: return rnmf ? launch_resid_t<1, true>(c, lamb) : launch_resid_t<1, false>(c, lamb);
+    case 2: return rnmf ? launch_resid_t<2, true>(c, lamb) : launch_resid_t<2, false>(c, lamb);
+    case 4: return rnmf ? launch_resid_t<4, true>(c, lamb) : launch_resid_t<4, false>(c, lamb);
+    case 8: return rnmf ? launch_resid_t<8, true>(c, lamb) : launch_resid_t<8, false>(c, lamb);
+  }
+  return fail(c, PMF_EINVAL, "bad NT");
+}
+
 int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2) in c->rnmf_err2
   const int nb = (int)(c->mp / 64);
   const float lamb = (float)c->lamb_w;
-  switch (c->NT) {
-    case 1: hipLaunchKernelGGL((k_rnmf_s<1>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
-    case 2: hipLaunchKernelGGL((k_rnmf_s<2>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
-    case 4: hipLaunchKernelGGL((k_rnmf_s<4>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
-    case 8: hipLaunchKernelGGL((k_rnmf_s<8>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart); break;
-  }
-  HIPCHK(c, hipGetLastError());
+  PMFCHK(launch_resid(c, true, lamb));
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 4);
   HIPCHK(c, hipGetLastError());
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->dScal + 4, c->dScal + 4, 1, ncclDouble, ncclSum, c->comm, c->stream));
@@ -590,13 +609,7 @@ int do_update_h(pmf_ctx* c) {
 int frobenius_direct(pmf_ctx* c, double* out) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
   const int nb = (int)(c->mp / 64);
-  switch (c->NT) {
-    case 1: hipLaunchKernelGGL((k_resid<1>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
-    case 2: hipLaunchKernelGGL((k_resid<2>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
-    case 4: hipLaunchKernelGGL((k_resid<4>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
-    case 8: hipLaunchKernelGGL((k_resid<8>), dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, c->dPart); break;
-  }
-  HIPCHK(c, hipGetLastError());
+  PMFCHK(launch_resid(c, false, 0.f));
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
   HIPCHK(c, hipGetLastError());
   if (c->comm)

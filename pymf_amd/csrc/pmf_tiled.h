@@ -290,78 +290,64 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __rest
   }
 }
 
-// RNMF update_s (rnmf.py:96-98) for 64 rows per block: R = V - W H on MFMA, S = soft(R, lamb);
-// stores D = S - V (the matrix both RNMF contractions actually use, rnmf.py:102,111) and the
-// float64 partial of sum(R^2) -- the Frobenius error comes for free.
+// Residual pass over 64 rows per block: R = V - W H with W H on MFMA.
+//   RNMF = false: part[block] = sum(R^2) in float64                  (pymf/nmf.py:110)
+//   RNMF = true : additionally S = soft_threshold(R, lamb) and D = S - V is stored
+//                 (rnmf.py:96-98; D is what both RNMF contractions use, rnmf.py:102,111).
+// The W fragments of the wave's 16 rows stay in registers; the H panel [KP][64] is staged in LDS
+// (double buffered, one barrier per panel; rows padded to 80 floats so the 4 k-rows of a
+// fragment read fall on distinct banks); the V values of a panel are requested before its MFMAs.
 template <int NT>
-__global__ __launch_bounds__(256) void k_rnmf_s(const float* __restrict__ V, int64_t ldv, int np,
-                                                const float* __restrict__ W,
-                                                const float* __restrict__ H, int64_t ldh, float lamb,
-                                                float* __restrict__ D, double* __restrict__ part) {
-  constexpr int KP = 16 * NT;
-  __shared__ double wsum[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = lane & 15, kq = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * 64 + 16 * wv;
-  float af[4 * NT];
-#pragma unroll
-  for (int s = 0; s < 4 * NT; ++s) af[s] = W[(row0 + i) * KP + 4 * s + kq];
-  double tot = 0.0;
-  for (int cp = 0; cp < np; cp += 64) {
-    f32x4 acc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4 * NT; ++s) {
-      const float* hr = H + (int64_t)(4 * s + kq) * ldh + cp + i;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(af[s], hr[16 * nt], acc[nt]);
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t off = (row0 + 4 * kq + j) * ldv + cp + 16 * nt + i;
-        const float v = V[off];
-        const float r = v - acc[nt][j];
-        ss += r * r;
-        float sv = 0.f;                           // soft thresholding, rnmf.py:75-79
-        if (r > lamb) sv = r - lamb;
-        else if (r < -lamb) sv = r + lamb;
-        D[off] = sv - v;
-      }
-    tot += (double)ss;
-  }
-  tot = wave_sum_f64(tot);
-  if (lane == 0) wsum[wv] = tot;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
+constexpr size_t resid_smem_bytes() { return (size_t)2 * 16 * NT * 80 * sizeof(float); }
 
-// Partial sums of (V - W H)^2 for 64 rows per block; part[block] in float64.
-template <int NT>
+template <int NT, bool RNMF>
 __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int64_t ldv, int np,
                                                const float* __restrict__ W,
-                                               const float* __restrict__ H, int64_t ldh,
-                                               double* __restrict__ part) {
-  constexpr int KP = 16 * NT;
+                                               const float* __restrict__ H, int64_t ldh, float lamb,
+                                               float* __restrict__ D, double* __restrict__ part) {
+  constexpr int KP = 16 * NT, HP = 80;
+  extern __shared__ __attribute__((aligned(16))) float hsm[];     // 2 x [KP][HP]
   __shared__ double wsum[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * 64 + 16 * wv;
-  // A fragments of this wave's 16 rows of W: step s covers bases 4s + kq.
-  float af[4 * NT];
+  float af[4 * NT];                                   // A[i = row][k = 4s + kq]
 #pragma unroll
   for (int s = 0; s < 4 * NT; ++s) af[s] = W[(row0 + i) * KP + 4 * s + kq];
+  f32x4 hreg[NT];                                     // this thread's share of the next H panel
+  auto hload = [&](int cp) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int id = tid + 256 * q, kk = id >> 4, c4 = id & 15;
+      hreg[q] = *reinterpret_cast<const f32x4*>(H + (int64_t)kk * ldh + cp + 4 * c4);
+    }
+  };
+  auto hstore = [&](float* dst) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int id = tid + 256 * q, kk = id >> 4, c4 = id & 15;
+      *reinterpret_cast<f32x4*>(dst + kk * HP + 4 * c4) = hreg[q];
+    }
+  };
   double tot = 0.0;
-  for (int cp = 0; cp < np; cp += 64) {
+  hload(0);
+  int buf = 0;
+  for (int cp = 0; cp < np; cp += 64, buf ^= 1) {
+    float* hp = hsm + buf * (KP * HP);
+    hstore(hp);
+    __syncthreads();
+    if (cp + 64 < np) hload(cp + 64);
+    float vv[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vv[nt][j] = V[(row0 + 4 * kq + j) * ldv + cp + 16 * nt + i];
     f32x4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4 * NT; ++s) {
-      const float* hr = H + (int64_t)(4 * s + kq) * ldh + cp + i;
+      const float* hr = hp + (4 * s + kq) * HP + i;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(af[s], hr[16 * nt], acc[nt]);
     }
@@ -370,13 +356,20 @@ __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int6
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d = V[(row0 + 4 * kq + j) * ldv + cp + 16 * nt + i] - acc[nt][j];
-        ss += d * d;
+        const float v = vv[nt][j];
+        const float r = v - acc[nt][j];
+        ss += r * r;
+        if (RNMF) {
+          float sv = 0.f;                           // soft thresholding, rnmf.py:75-79
+          if (r > lamb) sv = r - lamb;
+          else if (r < -lamb) sv = r + lamb;
+          D[(row0 + 4 * kq + j) * ldv + cp + 16 * nt + i] = sv - v;
+        }
       }
     tot += (double)ss;
   }
   tot = wave_sum_f64(tot);
   if (lane == 0) wsum[wv] = tot;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
