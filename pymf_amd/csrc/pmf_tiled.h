@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 // Partials of P = W^T V and S = W^T W over one chunk of rows.
 // grid = (nchunks, ceil(np/256)); wave w of a block owns columns [256*by + 64*w, +64).
 // slab[chunk][KP][np + KP]: P in columns [0,np), S in [np, np+KP) (written by by == 0).
+// The MFMA M / N index of a lane is free, so the operands are fetched with full-width vector
+// loads: lane i reads NT consecutive bases (W row = 16*NT floats = one 16-lane row) and 4
+// consecutive columns of V; tile e then holds bases {NT*i + e} resp. columns {4*i + e}, and the
+// permutation is undone in the slab store.  4 + 4 vector loads feed the 4*NT*(4 + ...) MFMAs of a
+// 16-row step (was 16 + 4*NT dword loads).
 template <int NT>
 __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, int64_t ldv, int np,
                                                  const float* __restrict__ W, int64_t mp,
@@ -166,21 +171,26 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
   }
 
   for (int64_t r = r_begin; r < r_end; r += 16) {
-    float af[NT][4], bf[4][4], sf[ST][4];
+    float af[NT][4], bf[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t row = r + 4 * kq + j;   // k index of MFMA step j for this lane group
-      const float* wr = W + row * KP + i;
+      const float* wr = W + row * KP + NT * i;          // bases NT*i .. NT*i + NT-1
+      if (NT >= 4) {
 #pragma unroll
-      for (int mt = 0; mt < NT; ++mt) af[mt][j] = wr[16 * mt];
+        for (int q = 0; q < NT / 4; ++q) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * q);
 #pragma unroll
-      for (int st = 0; st < ST; ++st) {
-        const int nt = wv + 4 * st;
-        sf[st][j] = (sact && nt < NT) ? wr[16 * nt] : 0.f;
+          for (int e = 0; e < 4; ++e) af[4 * q + e][j] = w4[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < NT; ++e) af[e][j] = wr[e];
       }
-      const float* vr = V + row * ldv + c0 + i;
+      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+      if (pact) v4 = *reinterpret_cast<const f32x4*>(V + row * ldv + c0 + 4 * i);   // columns 4i..4i+3
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bf[nt][j] = pact ? vr[16 * nt] : 0.f;
+      for (int e = 0; e < 4; ++e) bf[e][j] = v4[e];
     }
     if (pact) {
 #pragma unroll
@@ -191,31 +201,41 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
           for (int nt = 0; nt < 4; ++nt) P[mt][nt] = mfma16(af[mt][j], bf[nt][j], P[mt][nt]);
     }
     if (sact) {
+      // wave w forms the S tiles (mt, nt = w + 4 st); the B operand is the same register file
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-          for (int st = 0; st < ST; ++st) S[mt][st] = mfma16(af[mt][j], sf[st][j], S[mt][st]);
+          for (int st = 0; st < ST; ++st) {
+            float b = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              if (nt == wv + 4 * st) b = af[nt][j];
+            S[mt][st] = mfma16(af[mt][j], b, S[mt][st]);
+          }
     }
   }
 
+  // tile (mt, nt), lane (c = i, q = kq), register jj  <->  base NT*(4q + jj) + mt,  column 4c + nt
   const int64_t ldp = (int64_t)np + KP;
   float* base = slab + (int64_t)blockIdx.x * KP * ldp;
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      float* rowp = base + (int64_t)(16 * mt + 4 * kq + jj) * ldp;
+      float* rowp = base + (int64_t)(NT * (4 * kq + jj) + mt) * ldp;
       if (pact) {
+        f32x4 o;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) rowp[c0 + 16 * nt + i] = P[mt][nt][jj];
+        for (int nt = 0; nt < 4; ++nt) o[nt] = P[mt][nt][jj];
+        *reinterpret_cast<f32x4*>(rowp + c0 + 4 * i) = o;          // columns 4i .. 4i+3
       }
       if (sact) {
 #pragma unroll
         for (int st = 0; st < ST; ++st) {
           const int nt = wv + 4 * st;
-          if (nt < NT) rowp[np + 16 * nt + i] = S[mt][st][jj];
+          if (nt < NT) rowp[np + NT * i + nt] = S[mt][st][jj];   // column base NT*c + nt
         }
       }
     }
