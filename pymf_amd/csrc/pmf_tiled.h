@@ -357,35 +357,37 @@ __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int6
     hstore(hp);
     __syncthreads();
     if (cp + 64 < np) hload(cp + 64);
-    float vv[4][4];
+    // tile e holds columns {4i + e} (the MFMA N index of a lane is free): V, the H fragments and
+    // the D store are all 16-byte accesses
+    f32x4 vv[4];                                       // vv[j] = V[row 4kq + j][cp + 4i .. +3]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vv[nt][j] = V[(row0 + 4 * kq + j) * ldv + cp + 16 * nt + i];
+    for (int j = 0; j < 4; ++j)
+      vv[j] = *reinterpret_cast<const f32x4*>(V + (row0 + 4 * kq + j) * ldv + cp + 4 * i);
     f32x4 acc[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4 * NT; ++s) {
-      const float* hr = hp + (4 * s + kq) * HP + i;
+      const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + (4 * s + kq) * HP + 4 * i);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(af[s], hr[16 * nt], acc[nt]);
+      for (int e = 0; e < 4; ++e) acc[e] = mfma16(af[s], hq[e], acc[e]);
     }
     float ss = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int j = 0; j < 4; ++j) {
+      f32x4 dq;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float v = vv[nt][j];
-        const float r = v - acc[nt][j];
+      for (int e = 0; e < 4; ++e) {
+        const float v = vv[j][e];
+        const float r = v - acc[e][j];
         ss += r * r;
-        if (RNMF) {
-          float sv = 0.f;                           // soft thresholding, rnmf.py:75-79
-          if (r > lamb) sv = r - lamb;
-          else if (r < -lamb) sv = r + lamb;
-          D[(row0 + 4 * kq + j) * ldv + cp + 16 * nt + i] = sv - v;
-        }
+        float sv = 0.f;                             // soft thresholding, rnmf.py:75-79
+        if (r > lamb) sv = r - lamb;
+        else if (r < -lamb) sv = r + lamb;
+        dq[e] = sv - v;
       }
+      if (RNMF) *reinterpret_cast<f32x4*>(D + (row0 + 4 * kq + j) * ldv + cp + 4 * i) = dq;
+    }
     tot += (double)ss;
   }
   tot = wave_sum_f64(tot);
