@@ -359,8 +359,11 @@ bool nmf_h_gram(pmf_ctx* c, int* rc) {
   return false;
 }
 
-int h_step_from_ps(pmf_ctx* c) {   // dPS holds the rank-local sums
-  PMFCHK(allreduce_ps(c));
+// dPS holds (W^T V | W^T W) of the current W summed over ALL ranks (ps_valid).  It does not depend
+// on H, so repeated H steps with an unchanged W -- factorize(compute_w=False), the reference's
+// documented "coefficients for an existing basis" use (nmf.py:56-65) -- reuse it: after the first
+// iteration such a loop costs one k x n sized kernel per iteration and no pass over V at all.
+int h_step_from_ps(pmf_ctx* c) {
   int hrc = PMF_OK;
   if (nmf_h_gram(c, &hrc)) {
     PMFCHK(hrc);
@@ -393,15 +396,24 @@ int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
   return reduce_slabs(c, c->nchunks);
 }
 
+int ensure_ps(pmf_ctx* c) {  // two-pass path: (re)build the all-rank (P | S) unless it is current
+  if (c->ps_valid) return PMF_OK;
+  PMFCHK(ps_tiled(c));
+  PMFCHK(allreduce_ps(c));
+  c->ps_valid = true;
+  return PMF_OK;
+}
+
 int nmf_update_h(pmf_ctx* c) {
   if (c->algo == PMF_ALGO_RNMF) {                // rnmf.py:100-107: H step on D = S - data, then update_s
     if (!c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
-    PMFCHK(ps_tiled(c));
+    c->ps_valid = false;                         // D changed in the last update_s
+    PMFCHK(ensure_ps(c));
     PMFCHK(h_step_from_ps(c));
     c->ps_valid = false;                         // (P | S) were built from D, not from V
     return rnmf_update_s(c);
   }
-  PMFCHK(ps_tiled(c));
+  PMFCHK(ensure_ps(c));
   return h_step_from_ps(c);
 }
 
@@ -422,6 +434,8 @@ int nmf_fused_iteration(pmf_ctx* c) {
                        c->fused_wgs, c->NT, NTP, c->np, c->dPS);
     HIPCHK(c, hipGetLastError());
   }
+  PMFCHK(allreduce_ps(c));
+  c->ps_valid = true;
   return h_step_from_ps(c);
 }
 
@@ -459,6 +473,8 @@ int snmf_fused_iteration(pmf_ctx* c) {
                        c->fused_wgs, c->NT, NTP, c->np, c->dPS);
     HIPCHK(c, hipGetLastError());
   }
+  PMFCHK(allreduce_ps(c));
+  c->ps_valid = true;
   return h_step_from_ps(c);
 }
 
@@ -533,6 +549,8 @@ int snmf_csr_fused_iteration(pmf_ctx* c) {
     stat_end(c);
     PMFCHK(mrc);
     PMFCHK(reduce_slabs(c, wgs));
+    PMFCHK(allreduce_ps(c));
+    c->ps_valid = true;
     return h_step_from_ps(c);
   }
   switch (c->NT) {
@@ -544,11 +562,13 @@ int snmf_csr_fused_iteration(pmf_ctx* c) {
   }
   stat_end(c);
   PMFCHK(reduce_slabs(c, wgs));
+  PMFCHK(allreduce_ps(c));
+  c->ps_valid = true;
   return h_step_from_ps(c);
 }
 
 int snmf_update_h(pmf_ctx* c) {
-  PMFCHK(ps_tiled(c));
+  PMFCHK(ensure_ps(c));
   return h_step_from_ps(c);
 }
 
@@ -567,8 +587,7 @@ int als_update_w(pmf_ctx* c) {
 
 int als_update_h(pmf_ctx* c) {
   // HA = W^T W (nmfals.py:78), -FA = W^T V (nmfals.py:73), one QP per column (nmfals.py:74-75)
-  PMFCHK(ps_tiled(c));
-  PMFCHK(allreduce_ps(c));
+  PMFCHK(ensure_ps(c));
   const int64_t ldp = (int64_t)c->np + c->KP;
   hipLaunchKernelGGL(k_hessian_from_ps, dim3((unsigned)((c->KP * c->KP + 255) / 256)), dim3(256), 0,
                      c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
@@ -865,7 +884,7 @@ int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
 int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dH, c->np, c->k, c->n, 0, seed));
-  c->have_h = true; c->g_valid = false; c->ps_valid = false;
+  c->have_h = true; c->g_valid = false; c->trace_ready = false;
   return PMF_OK;
 }
 
@@ -885,7 +904,7 @@ int pmf_set_h_f32(pmf_ctx* c, const float* H) {
   if (!c || !H) return fail(c, PMF_EINVAL, "pmf_set_h_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false; c->ps_valid = false;
+  c->have_h = true; c->g_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
   return PMF_OK;
 }
 int pmf_get_h_f32(pmf_ctx* c, float* H) {

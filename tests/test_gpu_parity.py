@@ -238,7 +238,7 @@ def test_full_size_properties_cfg4(pm):
     for _ in range(6):                                            # hooks: tiled kernels + direct residual
         b.update_w()
         b.update_h()
-        b.set_h(b.get_h())                                        # invalidates (W^T V | W^T W): forces the direct pass
+        b.set_w(b.get_w())                                        # "new" W invalidates (W^T V | W^T W): forces the direct pass
         fb.append(b.frobenius())
     np.testing.assert_allclose(ferr, np.array(fb), rtol=2e-6)     # (2) + (3)
     Ha, Hb = a.get_h(), b.get_h()                                 # H depends on every row of W
@@ -362,7 +362,7 @@ def test_fused_vs_tiled_random_shapes(pm):
             fb = []
             for _ in range(2):
                 b.update_w(); b.update_h()
-                b.set_h(b.get_h())
+                b.set_w(b.get_w())             # stale (P | S): direct residual pass
                 fb.append(b.frobenius())
             tol = 2e-5 if algo == _lib.ALGO_NMF else 5e-4     # SNMF: inv(H H^T) amplifies for k ~ n
             assert rel_fro(a.get_h(), b.get_h()) < tol, (algo, m, n, k)
@@ -388,3 +388,28 @@ def test_fifty_iterations_drift(pm):
     assert rel_fro(mdl.W, ref.W) < TOL_X
     assert rel_fro(mdl.H, ref.H) < TOL_X
     np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+
+
+def test_fixed_basis_loop_reuses_partials(pm):
+    """factorize(compute_w=False): the reference's 'coefficients for an existing basis' use
+    (nmf.py:56-65).  W never changes, so (W^T V | W^T W) is formed once and every further iteration
+    is a k x n sized kernel -- results must equal the oracle, which recomputes everything."""
+    from oracle import NMFOracle, SNMFOracle
+    rs = np.random.RandomState(6)
+    V = rs.random_sample((5000, 200)).astype(np.float32)
+    W0, H0 = rs.random_sample((5000, 40)), rs.random_sample((40, 200))
+    for cls, ocls in ((pm.NMF, NMFOracle), (pm.SNMF, SNMFOracle)):
+        mdl = cls(V, num_bases=40)
+        mdl.W, mdl.H = W0.copy(), H0.copy()
+        mdl.factorize(niter=25, compute_w=False)
+        ref = ocls(V, num_bases=40)
+        ref.W, ref.H = W0.copy(), H0.copy()
+        ref.factorize(niter=25, compute_w=False)
+        assert rel_fro(mdl.H, ref.H) < TOL_X
+        np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+        np.testing.assert_array_equal(mdl.W, W0)                 # W untouched
+        mdl.W = W0 * 1.5                                         # a new basis must invalidate the cache
+        ref.W = W0 * 1.5
+        mdl.factorize(niter=3, compute_w=False)
+        ref.factorize(niter=3, compute_w=False)
+        assert rel_fro(mdl.H, ref.H) < TOL_X

@@ -11,7 +11,7 @@ for name, fn in (("update_w (k_rowgemm<4,NMF_W>)", ctx.update_w), ("update_h (k_
     t = time.time()
     for _ in range(20): fn()
     print("%-45s %.3f ms" % (name, (time.time() - t) / 20 * 1e3))
-ctx.set_h(ctx.get_h())     # stale (P | S): forces the direct residual pass
+ctx.set_w(ctx.get_w())     # "new" W: stale (P | S), forces the direct residual pass
 t = time.time()
 for _ in range(10):
     ctx.set_h(ctx.get_h()); ctx.frobenius()
