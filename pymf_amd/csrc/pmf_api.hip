@@ -63,6 +63,8 @@ struct pmf_ctx {
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
   bool ps_valid = false;        // dPS = (W^T V | W^T W) of the CURRENT W, summed over all ranks
+  bool num_valid = false;       // dW1 holds Num = V H^T of the current V, H (fixed-H loops, NMF)
+  bool fixed_h_loop = false;    // pmf_factorize running compute_w without compute_h for > 1 iteration
   bool want_trace = false;      // pmf_factorize with PMF_COMPUTE_ERR: let the H-step kernel emit the trace terms
   bool trace_ready = false;     // dScal[2..3] already hold <P,H>, <S,HH^T> for the current W, H
   bool vnorm_valid = false;
@@ -298,6 +300,16 @@ int nmf_update_w(pmf_ctx* c) {
   }
   if (c->algo == PMF_ALGO_BNMF)
     return rowgemm<EPI_BNMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
+  if (c->fixed_h_loop) {
+    // H is not updated in this loop, so Num = V H^T is the same every iteration: the first one
+    // stores it, the others read it back and never touch V (W*G and the epilogue are all that is left)
+    if (!c->dW1) PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
+    if (c->num_valid)
+      return rowgemm<EPI_NMF_W_CACHED>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, c->dW1);
+    PMFCHK(rowgemm<EPI_NMF_W_SAVE>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, c->dW1));
+    c->num_valid = true;
+    return PMF_OK;
+  }
   return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
 }
 
@@ -368,6 +380,7 @@ int h_step_from_ps(pmf_ctx* c) {
   if (nmf_h_gram(c, &hrc)) {
     PMFCHK(hrc);
     c->g_valid = true;     // G (pad rows/cols are zero because the padded H rows are zero)
+    c->num_valid = false;  // H changed
     c->ps_valid = true;
     c->trace_ready = c->want_trace;
     if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
@@ -383,7 +396,7 @@ int h_step_from_ps(pmf_ctx* c) {
                        c->algo == PMF_ALGO_BNMF ? 1 : c->algo == PMF_ALGO_RNMF ? 2 : 0, (float)c->lamb_h,
                        c->k, (int)c->n);
   HIPCHK(c, hipGetLastError());
-  c->g_valid = false;
+  c->g_valid = false; c->num_valid = false;
   c->ps_valid = true;    // dPS belongs to the current W (update_h never touches W)
   c->trace_ready = false;
   if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
@@ -596,7 +609,7 @@ int als_update_h(pmf_ctx* c) {
   int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
   HIPCHK(c, hipGetLastError());
-  c->g_valid = false;
+  c->g_valid = false; c->num_valid = false;
   c->ps_valid = true;
   c->trace_ready = false;
   return PMF_OK;
@@ -832,7 +845,7 @@ int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
-  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false;
+  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
   return PMF_OK;
 }
 
@@ -855,7 +868,7 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
     HIPCHK(c, hipMemcpyAsync(c->dVals, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->ps_valid = false;
+  c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
   return PMF_OK;
 }
 
@@ -872,7 +885,7 @@ static int fill(pmf_ctx* c, float* X, int64_t ld, int64_t rows, int64_t cols, in
 int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
-  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false;
+  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
   return PMF_OK;
 }
 int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
@@ -884,7 +897,7 @@ int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
 int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dH, c->np, c->k, c->n, 0, seed));
-  c->have_h = true; c->g_valid = false; c->trace_ready = false;
+  c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;
   return PMF_OK;
 }
 
@@ -904,7 +917,7 @@ int pmf_set_h_f32(pmf_ctx* c, const float* H) {
   if (!c || !H) return fail(c, PMF_EINVAL, "pmf_set_h_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
+  c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
   return PMF_OK;
 }
 int pmf_get_h_f32(pmf_ctx* c, float* H) {
@@ -939,6 +952,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   if (iters_done) *iters_done = 0;
   if (converged_at) *converged_at = -1;
   c->want_trace = ce;
+  c->fixed_h_loop = cw && !ch && niter > 1 && c->algo == PMF_ALGO_NMF;
   const bool fused = cw && ch && c->fused_wgs > 0 && !c->v_csr &&
                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -970,6 +984,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
     }
   }
   c->want_trace = false;
+  c->fixed_h_loop = false;
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;

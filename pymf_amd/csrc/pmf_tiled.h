@@ -14,7 +14,9 @@
 #pragma once
 #include "pmf_dev.h"
 
-enum { EPI_STORE = 0, EPI_NMF_W = 1, EPI_BNMF_W = 2, EPI_RNMF_W = 3 };
+enum { EPI_STORE = 0, EPI_NMF_W = 1, EPI_BNMF_W = 2, EPI_RNMF_W = 3,
+       EPI_NMF_W_SAVE = 4,     // EPI_NMF_W + store Num = V H^T to C (first iteration of a fixed-H loop)
+       EPI_NMF_W_CACHED = 5 }; // Num read back from C: no pass over V (H, hence V H^T, unchanged)
 
 // A [R][64] f32 panel travelling global -> registers -> swizzled LDS, 256 threads.
 template <int R>
@@ -102,14 +104,27 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
   f32x4 num[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) num[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb);
-
   const int64_t rbase = row0 + 16 * wv + 4 * kq;   // + reg index j
-  if (EPI == EPI_NMF_W || EPI == EPI_BNMF_W || EPI == EPI_RNMF_W) {
+  if (EPI == EPI_NMF_W_CACHED) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) num[nt][j] = C[(rbase + j) * KP + 16 * nt + i];
+  } else {
+    tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb);
+  }
+  if (EPI == EPI_NMF_W_SAVE) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+  }
+
+  if (EPI != EPI_STORE) {
     f32x4 den[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    if (EPI != EPI_NMF_W_CACHED) __syncthreads();
     tile_gemm_nt<NT>(den, W + row0 * KP, KP, G, KP, KP, sa, sb);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)

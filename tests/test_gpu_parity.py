@@ -413,3 +413,29 @@ def test_fixed_basis_loop_reuses_partials(pm):
         mdl.factorize(niter=3, compute_w=False)
         ref.factorize(niter=3, compute_w=False)
         assert rel_fro(mdl.H, ref.H) < TOL_X
+
+
+def test_fixed_coefficients_loop_reuses_numerator(pm):
+    """factorize(compute_h=False) (tests/test_pymf.py:92): H never changes, so V H^T is formed in the
+    first iteration and read back afterwards -- results must equal the oracle."""
+    from oracle import NMFOracle
+    rs = np.random.RandomState(9)
+    V = rs.random_sample((3000, 300)).astype(np.float32)
+    W0, H0 = rs.random_sample((3000, 24)), rs.random_sample((24, 300))
+    mdl = pm.NMF(V, num_bases=24)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=12, compute_h=False)
+    ref = NMFOracle(V, num_bases=24)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=12, compute_h=False)
+    assert rel_fro(mdl.W, ref.W) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+    np.testing.assert_array_equal(mdl.H, H0)
+    mdl.H = H0 * 0.7                                         # new coefficients invalidate the cache
+    ref.H = H0 * 0.7
+    mdl.factorize(niter=4, compute_h=False)
+    ref.factorize(niter=4, compute_h=False)
+    assert rel_fro(mdl.W, ref.W) < TOL_X
+    mdl.factorize(niter=3)                                   # and the full loop still works afterwards
+    ref.factorize(niter=3)
+    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
