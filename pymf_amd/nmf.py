@@ -31,11 +31,12 @@ def _is_sparse(x):
 
 
 def _fingerprint(a):
-    """Cheap change detector for a host array (identity + strided sample)."""
-    flat = a.reshape(-1)
-    step = max(1, flat.shape[0] // 4096)
-    s = flat[::step]
-    return (id(a), a.shape, a.dtype.str, float(np.sum(s, dtype=np.float64)),
+    """Change detector for a host array: identity, layout and the float64 sum of ALL elements (one
+    pass at memory speed, cheaper than the float32 conversion + upload it saves).  A single-element
+    poke between two factorize() calls changes the sum, so the device copy is refreshed -- the
+    reference always computes from the current host arrays."""
+    flat = np.asarray(a).reshape(-1)
+    return (id(a), a.shape, a.dtype.str, float(np.sum(flat, dtype=np.float64)),
             float(flat[-1]) if flat.shape[0] else 0.0)
 
 

@@ -439,3 +439,20 @@ def test_fixed_coefficients_loop_reuses_numerator(pm):
     mdl.factorize(niter=3)                                   # and the full loop still works afterwards
     ref.factorize(niter=3)
     assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+
+
+def test_single_element_edit_is_noticed(pm):
+    from oracle import NMFOracle
+    rs = np.random.RandomState(13)
+    V = rs.random_sample((20000, 64)).astype(np.float32)
+    mdl = pm.NMF(V, num_bases=8)
+    np.random.seed(3)
+    mdl.factorize(niter=2)
+    ref = NMFOracle(V, num_bases=8)
+    ref.W, ref.H = mdl.W.copy(), mdl.H.copy()
+    mdl.W[12345, 3] = 0.0                                    # one poke in a 160 000-element array
+    ref.W[12345, 3] = 0.0
+    mdl.factorize(niter=2)
+    ref.factorize(niter=2)
+    assert mdl.W[12345, 3] == 0.0                            # multiplicative updates keep a zero at zero
+    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
