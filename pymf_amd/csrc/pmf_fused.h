@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   // Fragment double buffers: step s+1's LDS reads are issued before step s's MFMAs.
   f32x4 fa[2];
   f32x4 fb[2][NT];
-  float bf[2][4];
+  f32x4 bf[2];
   f32x4 wp[NT];          // previous block's new W rows: its S MFMAs run under this block's epilogue
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -321,11 +321,12 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 
     PMF_STAMP(ts4);
     // ---------------- phase B: P += W_b^T V_b ----------------
+    // The MFMA column index of a lane is free: P tile (mt, 4p + e) holds columns {64p + 4i + e},
+    // so ONE 16-byte read of chunk i of row 4kq + j feeds the four column tiles of a panel step
+    // (k_reduce_slabs_tiles undoes the permutation when it scatters into the row-major buffer).
     auto load_bf = [&](int s, int buf) {
       const int p = s >> 2, row = 4 * kq + (s & 3);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        bf[buf][nt] = (sV + p * 1024)[swz_off(row, 4 * nt + (i >> 2)) + (i & 3)];
+      bf[buf] = lds_read4(sV + p * 1024, row, i);
     };
     load_bf(0, 0);
 #pragma unroll
@@ -342,11 +343,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         if (p >= 1 && more) issue_v(blk + 1, p - 1, j);
       }
       if (s + 1 < NSN) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, NT >= 2 ? 2 : 1, 0);    // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // DS read
-        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NT >= 2 ? 2 : 1, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // the step's one DS read
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!SPREAD && j == 3) {

@@ -312,8 +312,9 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __rest
     const int i = lane & 15, kq = lane >> 4, r = wv;
     const int64_t ldp = (int64_t)np + KP;
     if (tile < NT * NTP) {
+      // P tile (mt, nt = 4p + e) of the fused kernel holds columns {64p + 4c + e} (lane c)
       const int mt = tile / NTP, nt = tile % NTP;
-      out[(int64_t)(16 * mt + 4 * kq + r) * ldp + 16 * nt + i] = v;
+      out[(int64_t)(16 * mt + 4 * kq + r) * ldp + 64 * (nt >> 2) + 4 * i + (nt & 3)] = v;
     } else {
       int sidx = tile - NT * NTP, mt = 0;
       while (sidx >= NT - mt) { sidx -= NT - mt; ++mt; }
