@@ -58,6 +58,17 @@ constexpr size_t fused_smem_bytes() {
   return (size_t)64 * (NPANEL * 16 * NT + 16 * NT + 4 * 16 * NPANEL + 4 * 16) * sizeof(float);
 }
 
+// Swizzle of the 16-row V tile.  It is read two ways: phase A takes 16 rows x one chunk per
+// k-group (swz_off's pattern), phase B takes ONE row per k-group x all 16 chunks.  A
+// ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- two
+// k-groups per LDS pass -- so rows r and r+4 must not put chunks {0-3,12-15} and {4-11} on the
+// same slots: flipping bit 3 of the XOR key on rows with bit 2 set keeps both reads
+// conflict-free (phase A only needs the key to be a bijection that preserves r ^ r' == 1).
+__device__ __forceinline__ int vtile_xor(int row) { return (row ^ ((row & 4) << 1)) & 15; }
+__device__ __forceinline__ f32x4 vtile_read4(const float* base, int row, int chunk) {
+  return *reinterpret_cast<const f32x4*>(base + row * 64 + ((chunk ^ vtile_xor(row)) << 2));
+}
+
 // blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
 enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2 };
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   for (int q = 0; q < 4; ++q) {
     const int row = 4 * q + (lane >> 4);
     const int c = (lane & 15) ^ row;
-    voff[q] = (unsigned)(row * NP * 4 + 16 * c);
+    voff[q] = (unsigned)(row * NP * 4 + 16 * ((lane & 15) ^ vtile_xor(row)));
     woff[q] = (unsigned)(row * KP * 4 + 16 * (4 * c < KP ? c : 0));   // beyond k: valid, never read
   }
   const char* Vb = reinterpret_cast<const char*>(V);
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     auto load_step = [&](int s, int buf) {
       if (s < NSN) {
         const int p = s >> 2, chunk = 4 * (s & 3) + kq;
-        fa[buf] = lds_read4(sV + p * 1024, i, chunk);
+        fa[buf] = vtile_read4(sV + p * 1024, i, chunk);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sH + p * (KP * 64), 16 * nt + i, chunk);
       } else {
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     // (k_reduce_slabs_tiles undoes the permutation when it scatters into the row-major buffer).
     auto load_bf = [&](int s, int buf) {
       const int p = s >> 2, row = 4 * kq + (s & 3);
-      bf[buf] = lds_read4(sV + p * 1024, row, i);
+      bf[buf] = vtile_read4(sV + p * 1024, row, i);
     };
     load_bf(0, 0);
 #pragma unroll
