@@ -119,6 +119,15 @@ int pmf_get_lambda(pmf_ctx* ctx, double* lamb_w, double* lamb_h);
 int pmf_rnmf_update_s(pmf_ctx* ctx);
 int pmf_rnmf_get_s_f32(pmf_ctx* ctx, float* S);
 
+/* NNDSVD initialisation (pymf/nndsvd.py:79-108 = NNDSVD.update_w, with the SVD of pymf/svd.py:125-148):
+ * fills the context's W and H from the dense V already set.  Needs n <= 1024 (the Gram matrix
+ * data^T data is n x n; a wide matrix is handled by the caller on the transposed problem, as the
+ * reference's SVD switches between its left and right forms, svd.py:237-246) and num_bases <= n.
+ * rank_found (may be NULL) receives how many of the leading num_bases eigenvalues exceed the
+ * reference's 1e-8 cut (svd.py:130-131); fewer than num_bases is PMF_EINVAL (the reference raises
+ * IndexError).  Row-sharded contexts sum the Gram matrix and the split norms over all ranks. */
+int pmf_nndsvd_init(pmf_ctx* ctx, int32_t* rank_found);
+
 /* Device time (ms, HIP events on the library's stream) of the last pmf_factorize loop. */
 int pmf_last_loop_ms(pmf_ctx* ctx, double* ms);
 

@@ -19,4 +19,5 @@ from .nmf_oracle import NMFOracle, nmf_update_w, nmf_update_h, frobenius_norm  #
 from .snmf_oracle import SNMFOracle, snmf_update_w, snmf_update_h  # noqa: F401
 from .bnmf_oracle import BNMFOracle  # noqa: F401
 from .rnmf_oracle import RNMFOracle, soft_thresholding  # noqa: F401
+from .nndsvd_oracle import NNDSVDOracle, nndsvd_closed_form, dense_svd  # noqa: F401
 from .nmfals_oracle import NMFALSOracle, nnqp_solve, als_update_w, als_update_h  # noqa: F401

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("pmf_get_lambda", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     ("pmf_rnmf_update_s", _c.c_int, [_ctx]),
     ("pmf_rnmf_get_s_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_nndsvd_init", _c.c_int, [_ctx, _c.POINTER(_c.c_int32)]),
     ("pmf_last_loop_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_profile_enable", _c.c_int, [_ctx, _c.c_int32]),
     ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
@@ -221,6 +222,12 @@ class Context(object):
         S = np.empty((self.m, self.n), dtype=np.float32)
         self._chk(self._lib.pmf_rnmf_get_s_f32(self._h, S.ctypes.data))
         return S
+
+    def nndsvd_init(self):
+        """W, H <- NNDSVD of the resident V (pymf/nndsvd.py:79-106); returns the rank found."""
+        found = ctypes.c_int32(0)
+        self._chk(self._lib.pmf_nndsvd_init(self._h, ctypes.byref(found)))
+        return int(found.value)
 
     def last_loop_ms(self):
         ms = ctypes.c_double(0.0)

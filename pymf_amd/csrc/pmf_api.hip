@@ -27,6 +27,7 @@
 #include "pmf_fused.h"
 #include "pmf_nnls.h"
 #include "pmf_csr.h"
+#include "pmf_nndsvd.h"
 
 namespace {
 
@@ -172,10 +173,10 @@ int colgemm(pmf_ctx* c, bool with_v = true) {
   dim3 grid((unsigned)c->nchunks, with_v ? (unsigned)((c->np + 255) / 256) : 1u);
   const float* Vp = with_v ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : nullptr;
   switch (c->NT) {
-    case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 8: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
+    case 8: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
     default: return fail(c, PMF_EINVAL, "bad NT");
   }
   HIPCHK(c, hipGetLastError());
@@ -251,6 +252,108 @@ int need(pmf_ctx* c, bool v, bool w, bool h) {
   if (w && !c->have_w) return fail(c, PMF_EINVAL, "W has not been set (pmf_set_w_f32)");
   if (h && !c->have_h) return fail(c, PMF_EINVAL, "H has not been set (pmf_set_h_f32)");
   HIPCHK(c, hipSetDevice(c->device));
+  return PMF_OK;
+}
+
+// ---- NNDSVD initialisation (pymf/nndsvd.py:79-108; kernels and the closed form: pmf_nndsvd.h) ----
+struct DevTemps {                 // scratch of one pmf_nndsvd_init call
+  std::vector<void*> p;
+  ~DevTemps() { for (void* q : p) (void)hipFree(q); }
+};
+
+template <typename T>
+int talloc(pmf_ctx* c, DevTemps& t, T** out, size_t count) {
+  PMFCHK(dalloc(c, out, count));
+  t.p.push_back(*out);
+  return PMF_OK;
+}
+
+int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
+  if (c->v_csr) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: dense V only");
+  if (c->n > 1024) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= 1024 (the Gram matrix is n x n; pass the transposed problem for wide data)");
+  if (c->k > c->n) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases exceeds the number of columns");
+  const int n = (int)c->n, np = c->np, KP = c->KP, ld = np;
+  const int nj = n + (n & 1);
+  DevTemps tmp;
+  double *Ad = nullptr, *Ad2 = nullptr, *evals = nullptr, *QT = nullptr, *sv = nullptr, *part = nullptr, *norms = nullptr;
+  float *slab = nullptr, *B = nullptr, *wscale = nullptr;
+  int *order = nullptr, *info = nullptr, *wmode = nullptr;
+  const int64_t blocks16 = c->mp / 16;
+  int gchunks = (int)std::min<int64_t>(512, blocks16);
+  const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;
+  gchunks = (int)((c->mp + rpc - 1) / rpc);
+  PMFCHK(talloc(c, tmp, &Ad, (size_t)np * np));
+  PMFCHK(talloc(c, tmp, &QT, (size_t)np * np));
+  PMFCHK(talloc(c, tmp, &Ad2, (size_t)np * np));
+  PMFCHK(talloc(c, tmp, &evals, (size_t)np));
+  PMFCHK(talloc(c, tmp, &slab, (size_t)gchunks * 128 * (np + 128)));
+  PMFCHK(talloc(c, tmp, &B, (size_t)KP * np));
+  PMFCHK(talloc(c, tmp, &sv, (size_t)KP));
+  PMFCHK(talloc(c, tmp, &order, (size_t)KP));
+  PMFCHK(talloc(c, tmp, &info, 2));
+  PMFCHK(talloc(c, tmp, &wscale, (size_t)KP));
+  PMFCHK(talloc(c, tmp, &wmode, (size_t)KP));
+  const int nblk = (int)std::min<int64_t>(512, (c->m + 255) / 256);
+  const int64_t rows_per_blk = (c->m + nblk - 1) / nblk;
+  PMFCHK(talloc(c, tmp, &part, (size_t)nblk * 2 * KP));
+  PMFCHK(talloc(c, tmp, &norms, (size_t)2 * KP));
+
+  // 1. A = V^T V, 128 (or 64) Gram rows per pass: the column block of V is the "W" operand
+  for (int c0 = 0; c0 < np;) {
+    const int wdt = (np - c0 >= 128) ? 128 : 64;
+    dim3 grid((unsigned)gchunks, (unsigned)((np + 255) / 256));
+    if (wdt == 128)
+      hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
+                         (int64_t)np, c->mp, rpc, slab);
+    else
+      hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
+                         (int64_t)np, c->mp, rpc, slab);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((wdt * np + 255) / 256)), dim3(256), 0, c->stream, slab,
+                       gchunks, wdt, np, c0, Ad, ld);
+    HIPCHK(c, hipGetLastError());
+    c0 += wdt;
+  }
+  if (c->comm) NCCLCHK(c, ncclAllReduce(Ad, Ad, (size_t)np * np, ncclDouble, ncclSum, c->comm, c->stream));
+  // 2./3. eigen-decomposition, top-k selection
+  {
+    const int64_t items = (int64_t)(nj / 2) * (nj / 2) + (int64_t)(nj / 2) * nj;
+    const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, items / 4096));
+    double *a_ = Ad, *b_ = Ad2, *q_ = QT, *e_ = evals;
+    int ld_ = ld, nj_ = nj, sweeps_ = 40;
+    int* done_ = info + 1;
+    void* args[] = {&a_, &b_, &q_, &ld_, &nj_, &sweeps_, &e_, &done_};
+    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_jacobi_eigh), dim3(wgs), dim3(1024), args, 0,
+                                         c->stream));
+  }
+  hipLaunchKernelGGL(k_nndsvd_select, dim3(1), dim3(1024), 0, c->stream, evals, QT, ld, nj, n, c->k, KP, np, B, sv,
+                     order, info);
+  HIPCHK(c, hipGetLastError());
+  int hinfo[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (rank_found) *rank_found = hinfo[0];
+  if (hinfo[0] < c->k)
+    return fail(c, PMF_EINVAL, "pmf_nndsvd_init: only " + std::to_string(hinfo[0]) + " eigenvalues of data^T data exceed 1e-8 "
+                "(svd.py:130-131), fewer than num_bases (the reference raises IndexError at nndsvd.py:94)");
+  // 4. U = V (v_i / s_i)  -> dW
+  PMFCHK(rowgemm<EPI_STORE>(c, c->dV, np, np, B, np, nullptr, nullptr, c->dW));
+  // 5. split norms over all ranks' rows, closed form
+  hipLaunchKernelGGL(k_split_norms, dim3((unsigned)nblk), dim3(256), 0, c->stream, c->dW, c->m, KP, rows_per_blk, part);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(256), 0, c->stream, part, nblk, KP, norms);
+  HIPCHK(c, hipGetLastError());
+  if (c->comm) NCCLCHK(c, ncclAllReduce(norms, norms, (size_t)2 * KP, ncclDouble, ncclSum, c->comm, c->stream));
+  hipLaunchKernelGGL(k_nndsvd_finalize, dim3(1), dim3(1024), 0, c->stream, QT, ld, order, sv, norms, n, c->k, KP, np,
+                     c->dH, wscale, wmode);
+  HIPCHK(c, hipGetLastError());
+  const int64_t total = c->mp * KP;
+  hipLaunchKernelGGL(k_nndsvd_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->dW, total, KP,
+                     c->m, wscale, wmode);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_w = c->have_h = true;
+  c->g_valid = c->ps_valid = c->num_valid = c->trace_ready = false;
   return PMF_OK;
 }
 
@@ -1026,6 +1129,12 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
   PMFCHK(download_padded(c, Vh.data(), c->n, c->dV, c->np, c->m, c->n));
   for (size_t q = 0; q < Dh.size(); ++q) S[q] = Dh[q] + Vh[q];
   return PMF_OK;
+}
+
+int pmf_nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
+  PMFCHK(need(c, true, false, false));
+  if (c->algo == PMF_ALGO_RNMF) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: not for RNMF contexts");
+  return nndsvd_init(c, rank_found);
 }
 
 int pmf_last_loop_ms(pmf_ctx* c, double* ms) {

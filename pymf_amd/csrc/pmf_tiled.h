@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 // 16-row step (was 16 + 4*NT dword loads).
 template <int NT>
 __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, int64_t ldv, int np,
-                                                 const float* __restrict__ W, int64_t mp,
+                                                 const float* __restrict__ W, int64_t ldw, int64_t mp,
                                                  int rows_per_chunk, float* __restrict__ slab) {
   constexpr int KP = 16 * NT;
   constexpr int ST = (NT + 3) / 4;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t row = r + 4 * kq + j;   // k index of MFMA step j for this lane group
-      const float* wr = W + row * KP + NT * i;          // bases NT*i .. NT*i + NT-1
+      const float* wr = W + row * ldw + NT * i;         // bases NT*i .. NT*i + NT-1
       if (NT >= 4) {
 #pragma unroll
         for (int q = 0; q < NT / 4; ++q) {

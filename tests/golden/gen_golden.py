@@ -27,7 +27,7 @@ def load_reference():
     pkg.__path__ = [os.path.join(REF, "pymf")]
     sys.modules["pymf"] = pkg
     mods = {}
-    for name in ("nmf", "snmf", "nmfnnls", "bnmf", "rnmf"):
+    for name in ("nmf", "snmf", "nmfnnls", "bnmf", "rnmf", "nndsvd"):
         mods[name] = importlib.import_module("pymf." + name)
     mods["nmfnnls"].map = lambda f, *a: list(builtins.map(f, *a))
     return mods
@@ -158,7 +158,37 @@ def main():
         cases[tag] = dict(V=Vr, W=mdl.W, H=mdl.H, S=mdl.S, ferr=np.asarray(mdl.ferr, dtype=np.float64),
                           k=np.int64(k_), niter=np.int64(it_), seed=np.int64(7), lamb=np.float64(lamb_))
 
+    # NNDSVD ("next" row 4): deterministic (no RNG); tall, wide, ragged, the docstring example
+    # (nndsvd.py:50-53), and the documented use -- NMF started from the NNDSVD factors (:59-64)
+    NNDSVD = mods["nndsvd"].NNDSVD
+    nd_inputs = {
+        "nndsvd_300x40_k6": (np.random.RandomState(3).random_sample((300, 40)).astype(np.float32), 6),
+        "nndsvd_40x300_k6": (np.random.RandomState(3).random_sample((40, 300)).astype(np.float32), 6),
+        "nndsvd_cfg1_k4": (V1, 4),
+        "nndsvd_37x29_k5": (V3, 5),
+        "nndsvd_doc_k2": (np.array([[1.0, 0.0, 2.0], [0.0, 1.0, 1.0]]), 2),
+        "nndsvd_1024x256_k64": (np.random.RandomState(1234).random_sample((1024, 256)).astype(np.float32), 64),
+    }
+    for tag, (Vn, k_) in nd_inputs.items():
+        mdl = NNDSVD(Vn, num_bases=k_)
+        mdl.factorize()
+        d = dict(W=mdl.W, H=mdl.H, ferr=np.asarray(mdl.ferr, dtype=np.float64), k=np.int64(k_))
+        if tag == "nndsvd_1024x256_k64":
+            d.update(V_seed=np.int64(1234), V_shape=np.array([1024, 256], dtype=np.int64))
+        else:
+            d["V"] = Vn
+        if tag == "nndsvd_300x40_k6":
+            nmf_mdl = NMF(Vn, num_bases=k_)
+            nmf_mdl.W = mdl.W.copy()
+            nmf_mdl.H = mdl.H.copy()
+            nmf_mdl.factorize(niter=10)
+            d.update(W_nmf10=nmf_mdl.W, H_nmf10=nmf_mdl.H, ferr_nmf10=np.asarray(nmf_mdl.ferr))
+        cases[tag] = d
+
+    only = sys.argv[1:]          # e.g. `gen_golden.py nndsvd` rewrites only the nndsvd_* fixtures
     for name, d in cases.items():
+        if only and not any(name.startswith(o) for o in only):
+            continue
         d = {k: v for k, v in d.items() if v is not None}
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
         f = d.get("ferr")

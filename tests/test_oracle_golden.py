@@ -105,3 +105,26 @@ def test_early_exit_truncates_ferr():
 def test_sentinel_without_factors():
     o = NMFOracle(np.ones((3, 4)), num_bases=2)
     assert o.frobenius_norm() == -123456
+
+
+NNDSVD_CASES = ["nndsvd_300x40_k6", "nndsvd_40x300_k6", "nndsvd_cfg1_k4", "nndsvd_37x29_k5", "nndsvd_doc_k2",
+                "nndsvd_1024x256_k64"]
+
+
+@pytest.mark.parametrize("name", NNDSVD_CASES)
+def test_nndsvd_oracle_matches_reference_golden(name):
+    """The restatement (with the reference's per-basis second SVD) and the closed form the device
+    path evaluates both reproduce pymf.NNDSVD: the restatement exactly, the closed form (evaluated in
+    float64) to the noise of the reference's float32 Gram matrix when the data are float32."""
+    from oracle import NNDSVDOracle, nndsvd_closed_form
+    g = load_golden(name)
+    k = int(g["k"])
+    o = NNDSVDOracle(g["V"], num_bases=k)
+    o.factorize(niter=7, compute_w=False)                # arguments are overridden (nndsvd.py:111-114)
+    assert len(o.ferr) == 1
+    assert rel_fro(o.W, g["W"]) < 1e-12 and rel_fro(o.H, g["H"]) < 1e-12
+    np.testing.assert_allclose(o.ferr, g["ferr"], rtol=1e-5)
+    Wc, Hc = nndsvd_closed_form(g["V"], k)
+    tolc = 1e-10 if g["V"].dtype == np.float64 else 2e-4
+    assert rel_fro(Wc, g["W"]) < tolc and rel_fro(Hc, g["H"]) < tolc
+    assert (Wc >= 0).all() and (Hc >= 0).all()
