@@ -119,6 +119,22 @@ int pmf_get_lambda(pmf_ctx* ctx, double* lamb_w, double* lamb_h);
 int pmf_rnmf_update_s(pmf_ctx* ctx);
 int pmf_rnmf_get_s_f32(pmf_ctx* ctx, float* S);
 
+/* Streamed V (the `data[:, :]` idiom of nmf.py:123,129 for data that does not fit
+ * in HBM: an h5py dataset, a memmap, a matrix beyond 288 GB).  NMF contexts only; pmf_set_v_* is not
+ * called.  One pass = one iteration of the reference loop (nmf.py:183-202):
+ *   pmf_stream_begin(ctx, flags, max_tile_rows)   flags as pmf_factorize (PMF_COMPUTE_W/H/ERR)
+ *   pmf_stream_tile(ctx, row0, rows, tile, ld)    row tiles in order; row0 and rows multiples of 64
+ *                                                 (the last tile may be ragged); `tile` is row-major
+ *                                                 host memory that must stay valid until the next but
+ *                                                 one pmf_stream_tile call or pmf_stream_end
+ *   pmf_stream_end(ctx, &ferr, &needs_direct)     H step; ferr = ||V - W H|| by the trace identity
+ * needs_direct = 1 reports that the identity cancels (residual energy below 1e-3 of ||V||^2): a pass with
+ * flags = PMF_STREAM_RESID evaluates sum((V - W H)^2) tile by tile instead (no update). */
+#define PMF_STREAM_RESID 8u
+int pmf_stream_begin(pmf_ctx* ctx, uint32_t flags, int64_t max_tile_rows);
+int pmf_stream_tile(pmf_ctx* ctx, int64_t row0, int64_t rows, const float* tile, int64_t ld);
+int pmf_stream_end(pmf_ctx* ctx, double* ferr, int32_t* needs_direct);
+
 /* NNDSVD initialisation (pymf/nndsvd.py:79-108 = NNDSVD.update_w, with the SVD of pymf/svd.py:125-148):
  * fills the context's W and H from the dense V already set.  Needs n <= 1024 (the Gram matrix
  * data^T data is n x n; a wide matrix is handled by the caller on the transposed problem, as the

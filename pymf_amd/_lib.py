@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("PMF_LIB") or os.path.join(_HERE, "csrc", "libpymf_hip
 PMF_OK = 0
 ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF, ALGO_RNMF = 0, 1, 2, 3, 4
 COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
+STREAM_RESID = 8
 NCCL_ID_BYTES = 128
 
 # every symbol include/pymf_hip.h declares: (name, restype, argtypes)
@@ -52,6 +53,9 @@ SYMBOLS = [
     ("pmf_rnmf_update_s", _c.c_int, [_ctx]),
     ("pmf_rnmf_get_s_f32", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_nndsvd_init", _c.c_int, [_ctx, _c.POINTER(_c.c_int32)]),
+    ("pmf_stream_begin", _c.c_int, [_ctx, _c.c_uint32, _c.c_int64]),
+    ("pmf_stream_tile", _c.c_int, [_ctx, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int64]),
+    ("pmf_stream_end", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int32)]),
     ("pmf_last_loop_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_profile_enable", _c.c_int, [_ctx, _c.c_int32]),
     ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
@@ -222,6 +226,29 @@ class Context(object):
         S = np.empty((self.m, self.n), dtype=np.float32)
         self._chk(self._lib.pmf_rnmf_get_s_f32(self._h, S.ctypes.data))
         return S
+
+    def stream_begin(self, compute_w=True, compute_h=True, compute_err=True, max_tile_rows=65536, resid=False):
+        """Open one streamed pass over V (pmf_stream_begin); resid=True: direct residual pass only."""
+        flags = STREAM_RESID if resid else \
+            ((COMPUTE_W if compute_w else 0) | (COMPUTE_H if compute_h else 0) | (COMPUTE_ERR if compute_err else 0))
+        self._chk(self._lib.pmf_stream_begin(self._h, flags, int(max_tile_rows)))
+        self._tiles_alive = []
+
+    def stream_tile(self, row0, tile):
+        """Hand rows [row0, row0 + len(tile)) to the pass; `tile` is kept alive until two tiles later."""
+        t = np.ascontiguousarray(tile, dtype=np.float32)
+        if t.ndim != 2 or t.shape[1] != self.n:
+            raise ValueError("tile must be rows x %d" % self.n)
+        self._chk(self._lib.pmf_stream_tile(self._h, int(row0), t.shape[0], t.ctypes.data, t.shape[1]))
+        self._tiles_alive = (self._tiles_alive + [t])[-3:]
+
+    def stream_end(self):
+        """Close the pass: returns (ferr or None, needs_direct)."""
+        ferr = ctypes.c_double(-1.0)
+        nd = ctypes.c_int32(0)
+        self._chk(self._lib.pmf_stream_end(self._h, ctypes.byref(ferr), ctypes.byref(nd)))
+        self._tiles_alive = []
+        return float(ferr.value), bool(nd.value)
 
     def nndsvd_init(self):
         """W, H <- NNDSVD of the resident V (pymf/nndsvd.py:79-106); returns the rank found."""

@@ -71,6 +71,17 @@ struct pmf_ctx {
   bool vnorm_valid = false;
   double vnorm2 = 0.0;          // ||V||_F^2 over all ranks
   double lamb_w = 0.0, lamb_h = 0.0;   // BNMF penalty weights (bnmf.py:84-85,118-119)
+  // streamed V (pmf_stream_*): row tiles pass through two device buffers, V is never resident
+  float* dTile[2] = {nullptr, nullptr};
+  int64_t tile_cap = 0;                      // rows per tile buffer (multiple of 64)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  double* dPSacc = nullptr;                  // float64 (P | S) accumulated over the tiles of a pass
+  double* dStAcc = nullptr;                  // [0] sum v^2, [1] sum (v - (W H))^2 over the tiles
+  bool st_active = false, st_vnorm_pending = false;
+  uint32_t st_flags = 0;
+  int64_t st_rows_seen = 0;
+  int st_tiles = 0;
   bool profile = false;
   double last_loop_ms = 0.0;
   KernelStat stat;
@@ -108,6 +119,8 @@ int fail(pmf_ctx* c, int code, const std::string& msg) {
 
 int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+int ensure_dv(pmf_ctx* c);
+
 int csr_ps(pmf_ctx* c);
 int csr_w(pmf_ctx* c);
 
@@ -116,6 +129,11 @@ int dalloc(pmf_ctx* c, T** p, size_t count) {
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
   HIPCHK(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
   return PMF_OK;
+}
+
+int ensure_dv(pmf_ctx* c) {
+  if (c->dV) return PMF_OK;
+  return dalloc(c, &c->dV, (size_t)c->mp * c->np);
 }
 
 // ---- profiling of the dominant kernel -------------------------------------------------
@@ -142,7 +160,8 @@ void stat_end(pmf_ctx* c) {
 // ---- kernel launch helpers --------------------------------------------------------------
 template <int NT, int EPI>
 int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
-                   float* W, const float* G, float* C) {
+                   float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
+  if (rows_p < 0) { rows_p = c->mp; mvalid = c->m; }
   const float lamb = (float)c->lamb_w;
   const size_t smem = rowgemm_smem_bytes<NT>();
   static bool attr_done = false;
@@ -151,20 +170,20 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)(c->mp / 64)), dim3(256), smem, c->stream,
-                     A, lda, kdimA, B, ldb, W, G, C, lamb, c->m, c->k);
+  hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)(rows_p / 64)), dim3(256), smem, c->stream,
+                     A, lda, kdimA, B, ldb, W, G, C, lamb, mvalid, c->k);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
 
 template <int EPI>
 int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
-            float* W, const float* G, float* C) {
+            float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
   switch (c->NT) {
-    case 1: return launch_rowgemm<1, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
-    case 2: return launch_rowgemm<2, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
-    case 4: return launch_rowgemm<4, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
-    case 8: return launch_rowgemm<8, EPI>(c, A, lda, kdimA, B, ldb, W, G, C);
+    case 1: return launch_rowgemm<1, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
+    case 2: return launch_rowgemm<2, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
+    case 4: return launch_rowgemm<4, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
+    case 8: return launch_rowgemm<8, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
   }
   return fail(c, PMF_EINVAL, "bad NT");
 }
@@ -359,7 +378,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
 
 // ---- NMF (multiplicative update) ---------------------------------------------------------
 template <int NT, bool RNMF>
-int launch_resid_t(pmf_ctx* c, float lamb) {
+int launch_resid_t(pmf_ctx* c, float lamb, const float* V, const float* W, int64_t rows_p) {
   const size_t smem = resid_smem_bytes<NT>();
   static bool attr_done = false;
   if (!attr_done) {
@@ -367,18 +386,20 @@ int launch_resid_t(pmf_ctx* c, float lamb) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_resid<NT, RNMF>), dim3((unsigned)(c->mp / 64)), dim3(256), smem, c->stream, c->dV,
-                     (int64_t)c->np, c->np, c->dW, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart);
+  hipLaunchKernelGGL((k_resid<NT, RNMF>), dim3((unsigned)(rows_p / 64)), dim3(256), smem, c->stream, V,
+                     (int64_t)c->np, c->np, W, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
 
-int launch_resid(pmf_ctx* c, bool rnmf, float lamb) {
+int launch_resid(pmf_ctx* c, bool rnmf, float lamb, const float* V = nullptr, const float* W = nullptr,
+                 int64_t rows_p = 0) {
+  if (!V) { V = c->dV; W = c->dW; rows_p = c->mp; }
   switch (c->NT) {
-    case 1: return rnmf ? launch_resid_t<1, true>(c, lamb) : launch_resid_t<1, false>(c, lamb);
-    case 2: return rnmf ? launch_resid_t<2, true>(c, lamb) : launch_resid_t<2, false>(c, lamb);
-    case 4: return rnmf ? launch_resid_t<4, true>(c, lamb) : launch_resid_t<4, false>(c, lamb);
-    case 8: return rnmf ? launch_resid_t<8, true>(c, lamb) : launch_resid_t<8, false>(c, lamb);
+    case 1: return rnmf ? launch_resid_t<1, true>(c, lamb, V, W, rows_p) : launch_resid_t<1, false>(c, lamb, V, W, rows_p);
+    case 2: return rnmf ? launch_resid_t<2, true>(c, lamb, V, W, rows_p) : launch_resid_t<2, false>(c, lamb, V, W, rows_p);
+    case 4: return rnmf ? launch_resid_t<4, true>(c, lamb, V, W, rows_p) : launch_resid_t<4, false>(c, lamb, V, W, rows_p);
+    case 8: return rnmf ? launch_resid_t<8, true>(c, lamb, V, W, rows_p) : launch_resid_t<8, false>(c, lamb, V, W, rows_p);
   }
   return fail(c, PMF_EINVAL, "bad NT");
 }
@@ -775,9 +796,7 @@ int ensure_vnorm(pmf_ctx* c) {
 // ||V||^2 - 2<P,H> + <S H,H> gives the same number from k x n sized data in float64 -- no third
 // pass over V and, across ranks, no extra collective (P, S are already all-reduced).  The identity
 // cancels when the fit is nearly exact; below 1e-3 relative residual energy the direct pass runs.
-int do_frobenius(pmf_ctx* c, double* out) {
-  if (c->v_csr || !c->ps_valid) return frobenius_direct(c, out);
-  PMFCHK(ensure_vnorm(c));
+int trace_e2(pmf_ctx* c, double* e2_out) {   // needs ps_valid and vnorm_valid
   double t[2] = {0.0, 0.0};
   if (c->trace_ready && c->ps_valid) {   // the H-step kernel already produced both terms
     HIPCHK(c, hipMemcpyAsync(t, c->dScal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -791,7 +810,15 @@ int do_frobenius(pmf_ctx* c, double* out) {
     HIPCHK(c, hipMemcpyAsync(t, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const double e2 = c->vnorm2 - 2.0 * t[0] + t[1];
+  *e2_out = c->vnorm2 - 2.0 * t[0] + t[1];
+  return PMF_OK;
+}
+
+int do_frobenius(pmf_ctx* c, double* out) {
+  if (c->v_csr || !c->ps_valid) return frobenius_direct(c, out);
+  PMFCHK(ensure_vnorm(c));
+  double e2 = 0.0;
+  PMFCHK(trace_e2(c, &e2));
   if (!(e2 > 1e-3 * c->vnorm2)) return frobenius_direct(c, out);
   *out = std::sqrt(e2);
   return PMF_OK;
@@ -894,7 +921,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF)
                        ? fused_grid_for(c->NT, c->np, c->mp) : 0;
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
-    PMFCHK(dalloc(c, &c->dV, (size_t)c->mp * c->np));
+    // dV [mp][np] is allocated by the first pmf_set_v_dense_f32 / pmf_fill_v_uniform: CSR and
+    // streamed (pmf_stream_*) contexts never hold a dense V
     PMFCHK(dalloc(c, &c->dW, (size_t)c->mp * c->KP));
     PMFCHK(dalloc(c, &c->dH, (size_t)c->KP * c->np));
     PMFCHK(dalloc(c, &c->dG, (size_t)c->KP * c->KP));
@@ -933,6 +961,11 @@ int pmf_ctx_destroy(pmf_ctx* c) {
                   (void*)c->dW1, (void*)c->dGinvT, (void*)c->dD, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
+  for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc})
+    if (p) hipFree(p);
+  for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
+    if (e) hipEventDestroy(e);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   for (hipEvent_t e : c->stat.ev) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -947,6 +980,7 @@ const char* pmf_path_name(const pmf_ctx* c) { return c ? c->path.c_str() : ""; }
 int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(ensure_dv(c));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
   c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
   return PMF_OK;
@@ -987,6 +1021,7 @@ static int fill(pmf_ctx* c, float* X, int64_t ld, int64_t rows, int64_t cols, in
 
 int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
+  PMFCHK(ensure_dv(c));
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
   c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
   return PMF_OK;
@@ -1128,6 +1163,161 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
   PMFCHK(download_padded(c, Dh.data(), c->n, c->dD, c->np, c->m, c->n));
   PMFCHK(download_padded(c, Vh.data(), c->n, c->dV, c->np, c->m, c->n));
   for (size_t q = 0; q < Dh.size(); ++q) S[q] = Dh[q] + Vh[q];
+  return PMF_OK;
+}
+
+// ---- streamed V: one pass = one reference iteration over row tiles handed in by the caller ------
+// (the `data[:, :]` idiom of nmf.py:123,129 for data that does not fit in HBM --
+// an h5py dataset, a memmap, a matrix larger than 288 GB.)  W stays resident; a tile is visited once
+// per pass: W step on its rows (nmf.py:128-132), then the partials of W^T V and W^T W of the NEW
+// rows, accumulated in float64 over the tiles; pmf_stream_end all-reduces them, runs the H step
+// (nmf.py:122-126) and evaluates ||V - W H|| by the trace identity.  Copies run on their own
+// stream into two device tiles, so the copy of tile t+1 overlaps the kernels of tile t.
+int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
+  if (!c) return PMF_EINVAL;
+  if (c->algo != PMF_ALGO_NMF) return fail(c, PMF_EINVAL, "pmf_stream_*: NMF contexts only");
+  if (!c->have_w || !c->have_h) return fail(c, PMF_EINVAL, "pmf_stream_begin: W and H must be set");
+  if (max_tile_rows < 1) return fail(c, PMF_EINVAL, "pmf_stream_begin: max_tile_rows must be >= 1");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t cap = std::min<int64_t>(round_up(max_tile_rows, 64), c->mp);
+  if (!c->copy_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_consumed[b], hipEventDisableTiming));
+    }
+    PMFCHK(dalloc(c, &c->dPSacc, (size_t)ps_elems(c)));
+    PMFCHK(dalloc(c, &c->dStAcc, 4));
+  }
+  if (cap > c->tile_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    for (int b = 0; b < 2; ++b) {
+      if (c->dTile[b]) { HIPCHK(c, hipFree(c->dTile[b])); c->dTile[b] = nullptr; }
+      PMFCHK(dalloc(c, &c->dTile[b], (size_t)cap * c->np));    // zeroed: pad columns stay 0
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tile_cap = cap;
+  }
+  c->st_flags = flags;
+  c->st_rows_seen = 0;
+  c->st_tiles = 0;
+  c->st_active = true;
+  c->st_vnorm_pending = !(flags & PMF_STREAM_RESID) && !c->vnorm_valid;
+  if ((flags & PMF_COMPUTE_W) && !(flags & PMF_STREAM_RESID)) PMFCHK(ensure_gram(c, 0.0));
+  return PMF_OK;
+}
+
+int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, int64_t ld) {
+  if (!c) return PMF_EINVAL;
+  if (!c->st_active) return fail(c, PMF_EINVAL, "pmf_stream_tile: no pass open (pmf_stream_begin)");
+  if (!tile || ld < c->n || rows < 1 || rows > c->tile_cap || row0 != c->st_rows_seen || row0 + rows > c->m ||
+      (row0 % 64) != 0 || (row0 + rows < c->m && (rows % 64) != 0))
+    return fail(c, PMF_EINVAL, "pmf_stream_tile: tiles must arrive in row order, start on a multiple of 64 rows, "
+                               "hold a multiple of 64 rows (except the last) and fit max_tile_rows");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int b = c->st_tiles & 1;
+  const int64_t rows_p = round_up(rows, 64);
+  float* T = c->dTile[b];
+  if (c->st_tiles >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_consumed[b], 0));
+  HIPCHK(c, hipMemcpy2DAsync(T, (size_t)c->np * sizeof(float), tile, (size_t)ld * sizeof(float),
+                             (size_t)c->n * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, c->copy_stream));
+  if (rows_p > rows)
+    HIPCHK(c, hipMemsetAsync(T + rows * c->np, 0, (size_t)(rows_p - rows) * c->np * sizeof(float), c->copy_stream));
+  HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+  float* Wt = c->dW + row0 * c->KP;
+  const int first = c->st_tiles == 0;
+  if (c->st_flags & PMF_STREAM_RESID) {
+    PMFCHK(launch_resid(c, false, 0.f, T, Wt, rows_p));
+    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, (int)(rows_p / 64), c->dScal + 5);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_accum_f64, dim3(1), dim3(64), 0, c->stream, c->dStAcc + 1, c->dScal + 5, first);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    if (c->st_vnorm_pending) {
+      const int nb = 256;
+      hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, c->stream, T, rows_p * c->np, c->dPart);
+      HIPCHK(c, hipGetLastError());
+      hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 5);
+      HIPCHK(c, hipGetLastError());
+      hipLaunchKernelGGL(k_accum_f64, dim3(1), dim3(64), 0, c->stream, c->dStAcc, c->dScal + 5, first);
+      HIPCHK(c, hipGetLastError());
+    }
+    if (c->st_flags & PMF_COMPUTE_W) {
+      PMFCHK(rowgemm<EPI_NMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
+      c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
+    }
+    if ((c->st_flags & (PMF_COMPUTE_H | PMF_COMPUTE_ERR)) && !((c->st_flags & PMF_COMPUTE_W) == 0 && c->ps_valid)) {
+      const int64_t blocks16 = rows_p / 16;
+      int tch = (int)std::min<int64_t>(c->nchunks, blocks16);
+      const int rpc = (int)((blocks16 + tch - 1) / tch) * 16;
+      tch = (int)((rows_p + rpc - 1) / rpc);
+      dim3 grid((unsigned)tch, (unsigned)((c->np + 255) / 256));
+      switch (c->NT) {
+        case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
+        case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
+        case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
+        default: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
+      }
+      HIPCHK(c, hipGetLastError());
+      const int64_t E = ps_elems(c);
+      hipLaunchKernelGGL(k_reduce_slabs_acc, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dSlab, tch,
+                         E, c->dPSacc, first);
+      HIPCHK(c, hipGetLastError());
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev_consumed[b], c->stream));
+  c->st_rows_seen += rows;
+  c->st_tiles += 1;
+  return PMF_OK;
+}
+
+int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
+  if (!c) return PMF_EINVAL;
+  if (!c->st_active) return fail(c, PMF_EINVAL, "pmf_stream_end: no pass open");
+  c->st_active = false;
+  if (needs_direct) *needs_direct = 0;
+  if (c->st_rows_seen != c->m)
+    return fail(c, PMF_EINVAL, "pmf_stream_end: the tiles covered " + std::to_string(c->st_rows_seen) + " of " +
+                std::to_string(c->m) + " rows");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->st_flags & PMF_STREAM_RESID) {
+    if (c->comm) NCCLCHK(c, ncclAllReduce(c->dStAcc + 1, c->dStAcc + 1, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    double ss = 0.0;
+    HIPCHK(c, hipMemcpyAsync(&ss, c->dStAcc + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ferr) *ferr = std::sqrt(ss);
+    return PMF_OK;
+  }
+  if (c->st_vnorm_pending) {
+    if (c->comm) NCCLCHK(c, ncclAllReduce(c->dStAcc, c->dStAcc, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->vnorm2, c->dStAcc, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->vnorm_valid = true;
+    c->st_vnorm_pending = false;
+  }
+  const bool need_ps = (c->st_flags & (PMF_COMPUTE_H | PMF_COMPUTE_ERR)) != 0;
+  if (need_ps && !c->ps_valid) {
+    const int64_t E = ps_elems(c);
+    hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dPSacc, E, c->dPS);
+    HIPCHK(c, hipGetLastError());
+    PMFCHK(allreduce_ps(c));
+    c->ps_valid = true;
+  }
+  if (c->st_flags & PMF_COMPUTE_H) {
+    c->want_trace = (c->st_flags & PMF_COMPUTE_ERR) != 0;
+    const int rc = h_step_from_ps(c);
+    c->want_trace = false;
+    PMFCHK(rc);
+  }
+  if ((c->st_flags & PMF_COMPUTE_ERR) && ferr) {
+    double e2 = 0.0;
+    PMFCHK(trace_e2(c, &e2));
+    if (!(e2 > 1e-3 * c->vnorm2) && needs_direct) *needs_direct = 1;   // cancellation: ask for a PMF_STREAM_RESID pass
+    *ferr = std::sqrt(e2 > 0.0 ? e2 : 0.0);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return PMF_OK;
 }
 

@@ -376,3 +376,23 @@ __global__ void k_fill_uniform(float* __restrict__ X, int64_t ld, int64_t rows, 
   const int64_t r = e / cols, c = e % cols;
   X[r * ld + c] = u01_from(seed, (uint64_t)((row0 + r) * cols_global + c));
 }
+
+// ---- streamed V (pmf_stream_*): accumulators that live across the tiles of one pass ----------
+// acc[e] (+)= sum over slabs of slab[c][e]  (float64; first != 0 starts a new pass)
+__global__ __launch_bounds__(256) void k_reduce_slabs_acc(const float* __restrict__ slab, int nslabs, int64_t E,
+                                                          double* __restrict__ acc, int first) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  double s = first ? 0.0 : acc[e];
+  for (int c = 0; c < nslabs; ++c) s += (double)slab[(int64_t)c * E + e];
+  acc[e] = s;
+}
+
+__global__ void k_accum_f64(double* __restrict__ dst, const double* __restrict__ src, int first) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = (first ? 0.0 : dst[0]) + src[0];
+}
+
+__global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ src, int64_t E, float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < E) dst[e] = (float)src[e];
+}

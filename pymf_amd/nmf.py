@@ -13,6 +13,7 @@ PLACE into the existing arrays (nmf.py:125-126,131-132) keeping their dtype;
 the arithmetic on the device is float32.
 """
 import logging
+import os
 
 import numpy as np
 
@@ -51,6 +52,10 @@ class NMF(object):
     _EPS = 10 ** -8          # nmf.py:69
     _ALGO = _lib.ALGO_NMF
     _REBIND_W = False        # SNMF rebinds self.W (snmf.py:70); NMF mutates in place
+    #: rows per tile for out-of-core data: when set (or env PYMF_STREAM_ROWS), `data` is never made
+    #: resident -- every iteration reads it tile by tile through `data[r0:r1, :]` (an h5py dataset,
+    #: a np.memmap, anything with that slicing) and streams the tiles through the device.
+    stream_rows = None
 
     def __init__(self, data, num_bases=4):
         def setup_logging():                                   # nmf.py:73-90
@@ -99,9 +104,32 @@ class NMF(object):
         raise TypeError("scipy.sparse data is not supported by %s (the reference fails "
                         "with UFuncTypeError at nmf.py:131)" % type(self).__name__)
 
-    def _sync_to_device(self):
+    def _stream_rows(self):
+        """Tile height of the streamed mode (rounded to 64 rows), or 0 when `data` is kept resident."""
+        r = self.stream_rows or int(os.environ.get("PYMF_STREAM_ROWS", "0") or 0)
+        if not r or self._ALGO != _lib.ALGO_NMF or _is_sparse(self.data):
+            return 0
+        return max(64, (int(r) + 63) // 64 * 64)
+
+    def _stream_pass(self, ctx, rows, **flags):
+        """One pass over `data` in row tiles (pmf_stream_begin / _tile / _end)."""
+        ctx.stream_begin(max_tile_rows=rows, **flags)
+        m = self._data_dimension
+        for r0 in range(0, m, rows):
+            ctx.stream_tile(r0, np.asarray(self.data[r0:min(m, r0 + rows), :]))
+        return ctx.stream_end()
+
+    def _stream_iteration(self, ctx, rows, compute_w, compute_h, compute_err):
+        ferr, needs_direct = self._stream_pass(ctx, rows, compute_w=compute_w, compute_h=compute_h,
+                                               compute_err=compute_err)
+        if compute_err and needs_direct:          # nearly exact fit: the trace identity cancels
+            ferr, _ = self._stream_pass(ctx, rows, resid=True)
+        return ferr
+
+    def _sync_to_device(self, with_data=True):
         ctx = self._context()
-        self._upload_data(ctx)
+        if with_data and not self._stream_rows():
+            self._upload_data(ctx)
         for name, fp_attr, setter in (("W", "_w_fp", ctx.set_w), ("H", "_h_fp", ctx.set_h)):
             arr = getattr(self, name)
             if not np.issubdtype(np.asarray(arr).dtype, np.floating):
@@ -129,6 +157,9 @@ class NMF(object):
     def frobenius_norm(self):
         """||data - W H||_F (nmf.py:100-114); -123456 without W/H or for sparse data."""
         if hasattr(self, 'H') and hasattr(self, 'W') and not _is_sparse(self.data):
+            rows = self._stream_rows()
+            if rows:
+                return self._stream_pass(self._sync_to_device(), rows, resid=True)[0]
             return self._sync_to_device().frobenius()
         return -123456
 
@@ -145,12 +176,20 @@ class NMF(object):
 
     def update_h(self):                                        # nmf.py:122-126
         ctx = self._sync_to_device()
-        ctx.update_h()
+        rows = self._stream_rows()
+        if rows:
+            self._stream_iteration(ctx, rows, False, True, False)
+        else:
+            ctx.update_h()
         self._pull(ctx, False, True)
 
     def update_w(self):                                        # nmf.py:128-132
         ctx = self._sync_to_device()
-        ctx.update_w()
+        rows = self._stream_rows()
+        if rows:
+            self._stream_iteration(ctx, rows, True, False, False)
+        else:
+            ctx.update_w()
         self._pull(ctx, True, False)
 
     def converged(self, i):                                    # nmf.py:134-139
@@ -174,8 +213,12 @@ class NMF(object):
             self.ferr = np.zeros(niter)
 
         ctx = self._sync_to_device()
-        ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
-                                            conv_eps=self._EPS)
+        rows = self._stream_rows()
+        if rows:
+            ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
+        else:
+            ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
+                                                conv_eps=self._EPS)
         self._last_iters = done
         self._pull(ctx, compute_w and done > 0, compute_h and done > 0)
 
@@ -188,6 +231,22 @@ class NMF(object):
                 self._logger.info('Iteration ' + str(i + 1) + '/' + str(niter))
         if compute_err and conv_at >= 0:                       # nmf.py:198-202
             self.ferr = self.ferr[:conv_at]
+
+
+    def _factorize_streamed(self, ctx, rows, niter, compute_w, compute_h, compute_err):
+        """The loop of nmf.py:182-202 with one streamed pass per iteration; same return triple as
+        Context.factorize: (ferr, iterations executed, iteration at which converged() fired or -1)."""
+        ferr = np.zeros(max(int(niter), 1)) if compute_err else None
+        done, conv_at = 0, -1
+        for i in range(niter):
+            e = self._stream_iteration(ctx, rows, compute_w, compute_h, compute_err)
+            done = i + 1
+            if compute_err:
+                ferr[i] = e
+                if i > 1 and abs(ferr[i] - ferr[i - 1]) / self._num_samples < self._EPS:   # nmf.py:134-139,198
+                    conv_at = i
+                    break
+        return ferr, done, conv_at
 
 
 def _setup_module():      # keep `python -m doctest`-style entry harmless

@@ -1,0 +1,141 @@
+"""GPU parity for the streamed (out-of-core) NMF path, SURVEY 8(f) row 4: `data` is read tile by
+tile through `data[r0:r1, :]` and never made resident.  The arithmetic is the resident path's (same
+W-step kernel per tile, W^T V | W^T W accumulated over the tiles in float64), so the tolerances of
+tests/test_gpu_parity.py apply: 2e-5 relative Frobenius on W, H and 1e-5 on ferr."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import pymf_amd
+    from pymf_amd import _lib
+    assert _lib.device_count() >= 1
+    return pymf_amd
+
+
+class SliceOnly(object):
+    """An h5py-dataset-like source: has .shape, serves row slices, refuses to be read whole."""
+
+    def __init__(self, arr, max_rows):
+        self._a, self.shape, self.max_rows, self.reads = arr, arr.shape, max_rows, 0
+
+    def __getitem__(self, key):
+        rs = key[0] if isinstance(key, tuple) else key
+        start, stop, _ = rs.indices(self.shape[0])
+        assert stop - start <= self.max_rows, "the streamed path must never read more than a tile"
+        self.reads += 1
+        return self._a[key]
+
+
+@pytest.mark.parametrize("name,rows", [("nmf_cfg4s", 512), ("nmf_cfg2s", 256), ("nmf_512x128_k16", 64),
+                                       ("nmf_37x29_k5", 64), ("nmf_cfg1_f64", 64)])
+def test_streamed_nmf_vs_reference_golden(pm, name, rows):
+    g = load_golden(name)
+    src = SliceOnly(g["V"], rows)
+    mdl = pm.NMF(src, num_bases=int(g["k"]))
+    mdl.stream_rows = rows
+    mdl.W = g["W0"].copy()
+    mdl.H = g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert src.reads >= int(g["niter"]) * ((g["V"].shape[0] + rows - 1) // rows)
+    assert len(mdl.ferr) == len(g["ferr"])
+    np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=1e-5)
+    assert rel_fro(mdl.W, g["W"]) < 2e-5 and rel_fro(mdl.H, g["H"]) < 2e-5
+
+
+@pytest.mark.parametrize("shape,k,rows", [((5000, 200), 20, 1024), ((1000, 70), 7, 384), ((4096, 256), 64, 4096),
+                                          ((130, 300), 33, 64)])
+def test_streamed_equals_resident(pm, shape, k, rows, tmp_path):
+    rs = np.random.RandomState(shape[0] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    path = str(tmp_path / "v.f32")
+    V.tofile(path)
+    Vmm = np.memmap(path, dtype=np.float32, mode="r", shape=shape)       # out-of-core source
+    res = pm.NMF(V, num_bases=k)
+    res.W, res.H = W0.copy(), H0.copy()
+    res.factorize(niter=6)
+    st = pm.NMF(Vmm, num_bases=k)
+    st.stream_rows = rows
+    st.W, st.H = W0.copy(), H0.copy()
+    st.factorize(niter=6)
+    np.testing.assert_allclose(st.ferr, res.ferr, rtol=2e-6)
+    assert rel_fro(st.W, res.W) < 5e-6 and rel_fro(st.H, res.H) < 5e-6
+    assert abs(st.frobenius_norm() - res.frobenius_norm()) <= 2e-6 * res.frobenius_norm()
+
+
+def test_streamed_flags_and_hooks(pm):
+    from oracle import NMFOracle
+    rs = np.random.RandomState(9)
+    V = rs.random_sample((700, 90)).astype(np.float32)
+    W0, H0 = rs.random_sample((700, 9)), rs.random_sample((9, 90))
+    for flags in (dict(compute_w=False), dict(compute_h=False), dict(compute_err=False)):
+        o = NMFOracle(V, num_bases=9)
+        o.W, o.H = W0.copy(), H0.copy()
+        o.factorize(niter=4, **flags)
+        m = pm.NMF(V, num_bases=9)
+        m.stream_rows = 256
+        m.W, m.H = W0.copy(), H0.copy()
+        m.factorize(niter=4, **flags)
+        assert rel_fro(m.W, o.W) < 2e-5 and rel_fro(m.H, o.H) < 2e-5, flags
+        if flags.get("compute_err", True):
+            np.testing.assert_allclose(m.ferr, o.ferr, rtol=1e-5)
+        else:
+            assert not hasattr(m, "ferr")
+    o = NMFOracle(V, num_bases=9)
+    o.W, o.H = W0.copy(), H0.copy()
+    m = pm.NMF(V, num_bases=9)
+    m.stream_rows = 128
+    m.W, m.H = W0.copy(), H0.copy()
+    for _ in range(2):
+        m.update_w(); o.update_w()
+        m.update_h(); o.update_h()
+    assert rel_fro(m.W, o.W) < 2e-5 and rel_fro(m.H, o.H) < 2e-5
+    assert abs(m.frobenius_norm() - o.frobenius_norm()) <= 1e-5 * o.frobenius_norm()
+
+
+def test_streamed_early_exit_on_exact_data(pm):
+    """nmf.py:198-202 on exact data: the trace identity cancels, the direct residual pass takes over
+    and the loop stops with len(ferr) == 2 exactly as the reference does."""
+    g = load_golden("nmf_earlyexit")
+    mdl = pm.NMF(g["V"], num_bases=int(g["k"]))
+    mdl.stream_rows = 64
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]), compute_w=False)
+    assert len(mdl.ferr) == len(g["ferr"]) == 2
+    assert rel_fro(mdl.H, g["H"]) < 2e-5
+
+
+def test_stream_c_abi_contract(pm):
+    from pymf_amd import _lib
+    from pymf_amd._lib import PmfError
+    V = np.random.RandomState(1).random_sample((300, 40)).astype(np.float32)
+    ctx = _lib.Context(_lib.ALGO_NMF, 300, 40, 5)
+    with pytest.raises(PmfError):
+        ctx.stream_begin()                               # W, H not set
+    ctx.set_w(np.random.RandomState(2).random_sample((300, 5)))
+    ctx.set_h(np.random.RandomState(3).random_sample((5, 40)))
+    with pytest.raises(PmfError):
+        ctx.stream_tile(0, V[:64])                       # no pass open
+    ctx.stream_begin(max_tile_rows=128)
+    with pytest.raises(PmfError):
+        ctx.stream_tile(64, V[64:128])                   # out of order
+    with pytest.raises(PmfError):
+        ctx.stream_tile(0, V[:100])                      # inner tile not a multiple of 64 rows
+    with pytest.raises(PmfError):
+        ctx.stream_tile(0, V[:192])                      # larger than max_tile_rows
+    ctx.stream_tile(0, V[:128])
+    with pytest.raises(PmfError):
+        ctx.stream_end()                                 # rows missing
+    with pytest.raises(PmfError):
+        ctx.update_w()                                   # V was never made resident
+    snmf = _lib.Context(_lib.ALGO_SNMF, 300, 40, 5)
+    snmf.set_w(np.ones((300, 5))); snmf.set_h(np.ones((5, 40)))
+    with pytest.raises(PmfError):
+        snmf.stream_begin()                              # NMF contexts only
+    ctx.close(); snmf.close()
