@@ -31,6 +31,8 @@
 
 namespace {
 
+constexpr int PMF_HGRAM_MAX_WGS = 64;   // workgroups of k_nmf_h_gram (one or more 64-column panels each)
+
 std::string g_create_error;
 
 struct KernelStat {
@@ -57,6 +59,9 @@ struct pmf_ctx {
   bool s_valid = false;         // RNMF: D has been formed (update_s ran)
   double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
   double *dGd = nullptr, *dPart = nullptr, *dScal = nullptr;
+  float* dGpart = nullptr;      // k_nmf_h_gram: per-workgroup partial G, [PMF_HGRAM_MAX_WGS][KP][KP]
+  double* dT1part = nullptr;    // ... and partial <P, H_new>
+  unsigned* dTicket = nullptr;  // ... arrival counter (the kernel resets it)
   // CSR V (SNMF sparse path)
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
   bool v_csr = false;
@@ -437,60 +442,32 @@ int nmf_update_w(pmf_ctx* c) {
   return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
 }
 
-template <int NT, int NPANEL>
-int launch_h_gram_b(pmf_ctx* c);
-
-template <int NT, int NPANEL>
+template <int NT, bool BNMF>
 int launch_h_gram(pmf_ctx* c) {
-  if (c->algo == PMF_ALGO_BNMF) return launch_h_gram_b<NT, NPANEL>(c);
-  constexpr size_t smem = (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * (64 * NPANEL + 4)) * sizeof(float);
+  constexpr size_t smem = hgram_smem_bytes<NT>();
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, NPANEL, false>),
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, BNMF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL, false>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
-                     c->dG, c->dGd, 0.f, c->want_trace ? c->dScal + 2 : nullptr);
+  const int wgs = std::min(c->np / 64, PMF_HGRAM_MAX_WGS);
+  hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
+                     c->dG, c->dGd, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
+                     c->dGpart, c->dT1part, c->dTicket);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
 
-template <int NT, int NPANEL>
-int launch_h_gram_b(pmf_ctx* c) {
-  constexpr size_t smem = (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * (64 * NPANEL + 4)) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, NPANEL, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((k_nmf_h_gram<NT, NPANEL, true>), dim3(1), dim3(1024), smem, c->stream, c->dH, c->dPS,
-                     c->dG, c->dGd, (float)c->lamb_h, c->want_trace ? c->dScal + 2 : nullptr);
-  HIPCHK(c, hipGetLastError());
-  return PMF_OK;
-}
-
-// NMF on the fused-kernel shapes: H step and G = H H^T in one launch.  false: shape not covered.
+// NMF / BNMF: H step and G = H H^T in one launch.  false: not for this algorithm.
 bool nmf_h_gram(pmf_ctx* c, int* rc) {
   if (c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) return false;   // RNMF: generic k_nmf_h
-  if (c->np % 64) return false;
-  const int key = c->NT * 100 + c->np / 64;
-  switch (key) {
-    case 101: *rc = launch_h_gram<1, 1>(c); return true;
-    case 102: *rc = launch_h_gram<1, 2>(c); return true;
-    case 104: *rc = launch_h_gram<1, 4>(c); return true;
-    case 108: *rc = launch_h_gram<1, 8>(c); return true;
-    case 116: *rc = launch_h_gram<1, 16>(c); return true;
-    case 201: *rc = launch_h_gram<2, 1>(c); return true;
-    case 202: *rc = launch_h_gram<2, 2>(c); return true;
-    case 204: *rc = launch_h_gram<2, 4>(c); return true;
-    case 208: *rc = launch_h_gram<2, 8>(c); return true;
-    case 216: *rc = launch_h_gram<2, 16>(c); return true;
-    case 401: *rc = launch_h_gram<4, 1>(c); return true;
-    case 402: *rc = launch_h_gram<4, 2>(c); return true;
-    case 404: *rc = launch_h_gram<4, 4>(c); return true;
-    case 408: *rc = launch_h_gram<4, 8>(c); return true;
+  const bool b = c->algo == PMF_ALGO_BNMF;
+  switch (c->NT) {
+    case 1: *rc = b ? launch_h_gram<1, true>(c) : launch_h_gram<1, false>(c); return true;
+    case 2: *rc = b ? launch_h_gram<2, true>(c) : launch_h_gram<2, false>(c); return true;
+    case 4: *rc = b ? launch_h_gram<4, true>(c) : launch_h_gram<4, false>(c); return true;
+    case 8: *rc = b ? launch_h_gram<8, true>(c) : launch_h_gram<8, false>(c); return true;
   }
   return false;
 }
@@ -931,6 +908,9 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
     PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
     PMFCHK(dalloc(c, &c->dScal, 8));
+    PMFCHK(dalloc(c, &c->dGpart, (size_t)PMF_HGRAM_MAX_WGS * c->KP * c->KP));
+    PMFCHK(dalloc(c, &c->dT1part, (size_t)PMF_HGRAM_MAX_WGS));
+    PMFCHK(dalloc(c, &c->dTicket, 1));
     if (algo == PMF_ALGO_RNMF) PMFCHK(dalloc(c, &c->dD, (size_t)c->mp * c->np));
     if (algo != PMF_ALGO_NMF) {
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
@@ -961,7 +941,8 @@ int pmf_ctx_destroy(pmf_ctx* c) {
                   (void*)c->dW1, (void*)c->dGinvT, (void*)c->dD, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
-  for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc})
+  for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
+                  (void*)c->dT1part, (void*)c->dTicket})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);

@@ -66,135 +66,182 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
   }
 }
 
-// NMF H step AND the Gram matrix of the new H in ONE single-workgroup launch (16 waves, MFMA):
+// NMF H step AND the Gram matrix of the new H in ONE launch (MFMA):
 //   H <- (H * P) / (S H + 1e-9)   (pymf/nmf.py:122-126),  then  G = H H^T  (operand of the next
-//   update_w, nmf.py:130 reassociated).  Both are k x k x n sized: one CU does them in a few
-// microseconds, and the iteration loses two kernel boundaries.  Wave w owns columns
-// [16w, 16w+16) of H for the H step (it reads and rewrites only those columns of the LDS image, so
-// no barrier is needed inside the step) and one 16x16 tile of G afterwards.
-// LDS rows are padded by 4 floats: fragment reads (16 lanes on 16 rows) are conflict-free b128.
-template <int NT, int NPANEL, bool BNMF>
-__global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H,
+//   update_w, nmf.py:130 reassociated).
+// Both are k x k x n sized, but on ONE CU their 2 * KP * KP * np / 1024 MFMAs are the whole
+// duration (8 k cycles each at cfg4), so the columns are spread over workgroups: workgroup g takes
+// the 64-column panels g, g + grid, ...; the H step of a panel needs nothing from other panels, the
+// Gram matrix is a sum over panels.  Each workgroup keeps its partial G in registers across its
+// panels, writes it to Gpart[g], and the LAST workgroup to arrive (atomic ticket) adds the partials
+// in fixed order -- deterministic -- and writes G (float32 + float64) and the trace terms.
+// Wave w of 16 owns tiles (mt, ct) = (q / 4, q % 4), q = w, w + 16, ... of the panel for the H step
+// (the new values go to a second LDS image, the old one stays the B operand of the other waves)
+// and tiles q = w, w + 16, ... of G.  LDS rows are padded by 4 floats: fragment reads are
+// conflict-free b128.
+//   tout (optional): the two data-dependent terms of the trace identity for the residual,
+//   tout[0] = <P, H_new>,  tout[1] = <S H_new, H_new> = <S, G>  (float64 sums).
+template <int NT>
+constexpr size_t hgram_smem_bytes() { return (size_t)(16 * NT * (16 * NT + 4) + 2 * 16 * NT * 68) * sizeof(float); }
+
+template <int NT, bool BNMF>
+__global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int np,
                                                      const float* __restrict__ PS,
                                                      float* __restrict__ Gf, double* __restrict__ Gd,
-                                                     float lamb, double* __restrict__ tout) {
-  // tout (optional): the two data-dependent terms of the trace identity for the residual,
-  //   tout[0] = <P, H_new>,  tout[1] = <S H_new, H_new> = <S, H_new H_new^T> = <S, G>,
-  // both fall out of values this kernel holds anyway (float64 sums).
+                                                     float lamb, double* __restrict__ tout,
+                                                     float* Gpart, double* t1part, unsigned* ticket) {
   __shared__ double red[2][16];
-  constexpr int KP = 16 * NT, NP = 64 * NPANEL, NCT = NP / 16;
-  constexpr int LDS_S = KP + 4, LDS_H = NP + 4;
-  constexpr int64_t ldp = NP + KP;
+  __shared__ unsigned s_last;
+  constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
+  constexpr int HT = NT * 4;                  // H-step tiles of a panel
+  constexpr int HTW = (HT + 15) / 16;         // ... per wave
+  constexpr int GT = NT * NT;                 // G tiles
+  constexpr int GTW = (GT + 15) / 16;
+  const int64_t ldp = (int64_t)np + KP;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* ss = sm;                    // [KP][KP+4]
-  float* hs = sm + KP * LDS_S;       // [KP][NP+4]
+  float* ss = sm;                    // [KP][KP+4]   S = W^T W
+  float* hs = ss + KP * LDS_S;       // [KP][68]     old H panel
+  float* hn = hs + KP * LDS_H;       // [KP][68]     new H panel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
-  // this wave's P values (accumulator layout) are fetched up front, in the same round trip as the
-  // LDS staging loads, so the H step never waits on global memory again
-  constexpr int NCTW = (NCT + 15) / 16;
-  float pv[NCTW][NT][4];
-#pragma unroll
-  for (int cw = 0; cw < NCTW; ++cw)
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ct = wv + 16 * cw;
-        pv[cw][mt][r] = ct < NCT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + 16 * ct + i] : 0.f;
-      }
+  const int npanel = np >> 6;
   for (int q = tid; q < KP * (KP / 4); q += 1024) {
     const int r = q / (KP / 4), c4 = q % (KP / 4);
     *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) =
-        *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + NP + 4 * c4);
+        *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
   }
-  for (int q = tid; q < KP * (NP / 4); q += 1024) {
-    const int r = q / (NP / 4), c4 = q % (NP / 4);
-    *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) =
-        *reinterpret_cast<const f32x4*>(H + (int64_t)r * NP + 4 * c4);
-  }
-  __syncthreads();
-  double t1 = 0.0, t2 = 0.0;
-  // ---- H step: wave w <-> column tiles w, w+16, ... ----
+  f32x4 ge[GTW][4];
 #pragma unroll
-  for (int cw = 0; cw < NCTW; ++cw) {
-    const int ct = wv + 16 * cw;
-    if (ct >= NCT) break;
-    float bfr[NT][4];                 // B[k = 16t+4kq+e][col = 16ct+i] = H[k][col]
+  for (int g = 0; g < GTW; ++g)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int e = 0; e < 4; ++e) ge[g][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  double t1 = 0.0;
+
+  for (int p = blockIdx.x; p < npanel; p += gridDim.x) {
+    const int c0 = 64 * p;
+    // this wave's P values (accumulator layout) ride in the same round trip as the staging loads
+    float pv[HTW][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bfr[t][e] = hs[(16 * t + 4 * kq + e) * LDS_H + 16 * ct + i];
-    f32x4 den[NT];                    // the NT tile rows are independent MFMA chains
+    for (int h = 0; h < HTW; ++h) {
+      const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) den[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x4 a4[NT];
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-        a4[mt] = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) den[mt] = mfma16(a4[mt][e], bfr[t][e], den[mt]);
+      for (int r = 0; r < 4; ++r)
+        pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i] : 0.f;
     }
+    __syncthreads();                                  // the previous panel's images are free
+    for (int q = tid; q < KP * 16; q += 1024) {
+      const int r = q >> 4, c4 = q & 15;
+      *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) =
+          *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
+    }
+    __syncthreads();
+    // ---- H step ----
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
+    for (int h = 0; h < HTW; ++h) {
+      const int q = wv + 16 * h;
+      if (q >= HT) break;
+      const int mt = q >> 2, ct = q & 3;
+      f32x4 den[4];                                   // 4 independent chains, one per element of a 16-byte group
+#pragma unroll
+      for (int e = 0; e < 4; ++e) den[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)                   // B[k = 16t+4kq+e][col = 16ct+i] = H[k][col]
+          den[e] = mfma16(a4[e], hs[(16 * t + 4 * kq + e) * LDS_H + 16 * ct + i], den[e]);
+      }
+      const f32x4 dsum = (den[0] + den[1]) + (den[2] + den[3]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
-        const float h = hs[kk * LDS_H + col];
-        float hn;
+        const float hv = hs[kk * LDS_H + col];
+        float hnew;
         if (BNMF) {                                             // bnmf.py:79-82, H *= H1 / H2
-          const float h1 = pv[cw][mt][r] + (3.0f * lamb) * (h * h);
-          const float h2 = ((den[mt][r] + (2.0f * lamb) * (h * h * h)) + lamb * h) + PMF_EPS_DEN;
-          hn = h * (h1 / h2);
+          const float h1 = pv[h][r] + (3.0f * lamb) * (hv * hv);
+          const float h2 = ((dsum[r] + (2.0f * lamb) * (hv * hv * hv)) + lamb * hv) + PMF_EPS_DEN;
+          hnew = hv * (h1 / h2);
         } else {
-          hn = (h * pv[cw][mt][r]) / (den[mt][r] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:125-126)
+          hnew = (hv * pv[h][r]) / (dsum[r] + PMF_EPS_DEN);     // multiply, then divide (nmf.py:125-126)
         }
-        H[(int64_t)kk * NP + col] = hn;
-        hs[kk * LDS_H + col] = hn;    // only this wave reads/writes these 16 columns in this step
-        t1 = fma((double)pv[cw][mt][r], (double)hn, t1);
+        H[(int64_t)kk * np + c0 + col] = hnew;
+        hn[kk * LDS_H + col] = hnew;
+        t1 = fma((double)pv[h][r], (double)hnew, t1);
       }
-  }
-  __syncthreads();
-  // ---- G = H H^T: wave w <-> tile (w / NT, w % NT) ----
-  if (wv < NT * NT) {
-    const int mt = wv / NT, nt = wv % NT;
-    f32x4 ge[4];                      // 4 independent chains (one per element of the 16-byte group)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ge[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int t = 0; t < NP / 16; ++t) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (16 * mt + i) * LDS_H + 16 * t + 4 * kq);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(hs + (16 * nt + i) * LDS_H + 16 * t + 4 * kq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ge[e] = mfma16(a4[e], b4[e], ge[e]);
     }
-    const f32x4 g = (ge[0] + ge[1]) + (ge[2] + ge[3]);
+    __syncthreads();
+    // ---- partial G += H_p H_p^T ----
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int a = 16 * mt + 4 * kq + r, b = 16 * nt + i;
-      Gf[a * KP + b] = g[r];
-      if (Gd) Gd[a * KP + b] = (double)g[r];
-      t2 = fma((double)ss[a * LDS_S + b], (double)g[r], t2);
+    for (int g = 0; g < GTW; ++g) {
+      const int q = wv + 16 * g;
+      if (q >= GT) break;
+      const int mt = q / NT, nt = q % NT;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(hn + (16 * mt + i) * LDS_H + 16 * t + 4 * kq);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(hn + (16 * nt + i) * LDS_H + 16 * t + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ge[g][e] = mfma16(a4[e], b4[e], ge[g][e]);
+      }
+    }
+  }
+
+  // ---- partials out, ticket, the last workgroup finishes ----
+  float* mine = Gpart + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+  for (int g = 0; g < GTW; ++g) {
+    const int q = wv + 16 * g;
+    if (q >= GT) break;
+    const int mt = q / NT, nt = q % NT;
+    const f32x4 gs = (ge[g][0] + ge[g][1]) + (ge[g][2] + ge[g][3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[(16 * mt + 4 * kq + r) * KP + 16 * nt + i] = gs[r];
+  }
+  t1 = wave_sum_f64(t1);
+  if (lane == 0) red[0][wv] = t1;
+  __syncthreads();
+  if (tid == 0) {
+    double a1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a1 += red[0][w];
+    t1part[blockIdx.x] = a1;
+  }
+  __threadfence();                                    // partials visible device-wide before the ticket
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  // acquire: drop whatever this CU's L1 holds, then the partials are read with plain 16-byte loads
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int nwg = gridDim.x;
+  double t2 = 0.0;
+  for (int q4 = tid; q4 < KP * KP / 4; q4 += 1024) {
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};                   // fixed order over workgroups
+    const f32x4* src = reinterpret_cast<const f32x4*>(Gpart) + q4;
+    for (int w = 0; w < nwg; ++w) g += src[(size_t)w * (KP * KP / 4)];
+    *reinterpret_cast<f32x4*>(Gf + 4 * q4) = g;
+    const int r = (4 * q4) / KP, c = (4 * q4) % KP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (Gd) Gd[4 * q4 + e] = (double)g[e];
+      t2 = fma((double)ss[r * LDS_S + c + e], (double)g[e], t2);
     }
   }
   if (tout) {
-    t1 = wave_sum_f64(t1);
     t2 = wave_sum_f64(t2);
-    if (lane == 0) { red[0][wv] = t1; red[1][wv] = t2; }
+    if (lane == 0) red[1][wv] = t2;
     __syncthreads();
     if (tid == 0) {
       double a1 = 0.0, a2 = 0.0;
+      for (int w = 0; w < nwg; ++w) a1 += t1part[w];
 #pragma unroll
-      for (int w = 0; w < 16; ++w) { a1 += red[0][w]; a2 += red[1][w]; }
+      for (int w = 0; w < 16; ++w) a2 += red[1][w];
       tout[0] = a1;
       tout[1] = a2;
     }
   }
+  if (tid == 0) *ticket = 0u;                         // ready for the next launch (stream order)
 }
 
 // SNMF H step (pymf/snmf.py:72-91) with XW = P^T (P = W^T V) and WW = S = W^T W:
