@@ -62,6 +62,10 @@ struct pmf_ctx {
   float* dGpart = nullptr;      // k_nmf_h_gram: per-workgroup partial G, [PMF_HGRAM_MAX_WGS][KP][KP]
   double* dT1part = nullptr;    // ... and partial <P, H_new>
   unsigned* dTicket = nullptr;  // ... arrival counter (the kernel resets it)
+  // free-running pmf_factorize loop: device-side error history and stop flag
+  double* dFerr = nullptr; int64_t ferr_cap = 0;
+  int* dStop = nullptr;         // [0] 0 run / 1 converged / 2 identity cancels, [1] iteration
+  const int* stop_arg = nullptr;   // what the loop kernels get: dStop while free-running, else NULL
   // CSR V (SNMF sparse path)
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
   bool v_csr = false;
@@ -454,7 +458,7 @@ int launch_h_gram(pmf_ctx* c) {
   const int wgs = std::min(c->np / 64, PMF_HGRAM_MAX_WGS);
   hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
                      c->dG, c->dGd, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
-                     c->dGpart, c->dT1part, c->dTicket);
+                     c->dGpart, c->dT1part, c->dTicket, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -537,7 +541,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
   const int lrc = launch_fused(c->stream, c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT, c->np, c->dV,
-                               c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab);
+                               c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab, c->stop_arg);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -545,7 +549,7 @@ int nmf_fused_iteration(pmf_ctx* c) {
     const int NTP = c->np / 16;
     const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
     hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
-                       c->fused_wgs, c->NT, NTP, c->np, c->dPS);
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, c->stop_arg);
     HIPCHK(c, hipGetLastError());
   }
   PMFCHK(allreduce_ps(c));
@@ -584,7 +588,7 @@ int snmf_fused_iteration(pmf_ctx* c) {
     const int NTP = c->np / 16;
     const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
     hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
-                       c->fused_wgs, c->NT, NTP, c->np, c->dPS);
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, (const int*)nullptr);
     HIPCHK(c, hipGetLastError());
   }
   PMFCHK(allreduce_ps(c));
@@ -942,7 +946,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
-                  (void*)c->dT1part, (void*)c->dTicket})
+                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);
@@ -1076,21 +1080,68 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   int done = 0;
+  // Free-running form of the loop (NMF on the fused kernel with the error on): after a few
+  // iterations in the ordinary form, chunks of iterations are enqueued back to back; the error and
+  // the convergence test of nmf.py:134-139 run on the device (k_conv_check) and a raised stop flag
+  // turns every later launch of the chunk into a no-op, so the results are those of the ordinary
+  // loop while the host reads back once per chunk instead of once per iteration.
+  const bool can_free_run = fused && ce && c->algo == PMF_ALGO_NMF;
+  constexpr int kHostIters = 3, kChunk = 8;
+  bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
-    if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
-      PMFCHK(snmf_csr_fused_iteration(c));                // CSR: one pass over the rows
-    } else if (fused) {                                   // update_w + update_h, one pass over V
-      PMFCHK(c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c));
-    } else {
-      if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184
-      if (ch) PMFCHK(do_update_h(c));                     // nmf.py:186-187
-    }
-    ++done;
-    if (ce && c->algo == PMF_ALGO_RNMF && ch) {           // update_s already summed (V - W H)^2
+    if (free_run) {
+      const int chunk = std::min(kChunk, niter - i);
+      c->stop_arg = c->dStop;
+      int lrc = PMF_OK;
+      for (int j = 0; j < chunk && lrc == PMF_OK; ++j) {
+        lrc = nmf_fused_iteration(c);
+        if (lrc == PMF_OK) {
+          hipLaunchKernelGGL(k_conv_check, dim3(1), dim3(64), 0, c->stream, c->dScal + 2, c->vnorm2, conv_eps,
+                             (double)c->n, i + j, c->dFerr, c->dStop);
+          if (hipGetLastError() != hipSuccess) lrc = fail(c, PMF_EHIP, "k_conv_check launch failed");
+        }
+      }
+      c->stop_arg = nullptr;
+      PMFCHK(lrc);
+      int hstop[2] = {0, -1};
+      HIPCHK(c, hipMemcpyAsync(hstop, c->dStop, sizeof(hstop), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(ferr + i, c->dFerr + i, (size_t)chunk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      ferr[i] = std::sqrt(c->rnmf_err2);
-    } else if (ce) {
-      PMFCHK(do_frobenius(c, &ferr[i]));                  // nmf.py:189-190
+      if (hstop[0] == 0) {                                // the whole chunk ran
+        done += chunk;
+        i += chunk - 1;
+        continue;
+      }
+      // iterations i .. hstop[1] ran, the rest of the chunk were no-ops (with a communicator the
+      // all-reduces still ran on the stale (P | S): it no longer belongs to W)
+      const int s_it = hstop[1];
+      done += s_it - i + 1;
+      if (c->comm) { c->ps_valid = false; c->trace_ready = false; }
+      if (hstop[0] == 1) {                                // nmf.py:198-202
+        if (converged_at) *converged_at = s_it;
+        break;
+      }
+      // the trace identity cancels at iteration s_it: evaluate it directly and go on in the
+      // ordinary form, exactly what do_frobenius would have done
+      free_run = false;
+      i = s_it;
+      PMFCHK(frobenius_direct(c, &ferr[i]));
+    } else {
+      if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
+        PMFCHK(snmf_csr_fused_iteration(c));                // CSR: one pass over the rows
+      } else if (fused) {                                   // update_w + update_h, one pass over V
+        PMFCHK(c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c));
+      } else {
+        if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184
+        if (ch) PMFCHK(do_update_h(c));                     // nmf.py:186-187
+      }
+      ++done;
+      if (ce && c->algo == PMF_ALGO_RNMF && ch) {           // update_s already summed (V - W H)^2
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ferr[i] = std::sqrt(c->rnmf_err2);
+      } else if (ce) {
+        PMFCHK(do_frobenius(c, &ferr[i]));                  // nmf.py:189-190
+      }
     }
     if (ce) {
       if (i > 1) {                                        // nmf.py:198
@@ -1100,6 +1151,19 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
           break;
         }
       }
+    }
+    if (can_free_run && !free_run && i + 1 >= kHostIters && niter - (i + 1) >= 2 && c->vnorm_valid &&
+        ferr[i] * ferr[i] > 1e-2 * c->vnorm2) {
+      // far from the cancellation threshold: hand the history to the device and let it run
+      if (c->ferr_cap < niter) {
+        if (c->dFerr) { HIPCHK(c, hipFree(c->dFerr)); c->dFerr = nullptr; }
+        PMFCHK(dalloc(c, &c->dFerr, (size_t)niter));
+        c->ferr_cap = niter;
+      }
+      if (!c->dStop) PMFCHK(dalloc(c, &c->dStop, 2));
+      HIPCHK(c, hipMemcpyAsync(c->dFerr, ferr, (size_t)(i + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->dStop, 0, 2 * sizeof(int), c->stream));
+      free_run = true;
     }
   }
   c->want_trace = false;

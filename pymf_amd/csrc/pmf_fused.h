@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
                                                        const float* __restrict__ H,
                                                        const float* __restrict__ G, int blk_per,
                                                        int blk_extra, float lamb,
-                                                       float* __restrict__ slab
+                                                       float* __restrict__ slab,
+                                                       const int* __restrict__ stop
 #ifdef PMF_STAMPS
                                                        , unsigned long long* __restrict__ dbg
 #endif
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   // panel over the next phase A's first steps (one LDS-DMA per 16 MFMAs) -- needs 4 panels.
   constexpr bool SPREAD = (NPANEL == 4);
   constexpr bool SNMF = (MODE == FUSED_SNMF);
+  // free-running loops (pmf_factorize): a launch enqueued behind a converged iteration is a no-op
+  if (stop != nullptr && *stop != 0) return;
 #ifdef PMF_STAMPS
   unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
   PMF_STAMP(tk0);
@@ -465,7 +468,7 @@ static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF
 
 template <int NT, int NPANEL, int MODE>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
-                          int64_t mp, int wgs, float lamb, float* slab) {
+                          int64_t mp, int wgs, float lamb, float* slab, const int* stop) {
   const int nblk = (int)(mp / 16), nw = wgs * 4;
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL>();
@@ -477,20 +480,20 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
     attr_done = true;
   }
   hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
-                     blk_extra, lamb, slab);
+                     blk_extra, lamb, slab, stop);
   return PMF_OK;
 }
 
 // G: H H^T (NMF) or inv(H H^T)^T (SNMF), [KP][KP] float32.
 static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
                                const float* H, const float* G, int64_t mp, int wgs, float lamb,
-                               float* slab) {
+                               float* slab, const int* stop = nullptr) {
   const int key = NT * 10 + np / 64;
 #define PMF_FUSED_CASE(K, A, B)                                                                  \
   case K:                                                                                        \
-    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab) \
-           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab) \
-                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab);
+    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
+           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
+                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
     PMF_FUSED_CASE(12, 1, 2)

@@ -89,8 +89,10 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
                                                      const float* __restrict__ PS,
                                                      float* __restrict__ Gf, double* __restrict__ Gd,
                                                      float lamb, double* __restrict__ tout,
-                                                     float* Gpart, double* t1part, unsigned* ticket) {
+                                                     float* Gpart, double* t1part, unsigned* ticket,
+                                                     const int* __restrict__ stop) {
   __shared__ double red[2][16];
+  if (stop != nullptr && *stop != 0) return;
   __shared__ unsigned s_last;
   constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
   constexpr int HT = NT * 4;                  // H-step tiles of a panel
@@ -442,4 +444,19 @@ __global__ void k_accum_f64(double* __restrict__ dst, const double* __restrict__
 __global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ src, int64_t E, float* __restrict__ dst) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e < E) dst[e] = (float)src[e];
+}
+
+// Free-running pmf_factorize loop: iteration i's error and the reference's convergence test on the
+// device (nmf.py:134-139,198-202), so the host does not have to read ferr back after every
+// iteration.  tt = (<P,H>, <S,G>) from k_nmf_h_gram; ||V - W H||^2 = ||V||^2 - 2 tt[0] + tt[1].
+// stop[0]: 0 running, 1 converged at iteration stop[1], 2 the identity cancels at iteration
+// stop[1] (its error must be evaluated directly); once set, every later launch is a no-op.
+__global__ void k_conv_check(const double* __restrict__ tt, double vnorm2, double eps, double nsamp, int i,
+                             double* __restrict__ ferr, int* __restrict__ stop) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || stop[0] != 0) return;
+  const double e2 = vnorm2 - 2.0 * tt[0] + tt[1];
+  if (!(e2 > 1e-3 * vnorm2)) { stop[1] = i; stop[0] = 2; return; }
+  const double f = sqrt(e2);
+  ferr[i] = f;
+  if (i > 1 && fabs(f - ferr[i - 1]) / nsamp < eps) { stop[1] = i; stop[0] = 1; }
 }

@@ -289,8 +289,10 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__
 // buffer; S tiles above the diagonal are mirrored.
 __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __restrict__ slab, int nslabs,
                                                              int NT, int NTP, int np,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out,
+                                                             const int* __restrict__ stop) {
   __shared__ double part[16][64][4];
+  if (stop != nullptr && *stop != 0) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int KP = 16 * NT;
   const int NTU = NT * NTP + NT * (NT + 1) / 2;
