@@ -442,8 +442,11 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 // ---- host-side dispatch -----------------------------------------------------------------
 #ifndef PMF_FUSED_KERNEL_ONLY
 static inline bool fused_shape_ok(int NT, int np) {
+  // LDS: 64 * (npanel * 16 NT + 16 NT + 64 npanel + 64) floats <= 160 KiB
   const int npanel = np / 64;
-  return (NT == 1 || NT == 2 || NT == 4) && npanel >= 1 && npanel <= 4 && npanel != 3 && np % 64 == 0;
+  if (np % 64 != 0 || npanel < 1) return false;
+  const int max_panels = NT == 1 ? 6 : NT == 2 ? 5 : NT == 4 ? 4 : 0;
+  return npanel <= max_panels;
 }
 
 // Workgroups to launch (one per CU), 0 when the shape is not covered by the fused kernel.
@@ -497,12 +500,18 @@ static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const fl
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
     PMF_FUSED_CASE(12, 1, 2)
+    PMF_FUSED_CASE(13, 1, 3)
     PMF_FUSED_CASE(14, 1, 4)
+    PMF_FUSED_CASE(15, 1, 5)
+    PMF_FUSED_CASE(16, 1, 6)
     PMF_FUSED_CASE(21, 2, 1)
     PMF_FUSED_CASE(22, 2, 2)
+    PMF_FUSED_CASE(23, 2, 3)
     PMF_FUSED_CASE(24, 2, 4)
+    PMF_FUSED_CASE(25, 2, 5)
     PMF_FUSED_CASE(41, 4, 1)
     PMF_FUSED_CASE(42, 4, 2)
+    PMF_FUSED_CASE(43, 4, 3)
     PMF_FUSED_CASE(44, 4, 4)
   }
 #undef PMF_FUSED_CASE
