@@ -65,6 +65,7 @@ struct pmf_ctx {
   // free-running pmf_factorize loop: device-side error history and stop flag
   double* dFerr = nullptr; int64_t ferr_cap = 0;
   int* dStop = nullptr;         // [0] 0 run / 1 converged / 2 identity cancels, [1] iteration
+  int* dWarm = nullptr;         // k_nnqp: warm start allowed (k_spd_unique)
   const int* stop_arg = nullptr;   // what the loop kernels get: dStop while free-running, else NULL
   // CSR V (SNMF sparse path)
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
@@ -691,12 +692,20 @@ int snmf_update_h(pmf_ctx* c) {
 }
 
 // ---- NMFALS ---------------------------------------------------------------------------------
+int nnqp_warm_flag(pmf_ctx* c) {   // dWarm[0] = 1 iff the QPs over the current dGd have unique minimisers
+  if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
+  hipLaunchKernelGGL(k_spd_unique, dim3(1), dim3(64), 0, c->stream, c->dGd, c->KP, c->k, c->dWarm);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
 int als_update_w(pmf_ctx* c) {
   // HA = H H^T (nmfals.py:93), -FA = V H^T (nmfals.py:88), one QP per row (nmfals.py:89-90)
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
+  PMFCHK(nnqp_warm_flag(c));
   stat_begin(c);
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m);
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, c->dWarm);
   stat_end(c);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (W) failed");
   HIPCHK(c, hipGetLastError());
@@ -711,7 +720,8 @@ int als_update_h(pmf_ctx* c) {
                      c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
   HIPCHK(c, hipGetLastError());
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n);
+  PMFCHK(nnqp_warm_flag(c));
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, c->dWarm);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
   HIPCHK(c, hipGetLastError());
   c->g_valid = false; c->num_valid = false;
@@ -946,7 +956,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
-                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop})
+                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);

@@ -5,6 +5,10 @@
 // which is the QP the reference hands to cvxopt.solvers.qp(HA, FA = -f, -I, 0)
 // (nmfals.py:74,89).  HA is shared by all problems of a half step, only f differs.
 //
+// X holds the previous iterate on entry; when *warm_flag != 0 its support seeds the passive set.
+// k_spd_unique sets the flag iff HA, apart from dead (zero) rows, is well conditioned -- then the
+// minimiser is unique and the starting point cannot change it; a rank-deficient HA (the reference
+// test's rank-3 data with 4 bases) keeps the cold start, the path the reference's solver walks.
 // One wave per problem, lane t <-> variable t (k <= 64), everything in float64 as the
 // reference forces (nmfals.py:73,78).  Exact active set (Lawson-Hanson on the Gram
 // matrix): the inverse of HA restricted to the passive set is kept explicitly, row t in
@@ -27,6 +31,32 @@ __global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int
   Gd[q] = v;
 }
 
+// flag[0] = 1 iff the unpivoted LDL^T of HA (dead variables, diag <= 1e-12 max diag, left out) keeps
+// every pivot above 1e-8 of its diagonal entry.  One wave, the matrix in LDS.
+__global__ __launch_bounds__(64) void k_spd_unique(const double* __restrict__ Hd, int KP, int k,
+                                                   int* __restrict__ flag) {
+  __shared__ double M[64][65];
+  __shared__ double d0[64];
+  const int t = threadIdx.x;
+  for (int c = 0; c < 64; ++c) M[t][c] = (t < k && c < k) ? Hd[(int64_t)t * KP + c] : (t == c ? 1.0 : 0.0);
+  d0[t] = M[t][t];
+  __syncthreads();
+  double dmax = 0.0;
+  for (int j = 0; j < k; ++j) dmax = fmax(dmax, d0[j]);
+  int ok = 1;
+  for (int j = 0; j < k; ++j) {
+    if (!(d0[j] > 1e-12 * dmax)) continue;               // dead basis
+    const double piv = M[j][j];
+    if (!(piv > 1e-8 * d0[j])) { ok = 0; break; }
+    if (t > j && t < k && d0[t] > 1e-12 * dmax) {
+      const double l = M[t][j] / piv;
+      for (int c = j; c < k; ++c) M[t][c] = fma(-l, M[j][c], M[t][c]);
+    }
+    __syncthreads();
+  }
+  if (t == 0) flag[0] = ok;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -43,7 +73,8 @@ template <int KR>   // variable slots per problem: 16, 32 or 64 (k <= KR)
 __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int KP, int k,
                                               const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
                                               float* __restrict__ X, int64_t x_sk, int64_t x_sp,
-                                              int64_t nprob) {
+                                              int64_t nprob, const int* __restrict__ warm_flag) {
+  const bool warm = warm_flag != nullptr && *warm_flag != 0;
   extern __shared__ __attribute__((aligned(16))) double sH[];   // [KR][KR], + 1 double: tol
   const int tid = threadIdx.x, t = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,20 +100,8 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
     for (int c = 0; c < KR; ++c) A[c] = 0.0;
     unsigned long long pm = 0ull, ban = 0ull;   // passive set / numerically rejected (wave-uniform)
 
-    for (int outer = 0; outer < 3 * k + 3; ++outer) {
-      // ---- most violated dual: j = argmax w over the active (zero) set ----
-      double best = (active && !((pm | ban) & tbit)) ? w : -1.0e300;
-      int bi = t;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      }
-      if (!(best > tol)) break;
-      const int j = __builtin_amdgcn_readfirstlane(bi);
-
-      // ---- border the inverse with variable j: u = A h_P, sigma = HA[j][j] - h_P' u ----
+    // ---- border the inverse with variable j: u = A h_P, sigma = HA[j][j] - h_P' u ----
+    auto border = [&](int j, double rel_min) -> bool {
       const double h = sH[j * KR + (t < KR ? t : 0)];   // HA[j][t] = HA[t][j]
       double u = 0.0;
 #pragma unroll
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       const bool pas = (pm & tbit) != 0ull;
       const double hjj = readlane_f64(h, j);
       const double sig = hjj - wave_sum_f64(pas ? h * u : 0.0);
-      if (!(sig > 1e-13 * hjj)) { ban |= 1ull << j; continue; }   // numerically dependent column
+      if (!(sig > rel_min * hjj)) { ban |= 1ull << j; return false; }   // numerically dependent column
       const double inv = 1.0 / sig;
 #pragma unroll
       for (int c = 0; c < KR; ++c) {
@@ -105,9 +124,11 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
         }
       }
       pm |= 1ull << j;
-
-      // ---- inner loop: unconstrained optimum on the passive set, step back if infeasible ----
-      for (int inner = 0; inner < k + 2; ++inner) {
+      return true;
+    };
+    // ---- unconstrained optimum on the passive set, step back from the feasible x if infeasible ----
+    auto inner = [&]() {
+      for (int it = 0; it < k + 2; ++it) {
         const bool pin = (pm & tbit) != 0ull;
         double s = 0.0;
 #pragma unroll
@@ -152,12 +173,47 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
           if (t == r) x = 0.0;
         }
       }
-
-      // ---- dual w = f - HA x over the passive set ----
+    };
+    // ---- dual w = f - HA x over the passive set ----
+    auto dual = [&]() {
       w = f;
 #pragma unroll
       for (int c = 0; c < KR; ++c)
         if ((pm >> c) & 1ull) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
+    };
+
+    if (warm) {
+      // warm start (the ALS iterates change little from one half step to the next): the support of
+      // the previous solution is bordered in directly -- no arg-max, no trial solve, no dual per
+      // variable -- and the previous solution is the feasible point the first inner loop leaves from
+      const float x0f = active ? X[(int64_t)t * x_sk + prob * x_sp] : 0.f;
+      const double x0 = (x0f > 0.f) ? (double)x0f : 0.0;
+      unsigned long long todo = __ballot(x0 > 0.0);
+      while (todo) {
+        const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+        todo &= todo - 1ull;
+        border(j, 1e-13);                         // a dead basis (zero row of HA) just stays out
+      }
+      ban = 0ull;
+      x = (pm & tbit) ? x0 : 0.0;
+      if (pm) { inner(); dual(); }
+    }
+
+    for (int outer = 0; outer < 3 * k + 3; ++outer) {
+      // ---- most violated dual: j = argmax w over the active (zero) set ----
+      double best = (active && !((pm | ban) & tbit)) ? w : -1.0e300;
+      int bi = t;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (!(best > tol)) break;
+      const int j = __builtin_amdgcn_readfirstlane(bi);
+      if (!border(j, 1e-13)) continue;
+      inner();
+      dual();
     }
     if (active) X[(int64_t)t * x_sk + prob * x_sp] = (float)((pm & tbit) ? x : 0.0);
   }
@@ -165,7 +221,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
 
 // F(var, prob) = F[var * f_sk + prob * f_sp]; X likewise.  Hd: [KP][KP] float64.
 static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, const float* F, int64_t f_sk,
-                              int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob) {
+                              int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm = nullptr) {
   if (k > 64) return PMF_EINVAL;
   const int KR = k <= 16 ? 16 : k <= 32 ? 32 : 64;
   const size_t smem = (size_t)KR * KR * sizeof(double);
@@ -173,9 +229,9 @@ static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, co
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (blocks < 1) blocks = 1;
   switch (KR) {
-    case 16: hipLaunchKernelGGL((k_nnqp<16>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob); break;
-    case 32: hipLaunchKernelGGL((k_nnqp<32>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob); break;
-    default: hipLaunchKernelGGL((k_nnqp<64>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob); break;
+    case 16: hipLaunchKernelGGL((k_nnqp<16>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm); break;
+    case 32: hipLaunchKernelGGL((k_nnqp<32>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm); break;
+    default: hipLaunchKernelGGL((k_nnqp<64>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm); break;
   }
   return PMF_OK;
 }
