@@ -174,7 +174,8 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
   if (rows_p < 0) { rows_p = c->mp; mvalid = c->m; }
   const float lamb = (float)c->lamb_w;
   const size_t smem = rowgemm_smem_bytes<NT>();
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowgemm<NT, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -249,7 +250,8 @@ int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by
   const size_t smem = (size_t)c->np * c->KP * sizeof(float);
   if (smem > 160 * 1024) return fail(c, PMF_EINVAL, "CSR path: n * num_bases too large for the LDS accumulator");
   PMFCHK(colgemm(c, /*with_v=*/false));
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -390,7 +392,8 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
 template <int NT, bool RNMF>
 int launch_resid_t(pmf_ctx* c, float lamb, const float* V, const float* W, int64_t rows_p) {
   const size_t smem = resid_smem_bytes<NT>();
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resid<NT, RNMF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -450,7 +453,8 @@ int nmf_update_w(pmf_ctx* c) {
 template <int NT, bool BNMF>
 int launch_h_gram(pmf_ctx* c) {
   constexpr size_t smem = hgram_smem_bytes<NT>();
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, BNMF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -601,7 +605,8 @@ int snmf_fused_iteration(pmf_ctx* c) {
 template <int NT>
 int launch_csr_fused(pmf_ctx* c, int wgs) {
   const size_t smem = ((size_t)2 * c->np * c->KP + 4 * 16 * c->KP) * sizeof(float);
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_csr_fused<NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -617,7 +622,8 @@ int launch_csr_fused(pmf_ctx* c, int wgs) {
 template <int NT, int NTP>
 int launch_csr_mfma(pmf_ctx* c, int wgs) {
   const size_t smem = ((size_t)16 * NTP * 16 * NT + 64 * 16 * NTP) * sizeof(float) + 16;
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_csr_mfma<NT, NTP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -10,6 +10,15 @@
 // (k-step e of a group takes element e of both operands' float4).
 #pragma once
 #include <hip/hip_runtime.h>
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: launch helpers remember it per device.
+constexpr int PMF_MAX_DEVICES = 64;
+static inline int pmf_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= PMF_MAX_DEVICES) d = 0;
+  return d;
+}
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

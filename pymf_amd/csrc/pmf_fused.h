@@ -475,7 +475,8 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
   const int nblk = (int)(mp / 16), nw = wgs * 4;
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL>();
-  static bool attr_done = false;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
