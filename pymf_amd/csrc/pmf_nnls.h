@@ -103,25 +103,25 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
     // ---- border the inverse with variable j: u = A h_P, sigma = HA[j][j] - h_P' u ----
     auto border = [&](int j, double rel_min) -> bool {
       const double h = sH[j * KR + (t < KR ? t : 0)];   // HA[j][t] = HA[t][j]
+      // Invariant: A[c] of lane t is zero unless both t and c are passive, and x is zero off the
+      // passive set -- so every sum below runs over all KR slots without a test (the extra terms
+      // are exact zeros) and the loops are straight-line code.
       double u = 0.0;
 #pragma unroll
-      for (int c = 0; c < KR; ++c)
-        if ((pm >> c) & 1ull) u = fma(A[c], readlane_f64(h, c), u);
-      const bool pas = (pm & tbit) != 0ull;
+      for (int c = 0; c < KR; ++c) u = fma(A[c], readlane_f64(h, c), u);
       const double hjj = readlane_f64(h, j);
-      const double sig = hjj - wave_sum_f64(pas ? h * u : 0.0);
+      const double sig = hjj - wave_sum_f64(h * u);                     // u is zero off the passive set
       if (!(sig > rel_min * hjj)) { ban |= 1ull << j; return false; }   // numerically dependent column
       const double inv = 1.0 / sig;
+      const double ui = u * inv;
+      const bool isj = (t == j);
 #pragma unroll
       for (int c = 0; c < KR; ++c) {
-        if ((pm >> c) & 1ull) {
-          const double uc = readlane_f64(u, c);
-          if (pas) A[c] = fma(u * inv, uc, A[c]);
-          if (t == j) A[c] = -uc * inv;
-        } else if (c == j) {
-          if (pas) A[c] = -u * inv;
-          if (t == j) A[c] = inv;
-        }
+        const double uc = readlane_f64(u, c);                           // zero for c off the passive set (and c == j)
+        const double upd = fma(ui, uc, A[c]);
+        const double rowj = (c == j) ? inv : -uc * inv;                 // lane j: new row of the inverse
+        const double colj = (c == j) ? -ui : upd;                       // other lanes: new column j
+        A[c] = isj ? rowj : colj;
       }
       pm |= 1ull << j;
       return true;
@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
         const bool pin = (pm & tbit) != 0ull;
         double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < KR; ++c)
-          if ((pm >> c) & 1ull) s = fma(A[c], readlane_f64(f, c), s);
+        for (int c = 0; c < KR; ++c) s = fma(A[c], readlane_f64(f, c), s);
         if (!pin) s = 0.0;
         const bool bad = pin && !(s > 0.0);
         if (__ballot(bad) == 0ull) { x = s; break; }
@@ -156,18 +155,13 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
           for (int c = 0; c < KR; ++c)
             if (c == r) colr = A[c];
           const double arr = readlane_f64(colr, r);
-          const double scale = colr / arr;
-          const bool pt = (pm & tbit) != 0ull;
+          const double scale = colr / arr;                // zero on lanes off the passive set
+          const bool isr = (t == r);
 #pragma unroll
           for (int c = 0; c < KR; ++c) {
-            if ((pm >> c) & 1ull) {
-              const double arc = readlane_f64(A[c], r);   // inv[r][c]
-              if (pt && t != r && c != r) A[c] = fma(-scale, arc, A[c]);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < KR; ++c) {
-            if (c == r || t == r) A[c] = 0.0;
+            const double arc = readlane_f64(A[c], r);     // inv[r][c], zero for c off the passive set
+            const double v = fma(-scale, arc, A[c]);
+            A[c] = (isr || c == r) ? 0.0 : v;
           }
           pm &= ~(1ull << r);
           if (t == r) x = 0.0;
@@ -178,8 +172,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
     auto dual = [&]() {
       w = f;
 #pragma unroll
-      for (int c = 0; c < KR; ++c)
-        if ((pm >> c) & 1ull) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
+      for (int c = 0; c < KR; ++c) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
     };
 
     if (warm) {
