@@ -112,17 +112,13 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       const double hjj = readlane_f64(h, j);
       const double sig = hjj - wave_sum_f64(h * u);                     // u is zero off the passive set
       if (!(sig > rel_min * hjj)) { ban |= 1ull << j; return false; }   // numerically dependent column
+      // bordered inverse [A + u u'/sig, -u/sig; -u'/sig, 1/sig] = A + v v'/sig with v = (u; -1):
+      // row j and column j of A are zero beforehand, so ONE rank-one update writes all four parts
       const double inv = 1.0 / sig;
-      const double ui = u * inv;
-      const bool isj = (t == j);
+      const double v = (t == j) ? -1.0 : u;                             // u is zero off the passive set
+      const double vi = v * inv;
 #pragma unroll
-      for (int c = 0; c < KR; ++c) {
-        const double uc = readlane_f64(u, c);                           // zero for c off the passive set (and c == j)
-        const double upd = fma(ui, uc, A[c]);
-        const double rowj = (c == j) ? inv : -uc * inv;                 // lane j: new row of the inverse
-        const double colj = (c == j) ? -ui : upd;                       // other lanes: new column j
-        A[c] = isj ? rowj : colj;
-      }
+      for (int c = 0; c < KR; ++c) A[c] = fma(vi, readlane_f64(v, c), A[c]);
       pm |= 1ull << j;
       return true;
     };
