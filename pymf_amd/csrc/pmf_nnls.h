@@ -106,9 +106,16 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       // Invariant: A[c] of lane t is zero unless both t and c are passive, and x is zero off the
       // passive set -- so every sum below runs over all KR slots without a test (the extra terms
       // are exact zeros) and the loops are straight-line code.
+      // slots above the highest passive index hold zeros: the loops stop there (blocks of 8, one
+      // uniform branch each) -- the warm start borders in ascending order, so its early steps are short
+      const int hi = 63 - __builtin_clzll(pm | (1ull << j));
       double u = 0.0;
 #pragma unroll
-      for (int c = 0; c < KR; ++c) u = fma(A[c], readlane_f64(h, c), u);
+      for (int cb = 0; cb < KR; cb += 8) {
+        if (cb > hi) break;
+#pragma unroll
+        for (int c = cb; c < cb + 8; ++c) u = fma(A[c], readlane_f64(h, c), u);
+      }
       const double hjj = readlane_f64(h, j);
       const double sig = hjj - wave_sum_f64(h * u);                     // u is zero off the passive set
       if (!(sig > rel_min * hjj)) { ban |= 1ull << j; return false; }   // numerically dependent column
@@ -118,7 +125,11 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       const double v = (t == j) ? -1.0 : u;                             // u is zero off the passive set
       const double vi = v * inv;
 #pragma unroll
-      for (int c = 0; c < KR; ++c) A[c] = fma(vi, readlane_f64(v, c), A[c]);
+      for (int cb = 0; cb < KR; cb += 8) {
+        if (cb > hi) break;
+#pragma unroll
+        for (int c = cb; c < cb + 8; ++c) A[c] = fma(vi, readlane_f64(v, c), A[c]);
+      }
       pm |= 1ull << j;
       return true;
     };
@@ -126,9 +137,14 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
     auto inner = [&]() {
       for (int it = 0; it < k + 2; ++it) {
         const bool pin = (pm & tbit) != 0ull;
+        const int hi = pm ? 63 - __builtin_clzll(pm) : -1;
         double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < KR; ++c) s = fma(A[c], readlane_f64(f, c), s);
+        for (int cb = 0; cb < KR; cb += 8) {
+          if (cb > hi) break;
+#pragma unroll
+          for (int c = cb; c < cb + 8; ++c) s = fma(A[c], readlane_f64(f, c), s);
+        }
         if (!pin) s = 0.0;
         const bool bad = pin && !(s > 0.0);
         if (__ballot(bad) == 0ull) { x = s; break; }
@@ -166,9 +182,14 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
     };
     // ---- dual w = f - HA x over the passive set ----
     auto dual = [&]() {
+      const int hi = pm ? 63 - __builtin_clzll(pm) : -1;
       w = f;
 #pragma unroll
-      for (int c = 0; c < KR; ++c) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
+      for (int cb = 0; cb < KR; cb += 8) {
+        if (cb > hi) break;
+#pragma unroll
+        for (int c = cb; c < cb + 8; ++c) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
+      }
     };
 
     if (warm) {
