@@ -57,6 +57,13 @@ __global__ __launch_bounds__(64) void k_spd_unique(const double* __restrict__ Hd
   if (t == 0) flag[0] = ok;
 }
 
+#ifdef PMF_NNQP_COUNT   // diagnostic build only (tools/nnqp_probe.hip)
+__device__ unsigned long long g_nnqp_cnt[4];   // outer iterations, removals, problems, rejected borders
+#define PMF_NNQP_TICK(q) do { if (t == 0) atomicAdd(&g_nnqp_cnt[q], 1ull); } while (0)
+#else
+#define PMF_NNQP_TICK(q) do { } while (0)
+#endif
+
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
 
   for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const double f = active ? (double)F[(int64_t)t * f_sk + prob * f_sp] : 0.0;
+    PMF_NNQP_TICK(2);
     double x = 0.0, w = f;
     double A[KR];
 #pragma unroll
@@ -114,7 +122,11 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       for (int cb = 0; cb < KR; cb += 8) {
         if (cb > hi) break;
 #pragma unroll
-        for (int c = cb; c < cb + 8; ++c) u = fma(A[c], readlane_f64(h, c), u);
+        for (int c = cb; c < cb + 8; c += 4) {          // 4 broadcasts, then 4 fmas: no hazard nops
+          const double b0 = readlane_f64(h, c), b1 = readlane_f64(h, c + 1), b2 = readlane_f64(h, c + 2),
+                       b3 = readlane_f64(h, c + 3);
+          u = fma(A[c], b0, u); u = fma(A[c + 1], b1, u); u = fma(A[c + 2], b2, u); u = fma(A[c + 3], b3, u);
+        }
       }
       const double hjj = readlane_f64(h, j);
       const double sig = hjj - wave_sum_f64(h * u);                     // u is zero off the passive set
@@ -128,7 +140,12 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       for (int cb = 0; cb < KR; cb += 8) {
         if (cb > hi) break;
 #pragma unroll
-        for (int c = cb; c < cb + 8; ++c) A[c] = fma(vi, readlane_f64(v, c), A[c]);
+        for (int c = cb; c < cb + 8; c += 4) {
+          const double b0 = readlane_f64(v, c), b1 = readlane_f64(v, c + 1), b2 = readlane_f64(v, c + 2),
+                       b3 = readlane_f64(v, c + 3);
+          A[c] = fma(vi, b0, A[c]); A[c + 1] = fma(vi, b1, A[c + 1]);
+          A[c + 2] = fma(vi, b2, A[c + 2]); A[c + 3] = fma(vi, b3, A[c + 3]);
+        }
       }
       pm |= 1ull << j;
       return true;
@@ -143,7 +160,11 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
         for (int cb = 0; cb < KR; cb += 8) {
           if (cb > hi) break;
 #pragma unroll
-          for (int c = cb; c < cb + 8; ++c) s = fma(A[c], readlane_f64(f, c), s);
+          for (int c = cb; c < cb + 8; c += 4) {
+            const double b0 = readlane_f64(f, c), b1 = readlane_f64(f, c + 1), b2 = readlane_f64(f, c + 2),
+                         b3 = readlane_f64(f, c + 3);
+            s = fma(A[c], b0, s); s = fma(A[c + 1], b1, s); s = fma(A[c + 2], b2, s); s = fma(A[c + 3], b3, s);
+          }
         }
         if (!pin) s = 0.0;
         const bool bad = pin && !(s > 0.0);
@@ -162,6 +183,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
         while (rm) {
           const int r = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rm));
           rm &= rm - 1ull;
+          PMF_NNQP_TICK(1);
           double colr = 0.0;                     // inv[t][r]
 #pragma unroll
           for (int c = 0; c < KR; ++c)
@@ -188,7 +210,13 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       for (int cb = 0; cb < KR; cb += 8) {
         if (cb > hi) break;
 #pragma unroll
-        for (int c = cb; c < cb + 8; ++c) w = fma(-sH[c * KR + (t < KR ? t : 0)], readlane_f64(x, c), w);
+        for (int c = cb; c < cb + 8; c += 4) {
+          const double b0 = readlane_f64(x, c), b1 = readlane_f64(x, c + 1), b2 = readlane_f64(x, c + 2),
+                       b3 = readlane_f64(x, c + 3);
+          const int tl = t < KR ? t : 0;
+          w = fma(-sH[c * KR + tl], b0, w); w = fma(-sH[(c + 1) * KR + tl], b1, w);
+          w = fma(-sH[(c + 2) * KR + tl], b2, w); w = fma(-sH[(c + 3) * KR + tl], b3, w);
+        }
       }
     };
 
@@ -221,7 +249,8 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       }
       if (!(best > tol)) break;
       const int j = __builtin_amdgcn_readfirstlane(bi);
-      if (!border(j, 1e-13)) continue;
+      PMF_NNQP_TICK(0);
+      if (!border(j, 1e-13)) { PMF_NNQP_TICK(3); continue; }
       inner();
       dual();
     }
