@@ -931,6 +931,9 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dGpart, (size_t)PMF_HGRAM_MAX_WGS * c->KP * c->KP));
     PMFCHK(dalloc(c, &c->dT1part, (size_t)PMF_HGRAM_MAX_WGS));
     PMFCHK(dalloc(c, &c->dTicket, 1));
+    PMFCHK(dalloc(c, &c->dStop, 2));
+    c->ferr_cap = 4096;
+    PMFCHK(dalloc(c, &c->dFerr, (size_t)c->ferr_cap));
     if (algo == PMF_ALGO_RNMF) PMFCHK(dalloc(c, &c->dD, (size_t)c->mp * c->np));
     if (algo != PMF_ALGO_NMF) {
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
@@ -1096,13 +1099,13 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   int done = 0;
-  // Free-running form of the loop (NMF on the fused kernel with the error on): after a few
-  // iterations in the ordinary form, chunks of iterations are enqueued back to back; the error and
+  // Free-running form of the loop (NMF on the fused kernel with the error on): after one
+  // iteration in the ordinary form, chunks of iterations are enqueued back to back; the error and
   // the convergence test of nmf.py:134-139 run on the device (k_conv_check) and a raised stop flag
   // turns every later launch of the chunk into a no-op, so the results are those of the ordinary
   // loop while the host reads back once per chunk instead of once per iteration.
   const bool can_free_run = fused && ce && c->algo == PMF_ALGO_NMF;
-  constexpr int kHostIters = 3, kChunk = 8;
+  constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
     if (free_run) {
