@@ -898,6 +898,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   c->np = (int)round_up(n, 64);
   c->NT = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
   c->KP = 16 * c->NT;
+  // 448 columns are not a panel count the wide (two waves per block) fused kernel takes: pad to 512
+  if ((algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF) && c->NT <= 2 && c->np == 448) c->np = 512;
   int rc = [&]() -> int {
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -916,7 +918,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
     c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF)
-                       ? fused_grid_for(c->NT, c->np, c->mp) : 0;
+                       ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     // dV [mp][np] is allocated by the first pmf_set_v_dense_f32 / pmf_fill_v_uniform: CSR and
     // streamed (pmf_stream_*) contexts never hold a dense V

@@ -53,9 +53,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NT, int NPANEL>
+// SPLIT = 2 (wide data): the two waves of a pair share every 16-row block, each owning NPANEL of
+// the 2 * NPANEL column panels; H holds all panels, and a 4 * NT KiB exchange area carries the
+// partial Num tiles between the partners.
+template <int NT, int NPANEL, int SPLIT = 1>
 constexpr size_t fused_smem_bytes() {
-  return (size_t)64 * (NPANEL * 16 * NT + 16 * NT + 4 * 16 * NPANEL + 4 * 16) * sizeof(float);
+  return (size_t)64 * (SPLIT * NPANEL * 16 * NT + 16 * NT + 4 * 16 * NPANEL + 4 * 16) * sizeof(float) +
+         (SPLIT == 2 ? (size_t)4 * NT * 1024 : 0);
 }
 
 // Swizzle of the 16-row V tile.  It is read two ways: phase A takes 16 rows x one chunk per
@@ -73,7 +77,7 @@ __device__ __forceinline__ f32x4 vtile_read4(const float* base, int row, int chu
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
 enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2 };
 
-template <int NT, int NPANEL, int MODE>
+template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
                                                        float* __restrict__ W,
                                                        const float* __restrict__ H,
@@ -86,8 +90,10 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #endif
                                                        ) {
   constexpr int KP = 16 * NT;
-  constexpr int NP = 64 * NPANEL;
-  constexpr int NTP = 4 * NPANEL;   // column tiles of P
+  static_assert(SPLIT == 1 || (SPLIT == 2 && MODE != FUSED_SNMF), "SPLIT: 1, or 2 for the NMF/BNMF epilogues");
+  constexpr int NPT = NPANEL * SPLIT;   // column panels of the data; a wave owns NPANEL of them
+  constexpr int NP = 64 * NPT;
+  constexpr int NTP = 4 * NPANEL;   // column tiles of P held by one wave
   // DMA of the next block's V panel p is spread over phase B's panel p+1 steps and the last
   // panel over the next phase A's first steps (one LDS-DMA per 16 MFMAs) -- needs 4 panels.
   constexpr bool SPREAD = (NPANEL == 4);
@@ -99,8 +105,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   PMF_STAMP(tk0);
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sH = smem;                             // [NPANEL][KP][64]   swizzled rows
-  float* sG = sH + NPANEL * KP * 64;            // [KP][64]
+  float* sH = smem;                             // [NPT][KP][64]   swizzled rows
+  float* sG = sH + NPT * KP * 64;               // [KP][64]
   float* sVall = sG + KP * 64;                  // 4 waves x [NPANEL][16][64]
   float* sWall = sVall + 4 * NPANEL * 16 * 64;  // 4 waves x [16][64]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -108,11 +114,15 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   const int i = lane & 15, kq = lane >> 4;
   float* sV = sVall + wv * (NPANEL * 1024);
   float* sW = sWall + wv * 1024;
+  f32x4* sX = reinterpret_cast<f32x4*>(sWall + 4 * 1024);   // SPLIT 2: [4 waves][NT][64] partial Num
+  const int half = SPLIT == 2 ? (wv & 1) : 0;   // which NPANEL panels of a block this wave owns
+  const int hp = half * NPANEL;
 
-  // ---- this wave's contiguous range of 16-row blocks (all scalar) ----
-  const int gw = blockIdx.x * 4 + wv;
+  // ---- this wave's (SPLIT 2: this pair's) contiguous range of 16-row blocks (all scalar) ----
+  const int gw = SPLIT == 2 ? blockIdx.x * 2 + (wv >> 1) : blockIdx.x * 4 + wv;
   const int b0 = gw * blk_per + (gw < blk_extra ? gw : blk_extra);
   const int nb = blk_per + (gw < blk_extra ? 1 : 0);
+  const int nb_wg = blk_per + (blk_extra > 0 ? 1 : 0);   // SPLIT 2: barrier trips, same for every wave
 
   // LDS-DMA geometry: one instruction = 4 rows x 256 B; lane L fills physical chunk (L & 15)
   // of row 4q + (L >> 4), so it fetches logical chunk (L & 15) ^ row.  Per-lane BYTE offsets
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #ifdef PMF_ABLATE_DMA      // timing-only diagnostic build: outputs are wrong
     if (blk != b0) return;
 #endif
-    PMF_GLDS16(Vb + ((size_t)blk * (16 * NP * 4) + p * 256) + voff[q], sV + p * 1024 + q * 256);
+    PMF_GLDS16(Vb + ((size_t)blk * (16 * NP * 4) + (hp + p) * 256) + voff[q], sV + p * 1024 + q * 256);
   };
   auto issue_w = [&](int blk, int q) {
 #ifdef PMF_ABLATE_DMA
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   // instruction, all in flight together with the first block's V/W tiles ----
   {
     const int drow = lane >> 4, dchunk = lane & 15;
-    for (int d = wv; d < NPANEL * (KP / 4); d += 4) {          // H: panel p, rows 4rg..4rg+3
+    for (int d = wv; d < NPT * (KP / 4); d += 4) {             // H: panel p, rows 4rg..4rg+3
       const int p = d / (KP / 4), rg = d % (KP / 4);
       const int row = 4 * rg + drow;
       const float* src = H + (size_t)row * NP + 64 * p + 4 * (dchunk ^ (row & 15));
@@ -197,7 +207,11 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
   unsigned long long acc_wait = 0, acc_a = 0, acc_dma = 0, acc_epi = 0, acc_b = 0;
 #endif
-  for (int b = 0; b < nb; ++b) {
+  for (int b = 0; b < (SPLIT == 2 ? nb_wg : nb); ++b) {
+    if (SPLIT == 2) {
+      __syncthreads();                                  // the exchange area is free again
+      if (b >= nb) { __syncthreads(); continue; }       // a pair without this block only keeps step
+    }
     const int blk = b0 + b;
     const bool more = (b + 1 < nb);
     PMF_STAMP(ts0);
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         const int p = s >> 2, chunk = 4 * (s & 3) + kq;
         fa[buf] = vtile_read4(sV + p * 1024, i, chunk);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sH + p * (KP * 64), 16 * nt + i, chunk);
+        for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sH + (hp + p) * (KP * 64), 16 * nt + i, chunk);
       } else {
         const int chunk = 4 * (s - NSN) + kq;
         fa[buf] = lds_read4(sW, i, chunk);
@@ -288,6 +302,15 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                     // remaining MFMAs
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (SPLIT == 2) {
+      // Num of this wave's panels + Num of the partner's = V_b H^T: both partners form the same sum
+      // (a + b == b + a exactly), hence the same new W rows
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sX[(wv * NT + nt) * 64 + lane] = num[nt];
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) num[nt] += sX[((wv ^ 1) * NT + nt) * 64 + lane];
+    }
     PMF_STAMP(ts2);
     // old W rows in the accumulator (C) layout, then the W image is free: prefetch the next block's
     float wold[NT][4];
@@ -326,9 +349,11 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           w = pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);   // nmf.py:131-132
         }
         wn[nt][j] = w;
-        wdst[j * KP + 16 * nt] = w;
+        if (SPLIT == 1 || half == 0) {                       // one partner stores W and forms S
+          wdst[j * KP + 16 * nt] = w;
 #pragma unroll
-        for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
+          for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
+        }
       }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wp[nt] = wn[nt];
@@ -380,12 +405,14 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   PMF_STAMP(tk2);
 #endif
   // S of the last block
+  if (SPLIT == 1 || half == 0) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
+        for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
+  }
 
   // ---- sum the 4 waves' accumulators through LDS, write ONE tile-major slab per workgroup ----
   // Slab = NTU tiles of 64 lanes x float4 in the accumulator layout (P tiles, then the S tiles
@@ -395,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   constexpr int NTU = NT * NTP + NT * (NT + 1) / 2;
   __syncthreads();
   f32x4* ex = reinterpret_cast<f32x4*>(smem);   // two regions of NTU*64 f32x4
-  static_assert((size_t)2 * NTU * 64 * 16 <= fused_smem_bytes<NT, NPANEL>(), "exchange fits");
+  static_assert((size_t)2 * NTU * 64 * 16 <= fused_smem_bytes<NT, NPANEL, SPLIT>(), "exchange fits");
   auto put = [&](int region) {
     f32x4* dst = ex + (size_t)region * NTU * 64 + lane;
 #pragma unroll
@@ -424,10 +451,21 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   __syncthreads();
   if (wv < 2) put(wv);
   __syncthreads();
-  {
+  if (SPLIT == 1) {
     f32x4* out = reinterpret_cast<f32x4*>(slab) + (size_t)blockIdx.x * NTU * 64 + lane;
     for (int t = wv; t < NTU; t += 4)
       out[t * 64] = ex[t * 64 + lane] + ex[(size_t)NTU * 64 + t * 64 + lane];
+  } else {
+    // region h holds the P tiles of panels h * NPANEL .. (summed over the two pairs); S lives in
+    // region 0.  The slab is tile-major over ALL panels: P tile (mt, 4 * panel + e), then S.
+    constexpr int NTPT = 4 * NPT, NTUT = NT * NTPT + NT * (NT + 1) / 2;
+    f32x4* out = reinterpret_cast<f32x4*>(slab) + (size_t)blockIdx.x * NTUT * 64 + lane;
+    for (int t = wv; t < 2 * NT * NTP; t += 4) {
+      const int h = t / (NT * NTP), q = t % (NT * NTP), mt = q / NTP, nt = q % NTP;
+      out[(mt * NTPT + h * NTP + nt) * 64] = ex[(size_t)h * NTU * 64 + q * 64 + lane];
+    }
+    for (int t = wv; t < NT * (NT + 1) / 2; t += 4)
+      out[(NT * NTPT + t) * 64] = ex[(NT * NTP + t) * 64 + lane];
   }
 #ifdef PMF_STAMPS
   PMF_STAMP(tk3);
@@ -449,15 +487,23 @@ static inline bool fused_shape_ok(int NT, int np) {
   return npanel <= max_panels;
 }
 
+// Wider data, k <= 32: two waves share each 16-row block (SPLIT 2), 2 x 3 or 2 x 4 panels.
+static inline bool fused_shape_split(int NT, int np) {
+  if (NT == 2) return np == 384 || np == 512;
+  if (NT == 1) return np == 512;
+  return false;
+}
+
 // Workgroups to launch (one per CU), 0 when the shape is not covered by the fused kernel.
-static inline int fused_grid_for(int NT, int np, int64_t mp) {
-  if (!fused_shape_ok(NT, np)) return 0;
+static inline int fused_grid_for(int NT, int np, int64_t mp, bool allow_split = true) {
+  const bool split = allow_split && !fused_shape_ok(NT, np) && fused_shape_split(NT, np);
+  if (!fused_shape_ok(NT, np) && !split) return 0;
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
     cus = prop.multiProcessorCount;
   const int64_t nblk = mp / 16;
-  int64_t wgs = (nblk + 3) / 4;
+  int64_t wgs = split ? (nblk + 1) / 2 : (nblk + 3) / 4;
   if (wgs > cus) wgs = cus;
   return (int)wgs;
 }
@@ -469,21 +515,21 @@ static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF
   return buf;
 }
 
-template <int NT, int NPANEL, int MODE>
+template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
                           int64_t mp, int wgs, float lamb, float* slab, const int* stop) {
-  const int nblk = (int)(mp / 16), nw = wgs * 4;
+  const int nblk = (int)(mp / 16), nw = wgs * (SPLIT == 2 ? 2 : 4);   // waves, or pairs of waves
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
-  const size_t smem = fused_smem_bytes<NT, NPANEL>();
+  const size_t smem = fused_smem_bytes<NT, NPANEL, SPLIT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_fused<NT, NPANEL, MODE, SPLIT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return PMF_EHIP;
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
+  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE, SPLIT>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
                      blk_extra, lamb, slab, stop);
   return PMF_OK;
 }
@@ -492,6 +538,20 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
 static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
                                const float* H, const float* G, int64_t mp, int wgs, float lamb,
                                float* slab, const int* stop = nullptr) {
+  if (!fused_shape_ok(NT, np) && fused_shape_split(NT, np) && mode != FUSED_SNMF) {
+    const int skey = NT * 10 + np / 128;
+#define PMF_FUSED_SPLIT_CASE(K, A, B)                                                                   \
+  case K:                                                                                               \
+    return mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
+                              : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
+    switch (skey) {
+      PMF_FUSED_SPLIT_CASE(14, 1, 4)
+      PMF_FUSED_SPLIT_CASE(23, 2, 3)
+      PMF_FUSED_SPLIT_CASE(24, 2, 4)
+    }
+#undef PMF_FUSED_SPLIT_CASE
+    return PMF_EINVAL;
+  }
   const int key = NT * 10 + np / 64;
 #define PMF_FUSED_CASE(K, A, B)                                                                  \
   case K:                                                                                        \

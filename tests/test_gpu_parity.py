@@ -342,9 +342,10 @@ def test_fused_vs_tiled_random_shapes(pm):
     rs = np.random.RandomState(2024)
     shapes = [(16, 64, 16), (15, 33, 7), (4096 * 16 + 16, 256, 64), (16400, 192, 48), (1023 * 16, 128, 64),
               (1024 * 16, 64, 32), (1025 * 16 + 3, 256, 17), (70000, 250, 60), (33, 256, 64),
-              (5000, 300, 16), (5000, 384, 10), (9000, 320, 32), (3000, 190, 64), (20000, 130, 20)]
+              (5000, 300, 16), (5000, 384, 10), (9000, 320, 32), (3000, 190, 64), (20000, 130, 20),
+              (5000, 512, 32), (3000, 400, 20), (7000, 500, 9), (4099, 384, 31), (17, 450, 32), (65536 + 48, 512, 17)]
     for _ in range(10):
-        shapes.append((int(rs.randint(1, 40000)), int(rs.randint(1, 385)), int(rs.randint(1, 65))))
+        shapes.append((int(rs.randint(1, 40000)), int(rs.randint(1, 513)), int(rs.randint(1, 65))))
     for (m, n, k) in shapes:
         V = rs.random_sample((m, n)).astype(np.float32)
         W0 = rs.random_sample((m, k)).astype(np.float32)
