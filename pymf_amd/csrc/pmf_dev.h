@@ -58,10 +58,27 @@ __device__ __forceinline__ void lds_write4(float* base, int row, int chunk, f32x
   *reinterpret_cast<f32x4*>(base + swz_off(row, chunk)) = v;
 }
 
+// Sum over the 64 lanes, returned in every lane.  Butterfly inside each row of 16 lanes on DPP
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: register-to-register, a few cycles
+// each -- __shfl_xor goes through the LDS crossbar, ~100 cycles a step), then the four row sums are
+// read out as scalars.  Fixed order: deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_mov_f64<0xB1>(v);      // lane ^ 1
+  v += dpp_mov_f64<0x4E>(v);      // lane ^ 2
+  v += dpp_mov_f64<0x141>(v);     // i <-> 7 - i   (the other quad of the 8)
+  v += dpp_mov_f64<0x140>(v);     // i <-> 15 - i  (the other half of the row)
+  double r[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int q = 0; q < 4; ++q)
+    r[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * q),
+                            __builtin_amdgcn_readlane(__double2loint(v), 16 * q));
+  return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 // Counter-based U[0,1) generator for the synthetic fills (splitmix64 finaliser).

@@ -341,6 +341,86 @@ __global__ __launch_bounds__(1024) void k_inverse_spd(const double* __restrict__
     }
 }
 
+// inv(G) by bordering, one lane per row (KP = 64 W rows, W = 1 or 2 waves): the inverse of the leading
+// j x j block is extended by variable j with ONE rank-one update,
+//   [A + u u'/s, -u/s; -u'/s, 1/s] = A + v v'/s,  u = A g_j, s = g_jj - g_j'u, v = (u; -1)
+// (row and column j of A are zero beforehand), the step k_nnqp uses for its passive set -- no
+// pivot-row/column special cases, loops bounded by j.  Per step a lane does ~2 j fmas on its own
+// registers; the only cross-lane traffic is one sum (s) and the broadcast of v through LDS.
+// Used for k <= 64 (one wave; ~60 us against 73 us for the 1024-thread Gauss-Jordan above -- each of the
+// k steps is a latency chain: broadcast reads, one wave sum, one division, one LDS round trip).  With
+// W = 2 the compiler keeps the 128-entry row in scratch, so k > 64 stays on k_inverse_spd.
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_inverse_spd_border(const double* __restrict__ Gd, int ld, int k,
+                                                               float* __restrict__ GinvT) {
+  constexpr int KP = 64 * W;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  double* sG = smd;                    // [KP][KP] the matrix, identity on the padding
+  double* vecV = sG + KP * KP;         // [2][KP]  v of the current step (double buffered)
+  double* red = vecV + 2 * KP;         // [2][W]   per-wave partial sums (double buffered)
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  for (int q = t; q < KP * KP; q += 64 * W) {
+    const int r = q / KP, c = q % KP;
+    sG[q] = (r < k && c < k) ? Gd[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  // two 64-entry halves: each stays small enough for the compiler to keep it in registers
+  double A0[64], A1[W > 1 ? 64 : 1];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) A0[c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < (W > 1 ? 64 : 1); ++c) A1[c] = 0.0;
+#define PMF_INV_A(c) ((c) < 64 ? A0[(c) & 63] : A1[((c) - 64) & (W > 1 ? 63 : 0)])
+  for (int j = 0; j < k; ++j) {                      // the padding is the identity already (written below)
+    const int buf = j & 1;
+    const double* g = sG + (size_t)j * KP;          // row j = column j (symmetric)
+    double u4[4] = {0.0, 0.0, 0.0, 0.0};            // 4 chains: a lone wave is fma-latency bound
+#pragma unroll
+    for (int cb = 0; cb < KP; cb += 8) {
+      if (cb >= j) break;                            // columns >= j of A are still zero
+#pragma unroll
+      for (int c = cb; c < cb + 8; c += 2) {
+        const d2 gg = *reinterpret_cast<const d2*>(g + c);
+        u4[(c >> 1) & 3] = fma(PMF_INV_A(c), gg.x, u4[(c >> 1) & 3]);
+        u4[(c >> 1) & 3] = fma(PMF_INV_A(c + 1), gg.y, u4[(c >> 1) & 3]);
+      }
+    }
+    const double u = (u4[0] + u4[1]) + (u4[2] + u4[3]);
+    double part = wave_sum_f64(g[t] * u);            // rows >= j have u = 0
+    if (W > 1) {
+      if (lane == 0) red[buf * W + wv] = part;
+      __syncthreads();
+      part = 0.0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) part += red[buf * W + w];
+    }
+    const double inv = 1.0 / (g[j] - part);
+    const double v = (t == j) ? -1.0 : u;
+    vecV[buf * KP + t] = v;
+    __syncthreads();
+    const double vi = v * inv;
+    const double* vv = vecV + buf * KP;
+#pragma unroll
+    for (int cb = 0; cb < KP; cb += 8) {
+      if (cb > j) break;
+#pragma unroll
+      for (int c = cb; c < cb + 8; c += 2) {
+        const d2 x = *reinterpret_cast<const d2*>(vv + c);
+        PMF_INV_A(c) = fma(vi, x.x, PMF_INV_A(c));
+        PMF_INV_A(c + 1) = fma(vi, x.y, PMF_INV_A(c + 1));
+      }
+    }
+  }
+  // GinvT[c][r] = inv[r][c] ([ld][ld], identity on the padding); lane t holds row t
+  if (t < ld) {
+#pragma unroll
+    for (int c = 0; c < KP; ++c)
+      if (c < ld) GinvT[(int64_t)c * ld + t] = (t < k && c < k) ? (float)PMF_INV_A(c) : (t == c ? 1.f : 0.f);
+  }
+#undef PMF_INV_A
+}
+
 // Per-block float64 partials of sum(X^2) over a padded [rows][ld] buffer (padding is zero).
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ X, int64_t count,
                                                double* __restrict__ part) {

@@ -1,5 +1,8 @@
-// diagnostic: per-section cycle shares of k_nmf_fused<4,4,0> (cfg4)
+// diagnostic: per-section cycle shares of k_nmf_fused<4,4,STAMP_MODE> (cfg4)
 #define PMF_STAMPS
+#ifndef STAMP_MODE
+#define STAMP_MODE 0
+#endif
 #define PMF_FUSED_KERNEL_ONLY
 #include "/root/repo/pymf_amd/csrc/pmf_fused.h"
 #include <vector>
@@ -15,11 +18,11 @@ int main(int argc, char** argv){
   fillk<<<(mp*NP+255)/256,256>>>(V,mp*NP,1); fillk<<<(mp*KP+255)/256,256>>>(W,mp*KP,2);
   fillk<<<(KP*NP+255)/256,256>>>(H,KP*NP,3); fillk<<<(KP*KP+255)/256,256>>>(G,KP*KP,4);
   size_t smem=fused_smem_bytes<4,4>();
-  CK(hipFuncSetAttribute((const void*)&k_nmf_fused<4,4,0>, hipFuncAttributeMaxDynamicSharedMemorySize,(int)smem));
+  CK(hipFuncSetAttribute((const void*)&k_nmf_fused<4,4,STAMP_MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,(int)smem));
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for(int it=0; it<5; ++it){
     hipEventRecord(e0);
-    k_nmf_fused<4,4,0><<<wgs,256,smem>>>(V,W,H,G,(int)(mp/16/(wgs*4)),(int)((mp/16)%(wgs*4)),0.f,slab,nullptr,dbg);
+    k_nmf_fused<4,4,STAMP_MODE><<<wgs,256,smem>>>(V,W,H,G,(int)(mp/16/(wgs*4)),(int)((mp/16)%(wgs*4)),0.f,slab,nullptr,dbg);
     hipEventRecord(e1); CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms,e0,e1);
     std::vector<unsigned long long> h(wgs*4*8); CK(hipMemcpy(h.data(),dbg,h.size()*8,hipMemcpyDeviceToHost));
