@@ -481,6 +481,31 @@ bool nmf_h_gram(pmf_ctx* c, int* rc) {
   return false;
 }
 
+template <int NT>
+int launch_snmf_h(pmf_ctx* c) {
+  constexpr size_t smem = snmf_h_smem_bytes<NT>();
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[pmf_current_device()];
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_h_mfma<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_snmf_h_mfma<NT>), dim3((unsigned)(c->np / 64)), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS, c->stop_arg);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int snmf_h_step(pmf_ctx* c) {   // snmf.py:72-91 on MFMA, one workgroup per 64-column panel
+  switch (c->NT) {
+    case 1: return launch_snmf_h<1>(c);
+    case 2: return launch_snmf_h<2>(c);
+    case 4: return launch_snmf_h<4>(c);
+    case 8: return launch_snmf_h<8>(c);
+  }
+  return fail(c, PMF_EINVAL, "bad NT");
+}
+
 // dPS holds (W^T V | W^T W) of the current W summed over ALL ranks (ps_valid).  It does not depend
 // on H, so repeated H steps with an unchanged W -- factorize(compute_w=False), the reference's
 // documented "coefficients for an existing basis" use (nmf.py:56-65) -- reuse it: after the first
@@ -498,8 +523,7 @@ int h_step_from_ps(pmf_ctx* c) {
   }
   const size_t smem = (size_t)c->KP * 16 * sizeof(float);
   if (c->algo == PMF_ALGO_SNMF)
-    hipLaunchKernelGGL(k_snmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
-                       (int64_t)c->np, c->np, c->KP, c->dPS);
+    PMFCHK(snmf_h_step(c));
   else
     hipLaunchKernelGGL(k_nmf_h, dim3((unsigned)(c->np / 16)), dim3(256), smem, c->stream, c->dH,
                        (int64_t)c->np, c->np, c->KP, c->dPS,
@@ -590,7 +614,7 @@ int snmf_fused_iteration(pmf_ctx* c) {
   PMFCHK(snmf_inverse(c));
   stat_begin(c);
   const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dH, c->dGinvT, c->mp,
-                               c->fused_wgs, 0.f, c->dSlab);
+                               c->fused_wgs, 0.f, c->dSlab, c->stop_arg);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -598,7 +622,7 @@ int snmf_fused_iteration(pmf_ctx* c) {
     const int NTP = c->np / 16;
     const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
     hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
-                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, (const int*)nullptr);
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, c->stop_arg);
     HIPCHK(c, hipGetLastError());
   }
   PMFCHK(allreduce_ps(c));
@@ -1111,18 +1135,27 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   // the convergence test of nmf.py:134-139 run on the device (k_conv_check) and a raised stop flag
   // turns every later launch of the chunk into a no-op, so the results are those of the ordinary
   // loop while the host reads back once per chunk instead of once per iteration.
-  const bool can_free_run = fused && ce && c->algo == PMF_ALGO_NMF;
+  const bool can_free_run = fused && ce;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
     if (free_run) {
       const int chunk = std::min(kChunk, niter - i);
       c->stop_arg = c->dStop;
+      const double lamb_w0 = c->lamb_w, lamb_h0 = c->lamb_h;   // BNMF: every H step scales them (bnmf.py:84-85)
       int lrc = PMF_OK;
       for (int j = 0; j < chunk && lrc == PMF_OK; ++j) {
-        lrc = nmf_fused_iteration(c);
+        lrc = c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c);
+        const double* tt = c->dScal + 2;                  // k_nmf_h_gram left <P,H>, <S,G> there
+        if (lrc == PMF_OK && !c->trace_ready) {           // SNMF: the H-step kernel does not form them
+          const int nb = c->np / 16;
+          hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
+                             c->dH, (int64_t)c->np, c->np, c->KP, c->dPS, c->dPart);
+          hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+          tt = c->dScal;
+        }
         if (lrc == PMF_OK) {
-          hipLaunchKernelGGL(k_conv_check, dim3(1), dim3(64), 0, c->stream, c->dScal + 2, c->vnorm2, conv_eps,
+          hipLaunchKernelGGL(k_conv_check, dim3(1), dim3(64), 0, c->stream, tt, c->vnorm2, conv_eps,
                              (double)c->n, i + j, c->dFerr, c->dStop);
           if (hipGetLastError() != hipSuccess) lrc = fail(c, PMF_EHIP, "k_conv_check launch failed");
         }
@@ -1142,6 +1175,11 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       // all-reduces still ran on the stale (P | S): it no longer belongs to W)
       const int s_it = hstop[1];
       done += s_it - i + 1;
+      if (c->algo == PMF_ALGO_BNMF) {                     // only s_it - i + 1 H steps really ran
+        c->lamb_w = lamb_w0; c->lamb_h = lamb_h0;
+        for (int q = 0; q < s_it - i + 1; ++q) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }
+      }
+      c->trace_ready = false;
       if (c->comm) { c->ps_valid = false; c->trace_ready = false; }
       if (hstop[0] == 1) {                                // nmf.py:198-202
         if (converged_at) *converged_at = s_it;

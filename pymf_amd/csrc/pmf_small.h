@@ -275,6 +275,80 @@ __global__ __launch_bounds__(256) void k_snmf_h(float* __restrict__ H, int64_t l
   }
 }
 
+// The same H step on MFMA, one workgroup per 64-column panel (columns are independent): wave w owns
+// tiles (mt, ct) = (q / 4, q % 4), q = w, w + 16, ...; S is split into its positive and negative
+// parts in registers as the A fragments are read, so pos(WW) H and neg(WW) H are two accumulator
+// chains over the same operands.  LDS layout and staging as in k_nmf_h_gram.
+template <int NT>
+constexpr size_t snmf_h_smem_bytes() { return (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * 68) * sizeof(float); }
+
+template <int NT>
+__global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int np,
+                                                      const float* __restrict__ PS,
+                                                      const int* __restrict__ stop) {
+  if (stop != nullptr && *stop != 0) return;
+  constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
+  constexpr int HT = NT * 4, HTW = (HT + 15) / 16;
+  const int64_t ldp = (int64_t)np + KP;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* ss = sm;                    // [KP][KP+4]   WW = W^T W
+  float* hs = ss + KP * LDS_S;       // [KP][68]     H panel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int c0 = 64 * blockIdx.x;
+  float pv[HTW][4];
+#pragma unroll
+  for (int h = 0; h < HTW; ++h) {
+    const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i] : 0.f;
+  }
+  for (int q = tid; q < KP * (KP / 4); q += 1024) {
+    const int r = q / (KP / 4), c4 = q % (KP / 4);
+    *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) =
+        *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
+  }
+  for (int q = tid; q < KP * 16; q += 1024) {
+    const int r = q >> 4, c4 = q & 15;
+    *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) =
+        *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < HTW; ++h) {
+    const int q = wv + 16 * h;
+    if (q >= HT) break;
+    const int mt = q >> 2, ct = q & 3;
+    f32x4 accp[2], accn[2];            // 2 chains each
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { accp[e] = f32x4{0.f, 0.f, 0.f, 0.f}; accn[e] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ww = a4[e];                                  // WW[kk][j] = WW[j][kk]
+        const float wp = (fabsf(ww) + ww) * 0.5f;                // snmf.py:73-74
+        const float wn = (fabsf(ww) - ww) * 0.5f;                // snmf.py:76-77
+        const float hj = hs[(16 * t + 4 * kq + e) * LDS_H + 16 * ct + i];
+        accp[e & 1] = mfma16(wp, hj, accp[e & 1]);
+        accn[e & 1] = mfma16(wn, hj, accn[e & 1]);
+      }
+    }
+    const f32x4 a2 = accp[0] + accp[1], a1 = accn[0] + accn[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = 16 * mt + 4 * kq + r, col = 16 * ct + i;
+      const float xw = pv[h][r];
+      const float h1 = (fabsf(xw) + xw) * 0.5f + a1[r];
+      const float h2 = (fabsf(xw) - xw) * 0.5f + a2[r] + PMF_EPS_DEN;
+      H[(int64_t)kk * np + c0 + col] = hs[kk * LDS_H + col] * sqrtf(h1 / h2);
+    }
+  }
+}
+
 // inv(G) for the Gram matrix G = H H^T (symmetric positive definite when H has full row rank, which
 // snmf.py:69-70 needs anyway): in-place float64 Gauss-Jordan WITHOUT pivoting -- on an SPD matrix
 // every pivot is a positive Schur complement and the elimination is as stable as Cholesky.

@@ -460,24 +460,33 @@ def test_single_element_edit_is_noticed(pm):
     assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
 
 
-def test_free_running_loop_matches_stepwise_loop(pm):
+@pytest.mark.parametrize("algo_name", ["NMF", "SNMF", "BNMF"])
+def test_free_running_loop_matches_stepwise_loop(pm, algo_name):
     """pmf_factorize enqueues chunks of iterations with the error and the convergence test of
     nmf.py:134-139 on the device; the outcome must be the one of the iteration-by-iteration loop
-    (hooks + host-side test), including WHERE a convergence stops it."""
+    (hooks + host-side test), including WHERE a convergence stops it (and, for BNMF, the penalty
+    weights the reference's schedule has reached by then)."""
     from pymf_amd import _lib
+    algo = getattr(_lib, "ALGO_" + algo_name)
     rs = np.random.RandomState(77)
     m, n, k = 4096, 128, 16
     V = rs.random_sample((m, n)).astype(np.float32)
+    if algo_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
     W0 = rs.random_sample((m, k)).astype(np.float32)
     H0 = rs.random_sample((k, n)).astype(np.float32)
     for niter, eps in ((37, 1e-8), (60, 2e-5), (200, 1e-6)):
-        a = _lib.Context(_lib.ALGO_NMF, m, n, k)
+        a = _lib.Context(algo, m, n, k)
         a.set_v_dense(V); a.set_w(W0); a.set_h(H0)
+        if algo_name == "BNMF":
+            a.set_lambda(1.0 / niter, 1.0 / niter)
         fa, done_a, conv_a = a.factorize(niter, conv_eps=eps)
-        b = _lib.Context(_lib.ALGO_NMF, m, n, k)
+        b = _lib.Context(algo, m, n, k)
         b.set_v_dense(V); b.set_w(W0); b.set_h(H0)
+        if algo_name == "BNMF":
+            b.set_lambda(1.0 / niter, 1.0 / niter)
         fb, done_b, conv_b = [], 0, -1
-        for i in range(niter):                           # the reference loop, one C call per hook
+        for i in range(niter):                           # the reference loop, one C call per iteration
             f1, _, _ = b.factorize(1, conv_eps=0.0)
             fb.append(f1[0]); done_b += 1
             if i > 1 and abs(fb[i] - fb[i - 1]) / n < eps:
@@ -487,4 +496,6 @@ def test_free_running_loop_matches_stepwise_loop(pm):
         np.testing.assert_allclose(fa[:done_a], fb, rtol=1e-12)
         np.testing.assert_array_equal(a.get_w(), b.get_w())
         np.testing.assert_array_equal(a.get_h(), b.get_h())
+        if algo_name == "BNMF":
+            assert a.get_lambda() == b.get_lambda()
         a.close(); b.close()
