@@ -589,12 +589,10 @@ int nmf_fused_iteration(pmf_ctx* c) {
 // ---- SNMF -----------------------------------------------------------------------------------
 int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan in registers), identity on the padding
   PMFCHK(ensure_gram(c, 1.0));
-  if (c->KP <= 64) {   // one lane per row, bordering (pmf_small.h)
-    const size_t smem = ((size_t)64 * 64 + 2 * 64 + 4) * sizeof(double);
-    hipLaunchKernelGGL((k_inverse_spd_border<1>), dim3(1), dim3(64), smem, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
-  } else {
-    hipLaunchKernelGGL(k_inverse_spd, dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
-  }
+  if (c->KP <= 64)
+    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
+  else
+    hipLaunchKernelGGL((k_inverse_spd<8>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }

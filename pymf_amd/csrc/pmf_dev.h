@@ -58,6 +58,16 @@ __device__ __forceinline__ void lds_write4(float* base, int row, int chunk, f32x
   *reinterpret_cast<f32x4*>(base + swz_off(row, chunk)) = v;
 }
 
+// 1 / d in float64 without the IEEE division sequence: v_rcp_f64 (about 26 good bits) and two Newton
+// steps; the result is within an ulp or two of the correctly rounded quotient.  For reciprocals on a
+// serial critical path (pivots).
+__device__ __forceinline__ double pmf_rcp_f64(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = fma(fma(-d, x, 1.0), x, x);
+  x = fma(fma(-d, x, 1.0), x, x);
+  return x;
+}
+
 // Sum over the 64 lanes, returned in every lane.  Butterfly inside each row of 16 lanes on DPP
 // (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: register-to-register, a few cycles
 // each -- __shfl_xor goes through the LDS crossbar, ~100 cycles a step), then the four row sums are

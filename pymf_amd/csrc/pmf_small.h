@@ -352,147 +352,69 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
 // inv(G) for the Gram matrix G = H H^T (symmetric positive definite when H has full row rank, which
 // snmf.py:69-70 needs anyway): in-place float64 Gauss-Jordan WITHOUT pivoting -- on an SPD matrix
 // every pivot is a positive Schur complement and the elimination is as stable as Cholesky.
-// The 128 x 128 (identity-padded) matrix lives in REGISTERS: thread (ty, tx) of 32 x 32 owns rows
-// {ty + 32u} x columns {tx + 32v}, u, v < 4.  Per pivot only the pivot row and column go through
-// LDS (double buffered => ONE barrier per pivot).  Writes float32 inv(G)^T into GinvT[KP][KP]
-// (identity on the padding) so that a B[n][k] MFMA operand reads inv[k][n].
-__global__ __launch_bounds__(1024) void k_inverse_spd(const double* __restrict__ Gd, int KP, int k,
-                                                      float* __restrict__ GinvT) {
-  __shared__ double prow[2][128];
-  __shared__ double pcol[2][128];
-  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  double a[4][4];
+// The 16 B x 16 B (identity-padded) matrix lives in REGISTERS of 256 threads (one wave per SIMD):
+// thread (ty, tx) of 16 x 16 owns rows {ty + 16 u} x columns {tx + 16 v}, u, v < B.  Per pivot only
+// the pivot row and column go through LDS (double buffered => ONE barrier per pivot), and the step is
+// ONE rank-one update for every entry: with the pivot column's entry p replaced by a_pp - 1 and the
+// scaled pivot row's entry p by 1 + 1/a_pp,
+//   a_rc - pc[r] pr[c]  gives  a_pc / a_pp (row p),  -a_rp / a_pp (column p),  1 / a_pp (corner)
+// and the ordinary Schur update elsewhere.  Pivots are taken in the order p = pl + 16 pu (pu outer,
+// unrolled), any order being as good as another for an SPD matrix, so "which of my B rows is the
+// pivot row" is a compile-time fact.  Writes float32 inv(G)^T into GinvT[ld][ld] (identity on the
+// padding) so that a B[n][k] MFMA operand reads inv[k][n].
+// 128 x 128: 153 us as 1024 threads x 16 entries with per-entry case selects -> see DESIGN 3.3.
+template <int B>
+__global__ __launch_bounds__(256) void k_inverse_spd(const double* __restrict__ Gd, int ld, int k,
+                                                     float* __restrict__ GinvT) {
+  constexpr int KP = 16 * B;
+  __shared__ double prow[2][KP];
+  __shared__ double pcol[2][KP];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  double a[B][B];
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < B; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = ty + 32 * u, c = tx + 32 * v;
-      a[u][v] = (r < k && c < k) ? Gd[(int64_t)r * KP + c] : (r == c ? 1.0 : 0.0);
+    for (int v = 0; v < B; ++v) {
+      const int r = ty + 16 * u, c = tx + 16 * v;
+      a[u][v] = (r < k && c < k) ? Gd[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
     }
-  for (int p = 0; p < k; ++p) {
-    const int buf = p & 1, pu = p >> 5, pl = p & 31;
-    if (ty == pl) {                                   // owners of row p
+  int step = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (u == pu) {
+  for (int pu = 0; pu < B; ++pu) {
+    for (int pl = 0; pl < 16; ++pl) {
+      const int p = pl + 16 * pu;
+      if (p >= k) break;                                // identity padding: nothing to eliminate
+      const int buf = step & 1;
+      ++step;
+      if (ty == pl) {                                   // owners of row p
 #pragma unroll
-          for (int v = 0; v < 4; ++v) prow[buf][tx + 32 * v] = a[u][v];
-        }
-    }
-    if (tx == pl) {                                   // owners of column p
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (v == pu) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) pcol[buf][ty + 32 * u] = a[u][v];
-        }
-    }
-    __syncthreads();
-    const double d = 1.0 / prow[buf][p];
-    double pr[4], pc[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) pr[v] = prow[buf][tx + 32 * v] * d;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) pc[u] = pcol[buf][ty + 32 * u];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = ty + 32 * u, c = tx + 32 * v;
-        double x;
-        if (r == p) x = (c == p) ? d : pr[v];
-        else if (c == p) x = -pc[u] * d;
-        else x = fma(-pc[u], pr[v], a[u][v]);
-        a[u][v] = x;
+        for (int v = 0; v < B; ++v) prow[buf][tx + 16 * v] = a[pu][v];
       }
-  }
+      if (tx == pl) {                                   // owners of column p
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = ty + 32 * u, c = tx + 32 * v;     // GinvT[c][r] = inv[r][c]
-      if (r < KP && c < KP) GinvT[c * KP + r] = (r < k && c < k) ? (float)a[u][v] : (r == c ? 1.f : 0.f);
-    }
-}
-
-// inv(G) by bordering, one lane per row (KP = 64 W rows, W = 1 or 2 waves): the inverse of the leading
-// j x j block is extended by variable j with ONE rank-one update,
-//   [A + u u'/s, -u/s; -u'/s, 1/s] = A + v v'/s,  u = A g_j, s = g_jj - g_j'u, v = (u; -1)
-// (row and column j of A are zero beforehand), the step k_nnqp uses for its passive set -- no
-// pivot-row/column special cases, loops bounded by j.  Per step a lane does ~2 j fmas on its own
-// registers; the only cross-lane traffic is one sum (s) and the broadcast of v through LDS.
-// Used for k <= 64 (one wave; ~60 us against 73 us for the 1024-thread Gauss-Jordan above -- each of the
-// k steps is a latency chain: broadcast reads, one wave sum, one division, one LDS round trip).  With
-// W = 2 the compiler keeps the 128-entry row in scratch, so k > 64 stays on k_inverse_spd.
-template <int W>
-__global__ __launch_bounds__(64 * W) void k_inverse_spd_border(const double* __restrict__ Gd, int ld, int k,
-                                                               float* __restrict__ GinvT) {
-  constexpr int KP = 64 * W;
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) double smd[];
-  double* sG = smd;                    // [KP][KP] the matrix, identity on the padding
-  double* vecV = sG + KP * KP;         // [2][KP]  v of the current step (double buffered)
-  double* red = vecV + 2 * KP;         // [2][W]   per-wave partial sums (double buffered)
-  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-  for (int q = t; q < KP * KP; q += 64 * W) {
-    const int r = q / KP, c = q % KP;
-    sG[q] = (r < k && c < k) ? Gd[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  // two 64-entry halves: each stays small enough for the compiler to keep it in registers
-  double A0[64], A1[W > 1 ? 64 : 1];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) A0[c] = 0.0;
-#pragma unroll
-  for (int c = 0; c < (W > 1 ? 64 : 1); ++c) A1[c] = 0.0;
-#define PMF_INV_A(c) ((c) < 64 ? A0[(c) & 63] : A1[((c) - 64) & (W > 1 ? 63 : 0)])
-  for (int j = 0; j < k; ++j) {                      // the padding is the identity already (written below)
-    const int buf = j & 1;
-    const double* g = sG + (size_t)j * KP;          // row j = column j (symmetric)
-    double u4[4] = {0.0, 0.0, 0.0, 0.0};            // 4 chains: a lone wave is fma-latency bound
-#pragma unroll
-    for (int cb = 0; cb < KP; cb += 8) {
-      if (cb >= j) break;                            // columns >= j of A are still zero
-#pragma unroll
-      for (int c = cb; c < cb + 8; c += 2) {
-        const d2 gg = *reinterpret_cast<const d2*>(g + c);
-        u4[(c >> 1) & 3] = fma(PMF_INV_A(c), gg.x, u4[(c >> 1) & 3]);
-        u4[(c >> 1) & 3] = fma(PMF_INV_A(c + 1), gg.y, u4[(c >> 1) & 3]);
+        for (int u = 0; u < B; ++u) pcol[buf][ty + 16 * u] = a[u][pu];
       }
-    }
-    const double u = (u4[0] + u4[1]) + (u4[2] + u4[3]);
-    double part = wave_sum_f64(g[t] * u);            // rows >= j have u = 0
-    if (W > 1) {
-      if (lane == 0) red[buf * W + wv] = part;
       __syncthreads();
-      part = 0.0;
+      const double app = prow[buf][p];
+      const double d = pmf_rcp_f64(app);
+      double pr[B], pc[B];
 #pragma unroll
-      for (int w = 0; w < W; ++w) part += red[buf * W + w];
-    }
-    const double inv = 1.0 / (g[j] - part);
-    const double v = (t == j) ? -1.0 : u;
-    vecV[buf * KP + t] = v;
-    __syncthreads();
-    const double vi = v * inv;
-    const double* vv = vecV + buf * KP;
+      for (int v = 0; v < B; ++v) pr[v] = (tx + 16 * v == p) ? 1.0 + d : prow[buf][tx + 16 * v] * d;
 #pragma unroll
-    for (int cb = 0; cb < KP; cb += 8) {
-      if (cb > j) break;
+      for (int u = 0; u < B; ++u) pc[u] = (ty + 16 * u == p) ? app - 1.0 : pcol[buf][ty + 16 * u];
 #pragma unroll
-      for (int c = cb; c < cb + 8; c += 2) {
-        const d2 x = *reinterpret_cast<const d2*>(vv + c);
-        PMF_INV_A(c) = fma(vi, x.x, PMF_INV_A(c));
-        PMF_INV_A(c + 1) = fma(vi, x.y, PMF_INV_A(c + 1));
-      }
+      for (int u = 0; u < B; ++u)
+#pragma unroll
+        for (int v = 0; v < B; ++v) a[u][v] = fma(-pc[u], pr[v], a[u][v]);
     }
   }
-  // GinvT[c][r] = inv[r][c] ([ld][ld], identity on the padding); lane t holds row t
-  if (t < ld) {
 #pragma unroll
-    for (int c = 0; c < KP; ++c)
-      if (c < ld) GinvT[(int64_t)c * ld + t] = (t < k && c < k) ? (float)PMF_INV_A(c) : (t == c ? 1.f : 0.f);
-  }
-#undef PMF_INV_A
+  for (int u = 0; u < B; ++u)
+#pragma unroll
+    for (int v = 0; v < B; ++v) {
+      const int r = ty + 16 * u, c = tx + 16 * v;     // GinvT[c][r] = inv[r][c]
+      if (r < ld && c < ld) GinvT[(int64_t)c * ld + r] = (r < k && c < k) ? (float)a[u][v] : (r == c ? 1.f : 0.f);
+    }
 }
 
 // Per-block float64 partials of sum(X^2) over a padded [rows][ld] buffer (padding is zero).
