@@ -333,6 +333,67 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     // ------- epilogue W_b <- (W_b * Num) / (Den + eps), interleaved with S += of the previous block -------
     f32x4 wn[NT];
     float* wdst = W + (size_t)blk * (16 * KP) + (4 * kq) * KP + i;
+    if (MODE == FUSED_NMF) {
+      // The division of the 4 NT elements in STAGES (all numerators, all reciprocals, all quotients,
+      // all residuals, all corrections): a wave issues in order, so an element-by-element chain of
+      // dependent VALU ops also holds up the S MFMAs queued behind it; stage by stage every
+      // instruction has 4 NT - 1 independent ones between itself and its consumer.
+      float tnum[NT][4], dd[NT][4], rr[NT][4], qq[NT][4];
+      constexpr int NSM = 4 * (NT * (NT + 1) / 2);           // S MFMAs of the previous block
+      auto s_mfmas = [&](int lo, int hi) {                   // ... numbers lo .. hi-1 of them
+        if (SPLIT == 1 || half == 0) {
+          int q = 0;                                         // j outermost: consecutive MFMAs hit different tiles
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int mt = 0; mt <= nt; ++mt) {
+                if (q >= lo && q < hi) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
+                ++q;
+              }
+        }
+      };
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tnum[nt][j] = wold[nt][j] * num[nt][j];                // nmf.py:131 (multiply first)
+          dd[nt][j] = den[nt][j] + PMF_EPS_DEN;
+        }
+      s_mfmas(0, NSM / 5);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[nt][j] = __builtin_amdgcn_rcpf(dd[nt][j]);
+      s_mfmas(NSM / 5, 2 * NSM / 5);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qq[nt][j] = tnum[nt][j] * rr[nt][j];
+      s_mfmas(2 * NSM / 5, 3 * NSM / 5);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tnum[nt][j] = fmaf(-dd[nt][j], qq[nt][j], tnum[nt][j]);   // residual
+      s_mfmas(3 * NSM / 5, 4 * NSM / 5);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float w = fmaf(tnum[nt][j], rr[nt][j], qq[nt][j]);   // pmf_div, nmf.py:132
+          wn[nt][j] = w;
+#ifndef PMF_ABLATE_WSTORE
+          if (SPLIT == 1 || half == 0) wdst[j * KP + 16 * nt] = w;
+#endif
+        }
+      s_mfmas(4 * NSM / 5, NSM);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -340,13 +401,11 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         float w;
         if (MODE == FUSED_SNMF) {
           w = den[nt][j];                                    // W = (V H^T) inv(H H^T), snmf.py:70
-        } else if (MODE == FUSED_BNMF) {                     // bnmf.py:87-90, W *= W1 / W2
+        } else {                                             // bnmf.py:87-90, W *= W1 / W2
           const float w0 = wold[nt][j];
           const float w1 = num[nt][j] + (3.0f * lamb) * (w0 * w0);
           const float w2 = ((den[nt][j] + (2.0f * lamb) * (w0 * w0 * w0)) + lamb * w0) + PMF_EPS_DEN;
           w = w0 * pmf_div(w1, w2);
-        } else {
-          w = pmf_div(wold[nt][j] * num[nt][j], den[nt][j] + PMF_EPS_DEN);   // nmf.py:131-132
         }
         wn[nt][j] = w;
         if (SPLIT == 1 || half == 0) {                       // one partner stores W and forms S
@@ -355,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
         }
       }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wp[nt] = wn[nt];
 
