@@ -8,14 +8,14 @@ import collections, csv, glob, json, os, shutil, sys
 tag, statdir, benchlog = sys.argv[1:4]
 pmc_tags = sys.argv[4:]
 os.makedirs("profiles", exist_ok=True)
-ks = glob.glob(os.path.join(statdir, "**", "*kernel_stats.csv"), recursive=True)[0]
+ks = max(glob.glob(os.path.join(statdir, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest run
 shutil.copy(ks, "profiles/%s_bench_kernel_stats.csv" % tag)
 for line in open(benchlog):
     if line.startswith('{"metric"'):
         open("profiles/%s_bench_under_rocprof.json" % tag, "w").write(line)
 rows = {}
 for t in pmc_tags:
-    f = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % t, recursive=True)[0]
+    f = max(glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % t, recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
