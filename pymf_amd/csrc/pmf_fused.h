@@ -173,19 +173,25 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 
   // ---- H and G into LDS by LDS-DMA as well (whole workgroup, once): 4 rows x 256 B per
   // instruction, all in flight together with the first block's V/W tiles ----
+  // The MFMA N index of a lane is free: column i of tile nt of Num / Den (and of the new W) is
+  // basis NT i + nt, i.e. the NT tiles of a lane hold NT CONSECUTIVE bases, so the old W rows are
+  // fetched and the new ones stored NT floats at a time (16-byte accesses at k = 64).  All it takes
+  // is to put the rows of H and G into the LDS images in that order; k_reduce_slabs_tiles knows it.
   {
     const int drow = lane >> 4, dchunk = lane & 15;
     for (int d = wv; d < NPT * (KP / 4); d += 4) {             // H: panel p, rows 4rg..4rg+3
       const int p = d / (KP / 4), rg = d % (KP / 4);
-      const int row = 4 * rg + drow;
-      const float* src = H + (size_t)row * NP + 64 * p + 4 * (dchunk ^ (row & 15));
+      const int row = 4 * rg + drow;                           // LDS row 16 nt + i ...
+      const int bas = NT * (row & 15) + (row >> 4);            // ... holds basis NT i + nt (see below)
+      const float* src = H + (size_t)bas * NP + 64 * p + 4 * (dchunk ^ (row & 15));
       PMF_GLDS16(src, sH + p * (KP * 64) + rg * 256);
     }
     for (int rg = wv; rg < KP / 4; rg += 4) {                  // G: rows 4rg..4rg+3
       const int row = 4 * rg + drow;
+      const int bas = NT * (row & 15) + (row >> 4);
       int c = dchunk ^ (row & 15);
       if (4 * c >= KP) c = 0;                                  // beyond k: valid, never read
-      PMF_GLDS16(G + row * KP + 4 * c, sG + rg * 256);
+      PMF_GLDS16(G + bas * KP + 4 * c, sG + rg * 256);
     }
   }
   wait_vmcnt<0>();
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int row = 4 * kq + j, col = 16 * nt + i;
+            const int row = 4 * kq + j, col = NT * i + nt;
             sW[swz_off(row, col >> 2) + (col & 3)] = num[nt][j];
           }
         load_step(NSN, NSN & 1);
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int row = 4 * kq + j, col = 16 * nt + i;
+          const int row = 4 * kq + j, col = NT * i + nt;       // NT consecutive floats per (lane, j)
           wold[nt][j] = sW[swz_off(row, col >> 2) + (col & 3)];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 
     // ------- epilogue W_b <- (W_b * Num) / (Den + eps), interleaved with S += of the previous block -------
     f32x4 wn[NT];
-    float* wdst = W + (size_t)blk * (16 * KP) + (4 * kq) * KP + i;
+    float* wdst = W + (size_t)blk * (16 * KP) + (4 * kq) * KP + NT * i;
     if (MODE == FUSED_NMF) {
       // The division of the 4 NT elements in STAGES (all numerators, all reciprocals, all quotients,
       // all residuals, all corrections): a wave issues in order, so an element-by-element chain of
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           const float w = fmaf(tnum[nt][j], rr[nt][j], qq[nt][j]);   // pmf_div, nmf.py:132
           wn[nt][j] = w;
 #ifndef PMF_ABLATE_WSTORE
-          if (SPLIT == 1 || half == 0) wdst[j * KP + 16 * nt] = w;
+          if (SPLIT == 1 || half == 0) wdst[j * KP + nt] = w;
 #endif
         }
       s_mfmas(4 * NSM / 5, NSM);
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         }
         wn[nt][j] = w;
         if (SPLIT == 1 || half == 0) {                       // one partner stores W and forms S
-          wdst[j * KP + 16 * nt] = w;
+          wdst[j * KP + nt] = w;
 #pragma unroll
           for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
         }

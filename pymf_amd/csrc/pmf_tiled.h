@@ -314,14 +314,15 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __rest
     const int i = lane & 15, kq = lane >> 4, r = wv;
     const int64_t ldp = (int64_t)np + KP;
     if (tile < NT * NTP) {
-      // P tile (mt, nt = 4p + e) of the fused kernel holds columns {64p + 4c + e} (lane c)
+      // P tile (mt, nt = 4p + e) of the fused kernel holds columns {64p + 4c + e} (lane c) and, in
+      // tile row m, basis NT m + mt (the NT tiles of a lane are NT consecutive bases)
       const int mt = tile / NTP, nt = tile % NTP;
-      out[(int64_t)(16 * mt + 4 * kq + r) * ldp + 64 * (nt >> 2) + 4 * i + (nt & 3)] = v;
+      out[(int64_t)(NT * (4 * kq + r) + mt) * ldp + 64 * (nt >> 2) + 4 * i + (nt & 3)] = v;
     } else {
       int sidx = tile - NT * NTP, mt = 0;
       while (sidx >= NT - mt) { sidx -= NT - mt; ++mt; }
       const int nt = mt + sidx;
-      const int row = 16 * mt + 4 * kq + r, col = 16 * nt + i;
+      const int row = NT * (4 * kq + r) + mt, col = NT * i + nt;
       out[(int64_t)row * ldp + np + col] = v;
       if (nt > mt) out[(int64_t)col * ldp + np + row] = v;
     }
