@@ -569,8 +569,11 @@ int nmf_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
   PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
-  const int lrc = launch_fused(c->stream, c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT, c->np, c->dV,
-                               c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab, c->stop_arg);
+  const bool rn = c->algo == PMF_ALGO_RNMF;     // rnmf.py:100-115: both contractions run on D = S - data
+  if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+  const int lrc = launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
+                               c->np, rn ? c->dD : c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w,
+                               c->dSlab, c->stop_arg);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -583,7 +586,12 @@ int nmf_fused_iteration(pmf_ctx* c) {
   }
   PMFCHK(allreduce_ps(c));
   c->ps_valid = true;
-  return h_step_from_ps(c);
+  PMFCHK(h_step_from_ps(c));
+  if (rn) {                                     // rnmf.py:107: update_h ends with update_s
+    c->ps_valid = false;                        // (P | S) were built from D, not from V
+    return rnmf_update_s(c);
+  }
+  return PMF_OK;
 }
 
 // ---- SNMF -----------------------------------------------------------------------------------
@@ -944,7 +952,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->nchunks = (int)std::min<int64_t>(want, blocks16);
     c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
-    c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF)
+    c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF)
                        ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     // dV [mp][np] is allocated by the first pmf_set_v_dense_f32 / pmf_fill_v_uniform: CSR and
@@ -976,8 +984,10 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     pmf_ctx_destroy(c);
     return rc;
   }
-  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF ? FUSED_SNMF
-                                                                           : algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF))
+  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF   ? FUSED_SNMF
+                                                                           : algo == PMF_ALGO_BNMF ? FUSED_BNMF
+                                                                           : algo == PMF_ALGO_RNMF ? FUSED_RNMF
+                                                                                                   : FUSED_NMF))
                                : std::string("tiled");
   set_stat_model(c);
   *out = c;
@@ -1125,7 +1135,8 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   c->want_trace = ce;
   c->fixed_h_loop = cw && !ch && niter > 1 && c->algo == PMF_ALGO_NMF;
   const bool fused = cw && ch && c->fused_wgs > 0 && !c->v_csr &&
-                     (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF);
+                     (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF ||
+                      c->algo == PMF_ALGO_RNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   int done = 0;
   // Free-running form of the loop (NMF on the fused kernel with the error on): after one
@@ -1133,7 +1144,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   // the convergence test of nmf.py:134-139 run on the device (k_conv_check) and a raised stop flag
   // turns every later launch of the chunk into a no-op, so the results are those of the ordinary
   // loop while the host reads back once per chunk instead of once per iteration.
-  const bool can_free_run = fused && ce;   // NMF, BNMF, SNMF on the fused kernel
+  const bool can_free_run = fused && ce && c->algo != PMF_ALGO_RNMF;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182

@@ -75,7 +75,7 @@ __device__ __forceinline__ f32x4 vtile_read4(const float* base, int row, int chu
 
 // blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
-enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2 };
+enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2, FUSED_RNMF = 3 };   // RNMF: V is D = S - data
 
 template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
@@ -407,6 +407,9 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         float w;
         if (MODE == FUSED_SNMF) {
           w = den[nt][j];                                    // W = (V H^T) inv(H H^T), snmf.py:70
+        } else if (MODE == FUSED_RNMF) {                     // rnmf.py:109-115 on D = S - data, no epsilon
+          const float x = num[nt][j], d2 = 2.0f * den[nt][j];
+          w = d2 != 0.f ? wold[nt][j] * ((fabsf(x) - x) / d2) : 0.f;   // 0/0 on the zero padding
         } else {                                             // bnmf.py:87-90, W *= W1 / W2
           const float w0 = wold[nt][j];
           const float w1 = num[nt][j] + (3.0f * lamb) * (w0 * w0);
@@ -577,7 +580,7 @@ static inline int fused_grid_for(int NT, int np, int64_t mp, bool allow_split = 
 static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF) {
   static char buf[64];
   snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d%s>", NT, np / 64,
-           mode == FUSED_SNMF ? ",snmf" : mode == FUSED_BNMF ? ",bnmf" : "");
+           mode == FUSED_SNMF ? ",snmf" : mode == FUSED_BNMF ? ",bnmf" : mode == FUSED_RNMF ? ",rnmf" : "");
   return buf;
 }
 
@@ -608,8 +611,9 @@ static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const fl
     const int skey = NT * 10 + np / 128;
 #define PMF_FUSED_SPLIT_CASE(K, A, B)                                                                   \
   case K:                                                                                               \
-    return mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
-                              : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
+    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
+                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
     switch (skey) {
       PMF_FUSED_SPLIT_CASE(14, 1, 4)
       PMF_FUSED_SPLIT_CASE(23, 2, 3)
@@ -623,6 +627,7 @@ static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const fl
   case K:                                                                                        \
     return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
            : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
                                 : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
