@@ -462,7 +462,7 @@ int launch_h_gram(pmf_ctx* c) {
   }
   const int wgs = std::min(c->np / 64, PMF_HGRAM_MAX_WGS);
   hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
-                     c->dG, c->dGd, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
+                     c->dG, (double*)nullptr /* no reader of the float64 copy on the NMF/BNMF paths */, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
                      c->dGpart, c->dT1part, c->dTicket, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;

@@ -1,32 +1,55 @@
-"""Randomised odd-input sweep of pymf_amd.NMF against the oracle (dtype, layout, m/n/k of 1, k > n ...).
-ferr is compared relative to ||V||: an (almost) exact fit leaves a float32-sized residual floor."""
-import sys, numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+#!/usr/bin/env python3
+"""Randomised odd-input sweep of the pymf_amd classes against the oracle (dtype, layout, m/n/k of 1,
+k > n, every fused / split / tiled shape class).  ferr is compared relative to ||V||: an (almost)
+exact fit leaves a float32-sized residual floor."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import pymf_amd
-from oracle import NMFOracle, SNMFOracle
 from pymf_amd.rnmf import RNMF
-rs = np.random.RandomState(0)
-def rel(a,b): return np.linalg.norm(a-b)/max(np.linalg.norm(b),1e-30)
+from oracle import NMFOracle, SNMFOracle, BNMFOracle, RNMFOracle
+
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ntrial = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
 bad = 0
-cases = []
-for trial in range(40):
-    m = int(rs.choice([1,2,3,17,64,65,200,1000])); n = int(rs.choice([1,2,5,63,64,65,130,257,400,700]))
-    k = int(rs.choice([1,2,3,16,17,33,64,65,100,128]))
-    kind = rs.choice(["f32","f64","fortran","slice","int"])
-    V = rs.random_sample((m,n))
-    if kind=="f32": V=V.astype(np.float32)
-    elif kind=="fortran": V=np.asfortranarray(V.astype(np.float32))
-    elif kind=="slice": V=np.ascontiguousarray(rs.random_sample((2*m,2*n)).astype(np.float32))[::2, ::2]
-    elif kind=="int": V=(V*10).astype(np.int64)
-    W0=rs.random_sample((m,k)); H0=rs.random_sample((k,n))
-    for cls,orc in ((pymf_amd.NMF,NMFOracle),):
-        try:
-            a=cls(V,num_bases=k); a.W,a.H=W0.copy(),H0.copy(); a.factorize(niter=3)
-            o=orc(np.asarray(V,dtype=np.float64) if kind=="int" else V,num_bases=k); o.W,o.H=W0.copy(),H0.copy(); o.factorize(niter=3)
-            e=max(rel(a.W,o.W),rel(a.H,o.H)); fe=abs(a.ferr[-1]-o.ferr[-1])/max(np.linalg.norm(np.asarray(V,dtype=np.float64)),1e-12)   # float32 floor: relative to ||V||
-            flag = "" if (e<2e-5 and fe<2e-6) else "  <<<<<"
-            if flag: bad+=1
-            print(m,n,k,kind,cls.__name__,"relWH %.2e ferr %.2e"%(e,fe),flag)
-        except Exception as ex:
-            bad+=1; print(m,n,k,kind,cls.__name__,"EXC",type(ex).__name__,str(ex)[:100])
-print("bad",bad)
+for trial in range(ntrial):
+    m = int(rs.choice([1, 2, 3, 17, 64, 65, 200, 1000, 5000]))
+    n = int(rs.choice([1, 2, 5, 63, 64, 65, 130, 190, 257, 320, 384, 400, 450, 512, 600]))
+    k = int(rs.choice([1, 2, 3, 16, 17, 32, 33, 64, 65, 100, 128]))
+    kind = rs.choice(["f32", "f64", "fortran", "slice", "int"])
+    name = rs.choice(["NMF", "NMF", "SNMF", "BNMF", "RNMF"])
+    V = rs.random_sample((m, n))
+    if name == "BNMF":
+        V = (V < 0.3).astype(np.float64)
+    if name == "SNMF" and 2 * k > min(m, n):
+        name = "NMF"                      # H H^T singular: inv() is noise in the reference as well
+    if kind == "f32": V = V.astype(np.float32)
+    elif kind == "fortran": V = np.asfortranarray(V.astype(np.float32))
+    elif kind == "slice": V = np.ascontiguousarray(np.tile(V, (2, 2)).astype(np.float32))[::2, ::2]
+    elif kind == "int": V = (V * 10).astype(np.int64)
+    Vo = np.asarray(V, dtype=np.float64) if kind == "int" else V
+    W0 = rs.random_sample((m, k)); H0 = rs.random_sample((k, n))
+    try:
+        if name == "RNMF":
+            np.random.seed(trial); a = RNMF(V, num_bases=k, lamb=0.7); a.factorize(niter=3)
+            np.random.seed(trial); o = RNMFOracle(Vo, num_bases=k, lamb=0.7); o.factorize(niter=3)
+            tolw, tolf = 5e-3, 5e-4          # the soft threshold is discontinuous at float32 rounding
+        else:
+            cls = getattr(pymf_amd, name); orc = {"NMF": NMFOracle, "SNMF": SNMFOracle, "BNMF": BNMFOracle}[name]
+            a = cls(V, num_bases=k); a.W, a.H = W0.copy(), H0.copy(); a.factorize(niter=3)
+            o = orc(Vo, num_bases=k); o.W, o.H = W0.copy(), H0.copy(); o.factorize(niter=3)
+            tolw, tolf = (2e-5, 2e-6) if name != "SNMF" else (2e-3, 2e-5)
+        e = max(rel(a.W, o.W), rel(a.H, o.H))
+        fe = abs(a.ferr[-1] - o.ferr[-1]) / max(np.linalg.norm(np.asarray(V, dtype=np.float64)), 1e-12)
+        flag = "" if (e < tolw and fe < tolf) else "  <<<<<"
+        if flag: bad += 1
+        print(m, n, k, kind, name, getattr(a._ctx, "path_name", "?"), "relWH %.2e ferr %.2e" % (e, fe), flag)
+    except Exception as ex:
+        bad += 1; print(m, n, k, kind, name, "EXC", type(ex).__name__, str(ex)[:120])
+print("bad", bad)
