@@ -73,6 +73,9 @@ struct pmf_ctx {
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
+  int g_parts = 0;              // > 0 (with g_valid): G = sum of that many partials in dGpart, dG is stale
+  int trace_parts = 0;          // > 0 (with trace_ready): the trace terms are that many pairs in dT1part
+  bool gram_partial_ok = false; // pmf_factorize: the next consumer of G is the fused kernel
   bool ps_valid = false;        // dPS = (W^T V | W^T W) of the CURRENT W, summed over all ranks
   bool num_valid = false;       // dW1 holds Num = V H^T of the current V, H (fixed-H loops, NMF)
   bool fixed_h_loop = false;    // pmf_factorize running compute_w without compute_h for > 1 iteration
@@ -268,6 +271,12 @@ int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by
 }
 
 int ensure_gram(pmf_ctx* c, double pad_diag) {
+  if (c->g_valid && c->g_parts > 0) {            // k_nmf_h_gram left partial sums: add them up
+    const int E = c->KP * c->KP;
+    hipLaunchKernelGGL(k_sum_gparts, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dGpart, c->g_parts, E, c->dG);
+    HIPCHK(c, hipGetLastError());
+    c->g_parts = 0;
+  }
   if (c->g_valid) return PMF_OK;
   dim3 grid((unsigned)(c->KP / 16), (unsigned)(c->KP / 16));
   hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k,
@@ -461,10 +470,15 @@ int launch_h_gram(pmf_ctx* c) {
     attr_done = true;
   }
   const int wgs = std::min(c->np / 64, PMF_HGRAM_MAX_WGS);
+  // inside pmf_factorize's fused loop the next reader of G is the fused kernel, which adds the
+  // per-workgroup partials itself: the kernel then ends without waiting for its last workgroup
+  const int final_sum = c->gram_partial_ok ? 0 : 1;
   hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
                      c->dG, (double*)nullptr /* no reader of the float64 copy on the NMF/BNMF paths */, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
-                     c->dGpart, c->dT1part, c->dTicket, c->stop_arg);
+                     c->dGpart, c->dT1part, c->dTicket, c->stop_arg, final_sum);
   HIPCHK(c, hipGetLastError());
+  c->g_parts = final_sum ? 0 : wgs;
+  c->trace_parts = final_sum ? 0 : wgs;
   return PMF_OK;
 }
 
@@ -567,13 +581,16 @@ int nmf_update_h(pmf_ctx* c) {
 // One pass over V doing update_w AND the partials for update_h (pmf_fused.h).
 int nmf_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
-  PMFCHK(ensure_gram(c, 0.0));
+  const float* Gsrc = c->dG;
+  int ngp = 0;
+  if (c->g_valid && c->g_parts > 0) { Gsrc = c->dGpart; ngp = c->g_parts; }   // partial sums, added by the kernel
+  else PMFCHK(ensure_gram(c, 0.0));
   stat_begin(c);
   const bool rn = c->algo == PMF_ALGO_RNMF;     // rnmf.py:100-115: both contractions run on D = S - data
   if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
   const int lrc = launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
-                               c->np, rn ? c->dD : c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w,
-                               c->dSlab, c->stop_arg);
+                               c->np, rn ? c->dD : c->dV, c->dW, c->dH, Gsrc, c->mp, c->fused_wgs, (float)c->lamb_w,
+                               c->dSlab, c->stop_arg, ngp);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -830,7 +847,12 @@ int ensure_vnorm(pmf_ctx* c) {
 // cancels when the fit is nearly exact; below 1e-3 relative residual energy the direct pass runs.
 int trace_e2(pmf_ctx* c, double* e2_out) {   // needs ps_valid and vnorm_valid
   double t[2] = {0.0, 0.0};
-  if (c->trace_ready && c->ps_valid) {   // the H-step kernel already produced both terms
+  if (c->trace_ready && c->ps_valid && c->trace_parts > 0) {   // ... as per-workgroup pairs
+    double tp[2 * PMF_HGRAM_MAX_WGS];
+    HIPCHK(c, hipMemcpyAsync(tp, c->dT1part, (size_t)2 * c->trace_parts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int q = 0; q < c->trace_parts; ++q) { t[0] += tp[2 * q]; t[1] += tp[2 * q + 1]; }
+  } else if (c->trace_ready && c->ps_valid) {   // the H-step kernel already produced both terms
     HIPCHK(c, hipMemcpyAsync(t, c->dScal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   } else {
     const int nb = c->np / 16;
@@ -966,7 +988,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
     PMFCHK(dalloc(c, &c->dScal, 8));
     PMFCHK(dalloc(c, &c->dGpart, (size_t)PMF_HGRAM_MAX_WGS * c->KP * c->KP));
-    PMFCHK(dalloc(c, &c->dT1part, (size_t)PMF_HGRAM_MAX_WGS));
+    PMFCHK(dalloc(c, &c->dT1part, (size_t)2 * PMF_HGRAM_MAX_WGS));
     PMFCHK(dalloc(c, &c->dTicket, 1));
     PMFCHK(dalloc(c, &c->dStop, 2));
     c->ferr_cap = 4096;
@@ -1154,8 +1176,11 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       const double lamb_w0 = c->lamb_w, lamb_h0 = c->lamb_h;   // BNMF: every H step scales them (bnmf.py:84-85)
       int lrc = PMF_OK;
       for (int j = 0; j < chunk && lrc == PMF_OK; ++j) {
+        c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + j + 1 < niter;
         lrc = c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c);
-        const double* tt = c->dScal + 2;                  // k_nmf_h_gram left <P,H>, <S,G> there
+        const double* tt = c->dScal + 2;                  // k_nmf_h_gram left <P,H>, <S,G> there ...
+        int ntt = 1;
+        if (lrc == PMF_OK && c->trace_ready && c->trace_parts > 0) { tt = c->dT1part; ntt = c->trace_parts; }   // ... or as pairs
         if (lrc == PMF_OK && !c->trace_ready) {           // SNMF: the H-step kernel does not form them
           const int nb = c->np / 16;
           hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
@@ -1164,7 +1189,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
           tt = c->dScal;
         }
         if (lrc == PMF_OK) {
-          hipLaunchKernelGGL(k_conv_check, dim3(1), dim3(64), 0, c->stream, tt, c->vnorm2, conv_eps,
+          hipLaunchKernelGGL(k_conv_check, dim3(1), dim3(64), 0, c->stream, tt, ntt, c->vnorm2, conv_eps,
                              (double)c->n, i + j, c->dFerr, c->dStop);
           if (hipGetLastError() != hipSuccess) lrc = fail(c, PMF_EHIP, "k_conv_check launch failed");
         }
@@ -1188,6 +1213,12 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
         c->lamb_w = lamb_w0; c->lamb_h = lamb_h0;
         for (int q = 0; q < s_it - i + 1; ++q) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }
       }
+      if (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) {
+        // the launches behind the stop were no-ops, but the host-side picture of where G lives was
+        // advanced by them: put it back to what iteration s_it's H step (the last that ran) left
+        const bool part = s_it + 1 < niter;
+        c->g_parts = part ? std::min(c->np / 64, PMF_HGRAM_MAX_WGS) : 0;
+      }
       c->trace_ready = false;
       if (c->comm) { c->ps_valid = false; c->trace_ready = false; }
       if (hstop[0] == 1) {                                // nmf.py:198-202
@@ -1203,6 +1234,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
         PMFCHK(snmf_csr_fused_iteration(c));                // CSR: one pass over the rows
       } else if (fused) {                                   // update_w + update_h, one pass over V
+        c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + 1 < niter;
         PMFCHK(c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c));
       } else {
         if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184
@@ -1241,6 +1273,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   }
   c->want_trace = false;
   c->fixed_h_loop = false;
+  c->gram_partial_ok = false;
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;

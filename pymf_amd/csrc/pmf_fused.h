@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
                                                        const float* __restrict__ G, int blk_per,
                                                        int blk_extra, float lamb,
                                                        float* __restrict__ slab,
-                                                       const int* __restrict__ stop
+                                                       const int* __restrict__ stop, int ngp
 #ifdef PMF_STAMPS
                                                        , unsigned long long* __restrict__ dbg
 #endif
@@ -191,7 +191,16 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       const int bas = NT * (row & 15) + (row >> 4);
       int c = dchunk ^ (row & 15);
       if (4 * c >= KP) c = 0;                                  // beyond k: valid, never read
-      PMF_GLDS16(G + bas * KP + 4 * c, sG + rg * 256);
+      if (ngp == 0) {
+        PMF_GLDS16(G + bas * KP + 4 * c, sG + rg * 256);
+      } else {
+        // G arrives as the ngp per-workgroup partial sums of k_nmf_h_gram: add them here (fixed
+        // order) instead of making that kernel wait for its last workgroup
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < ngp; ++w)
+          g += *reinterpret_cast<const f32x4*>(G + (size_t)w * KP * KP + bas * KP + 4 * c);
+        *reinterpret_cast<f32x4*>(sG + rg * 256 + drow * 64 + dchunk * 4) = g;
+      }
     }
   }
   wait_vmcnt<0>();
@@ -586,7 +595,7 @@ static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF
 
 template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
-                          int64_t mp, int wgs, float lamb, float* slab, const int* stop) {
+                          int64_t mp, int wgs, float lamb, float* slab, const int* stop, int ngp) {
   const int nblk = (int)(mp / 16), nw = wgs * (SPLIT == 2 ? 2 : 4);   // waves, or pairs of waves
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL, SPLIT>();
@@ -599,21 +608,21 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
     attr_done = true;
   }
   hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE, SPLIT>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
-                     blk_extra, lamb, slab, stop);
+                     blk_extra, lamb, slab, stop, ngp);
   return PMF_OK;
 }
 
 // G: H H^T (NMF) or inv(H H^T)^T (SNMF), [KP][KP] float32.
 static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
                                const float* H, const float* G, int64_t mp, int wgs, float lamb,
-                               float* slab, const int* stop = nullptr) {
+                               float* slab, const int* stop = nullptr, int ngp = 0) {
   if (!fused_shape_ok(NT, np) && fused_shape_split(NT, np) && mode != FUSED_SNMF) {
     const int skey = NT * 10 + np / 128;
 #define PMF_FUSED_SPLIT_CASE(K, A, B)                                                                   \
   case K:                                                                                               \
-    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
-           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
-                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
+    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
+                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp);
     switch (skey) {
       PMF_FUSED_SPLIT_CASE(14, 1, 4)
       PMF_FUSED_SPLIT_CASE(23, 2, 3)
@@ -625,10 +634,10 @@ static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const fl
   const int key = NT * 10 + np / 64;
 #define PMF_FUSED_CASE(K, A, B)                                                                  \
   case K:                                                                                        \
-    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
-           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
-           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop) \
-                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop);
+    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
+           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
+                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp);
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
     PMF_FUSED_CASE(12, 1, 2)

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
                                                      float* __restrict__ Gf, double* __restrict__ Gd,
                                                      float lamb, double* __restrict__ tout,
                                                      float* Gpart, double* t1part, unsigned* ticket,
-                                                     const int* __restrict__ stop) {
+                                                     const int* __restrict__ stop, int final_sum) {
   __shared__ double red[2][16];
   if (stop != nullptr && *stop != 0) return;
   __shared__ unsigned s_last;
@@ -200,15 +200,35 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[(16 * mt + 4 * kq + r) * KP + 16 * nt + i] = gs[r];
   }
-  t1 = wave_sum_f64(t1);
-  if (lane == 0) red[0][wv] = t1;
-  __syncthreads();
-  if (tid == 0) {
-    double a1 = 0.0;
+  // This workgroup's share of <P,H> and of <S,G> = <S, sum of the partial G> (float64): the pairs are
+  // added in workgroup order by whoever finishes -- the last workgroup below, or, when the partials
+  // are left for the fused kernel to add (final_sum == 0), k_conv_check / the host.  Same numbers,
+  // same order either way.
+  {
+    double t2 = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) a1 += red[0][w];
-    t1part[blockIdx.x] = a1;
+    for (int g = 0; g < GTW; ++g) {
+      const int q = wv + 16 * g;
+      if (q >= GT) break;
+      const int mt = q / NT, nt = q % NT;
+      const f32x4 gs = (ge[g][0] + ge[g][1]) + (ge[g][2] + ge[g][3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        t2 = fma((double)ss[(16 * mt + 4 * kq + r) * LDS_S + 16 * nt + i], (double)gs[r], t2);
+    }
+    t1 = wave_sum_f64(t1);
+    t2 = wave_sum_f64(t2);
+    if (lane == 0) { red[0][wv] = t1; red[1][wv] = t2; }
+    __syncthreads();
+    if (tid == 0) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { a1 += red[0][w]; a2 += red[1][w]; }
+      t1part[2 * blockIdx.x] = a1;
+      t1part[2 * blockIdx.x + 1] = a2;
+    }
   }
+  if (!final_sum) return;
   __threadfence();                                    // partials visible device-wide before the ticket
   __syncthreads();
   if (tid == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
@@ -217,31 +237,21 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
   // acquire: drop whatever this CU's L1 holds, then the partials are read with plain 16-byte loads
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const int nwg = gridDim.x;
-  double t2 = 0.0;
   for (int q4 = tid; q4 < KP * KP / 4; q4 += 1024) {
     f32x4 g = {0.f, 0.f, 0.f, 0.f};                   // fixed order over workgroups
     const f32x4* src = reinterpret_cast<const f32x4*>(Gpart) + q4;
     for (int w = 0; w < nwg; ++w) g += src[(size_t)w * (KP * KP / 4)];
     *reinterpret_cast<f32x4*>(Gf + 4 * q4) = g;
-    const int r = (4 * q4) / KP, c = (4 * q4) % KP;
+    if (Gd) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (Gd) Gd[4 * q4 + e] = (double)g[e];
-      t2 = fma((double)ss[r * LDS_S + c + e], (double)g[e], t2);
+      for (int e = 0; e < 4; ++e) Gd[4 * q4 + e] = (double)g[e];
     }
   }
-  if (tout) {
-    t2 = wave_sum_f64(t2);
-    if (lane == 0) red[1][wv] = t2;
-    __syncthreads();
-    if (tid == 0) {
-      double a1 = 0.0, a2 = 0.0;
-      for (int w = 0; w < nwg; ++w) a1 += t1part[w];
-#pragma unroll
-      for (int w = 0; w < 16; ++w) a2 += red[1][w];
-      tout[0] = a1;
-      tout[1] = a2;
-    }
+  if (tout && tid == 0) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int w = 0; w < nwg; ++w) { a1 += t1part[2 * w]; a2 += t1part[2 * w + 1]; }
+    tout[0] = a1;
+    tout[1] = a2;
   }
   if (tid == 0) *ticket = 0u;                         // ready for the next launch (stream order)
 }
@@ -527,12 +537,25 @@ __global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ s
 // iteration.  tt = (<P,H>, <S,G>) from k_nmf_h_gram; ||V - W H||^2 = ||V||^2 - 2 tt[0] + tt[1].
 // stop[0]: 0 running, 1 converged at iteration stop[1], 2 the identity cancels at iteration
 // stop[1] (its error must be evaluated directly); once set, every later launch is a no-op.
-__global__ void k_conv_check(const double* __restrict__ tt, double vnorm2, double eps, double nsamp, int i,
-                             double* __restrict__ ferr, int* __restrict__ stop) {
+__global__ void k_conv_check(const double* __restrict__ tt, int ntt, double vnorm2, double eps, double nsamp,
+                             int i, double* __restrict__ ferr, int* __restrict__ stop) {
   if (threadIdx.x != 0 || blockIdx.x != 0 || stop[0] != 0) return;
-  const double e2 = vnorm2 - 2.0 * tt[0] + tt[1];
+  double t0 = tt[0], t1 = tt[1];
+  for (int q = 1; q < ntt; ++q) { t0 += tt[2 * q]; t1 += tt[2 * q + 1]; }   // ntt > 1: per-workgroup pairs
+  const double e2 = vnorm2 - 2.0 * t0 + t1;
   if (!(e2 > 1e-3 * vnorm2)) { stop[1] = i; stop[0] = 2; return; }
   const double f = sqrt(e2);
   ferr[i] = f;
   if (i > 1 && fabs(f - ferr[i - 1]) / nsamp < eps) { stop[1] = i; stop[0] = 1; }
+}
+
+// G = sum of the per-workgroup partial Gram matrices k_nmf_h_gram leaves when the fused kernel is not
+// the next consumer (fixed order).
+__global__ __launch_bounds__(256) void k_sum_gparts(const float* __restrict__ Gpart, int nparts, int E,
+                                                    float* __restrict__ G) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= E) return;
+  float g = 0.f;
+  for (int w = 0; w < nparts; ++w) g += Gpart[(size_t)w * E + q];
+  G[q] = g;
 }

@@ -498,4 +498,13 @@ def test_free_running_loop_matches_stepwise_loop(pm, algo_name):
         np.testing.assert_array_equal(a.get_h(), b.get_h())
         if algo_name == "BNMF":
             assert a.get_lambda() == b.get_lambda()
+        # wherever the loop stopped, the context must be in a state the single hooks can go on from
+        # (inside the loop G = H H^T lives as per-workgroup partial sums)
+        a.update_w(); b.update_w()
+        a.update_h(); b.update_h()
+        np.testing.assert_array_equal(a.get_w(), b.get_w())
+        np.testing.assert_array_equal(a.get_h(), b.get_h())
+        f2a, _, _ = a.factorize(3, conv_eps=0.0)
+        f2b, _, _ = b.factorize(3, conv_eps=0.0)
+        np.testing.assert_allclose(f2a, f2b, rtol=1e-12)
         a.close(); b.close()

@@ -11,7 +11,7 @@ int main(int argc, char** argv){
   const int NP = argc > 1 ? atoi(argv[1]) : 256;
   float *H,*PS,*G,*Gpart; double *Gd,*tout,*t1p; unsigned* ticket;
   CK(hipMalloc(&H,KP*NP*4)); CK(hipMalloc(&PS,KP*(NP+KP)*4)); CK(hipMalloc(&G,KP*KP*4)); CK(hipMalloc(&Gd,KP*KP*8)); CK(hipMalloc(&tout,16));
-  CK(hipMalloc(&Gpart,64*KP*KP*4)); CK(hipMalloc(&t1p,64*8)); CK(hipMalloc(&ticket,4)); CK(hipMemset(ticket,0,4));
+  CK(hipMalloc(&Gpart,64*KP*KP*4)); CK(hipMalloc(&t1p,64*16)); CK(hipMalloc(&ticket,4)); CK(hipMemset(ticket,0,4));
   fillk<<<(KP*NP+255)/256,256>>>(H,KP*NP,3); fillk<<<(KP*(NP+KP)+255)/256,256>>>(PS,KP*(NP+KP),5);
   constexpr size_t smem = hgram_smem_bytes<NT>();
   CK(hipFuncSetAttribute((const void*)&k_nmf_h_gram<NT,false>, hipFuncAttributeMaxDynamicSharedMemorySize,(int)smem));
@@ -19,7 +19,7 @@ int main(int argc, char** argv){
   for (int wgs = 1; wgs <= NP/64; wgs *= 2){
     for (int rep=0; rep<2; ++rep){
       hipEventRecord(e0);
-      for(int it=0; it<200; ++it) k_nmf_h_gram<NT,false><<<wgs,1024,smem>>>(H,NP,PS,G,(argc>2)?nullptr:Gd,0.f,(it&1)?tout:nullptr,Gpart,t1p,ticket,nullptr);
+      for(int it=0; it<200; ++it) k_nmf_h_gram<NT,false><<<wgs,1024,smem>>>(H,NP,PS,G,(argc>2)?nullptr:Gd,0.f,(it&1)?tout:nullptr,Gpart,t1p,ticket,nullptr,(argc>3)?0:1);
       hipEventRecord(e1); CK(hipDeviceSynchronize());
       float ms; hipEventElapsedTime(&ms,e0,e1);
       if (rep) printf("np=%d wgs=%d: %.2f us/launch back to back\n", NP, wgs, ms*1000/200);
