@@ -69,8 +69,9 @@ constexpr size_t fused_smem_bytes() {
 // same slots: flipping bit 3 of the XOR key on rows with bit 2 set keeps both reads
 // conflict-free (phase A only needs the key to be a bijection that preserves r ^ r' == 1).
 __device__ __forceinline__ int vtile_xor(int row) { return (row ^ ((row & 4) << 1)) & 15; }
+__device__ __forceinline__ int vtile_off(int row, int chunk) { return row * 64 + ((chunk ^ vtile_xor(row)) << 2); }
 __device__ __forceinline__ f32x4 vtile_read4(const float* base, int row, int chunk) {
-  return *reinterpret_cast<const f32x4*>(base + row * 64 + ((chunk ^ vtile_xor(row)) << 2));
+  return *reinterpret_cast<const f32x4*>(base + vtile_off(row, chunk));
 }
 
 // blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = 4 * q + (lane >> 4);
-    const int c = (lane & 15) ^ row;
-    voff[q] = (unsigned)(row * NP * 4 + 16 * ((lane & 15) ^ vtile_xor(row)));
+    const int c = (lane & 15) ^ vtile_xor(row);   // the W image is read both ways as well (Den fragments, old W rows)
+    voff[q] = (unsigned)(row * NP * 4 + 16 * c);
     woff[q] = (unsigned)(row * KP * 4 + 16 * (4 * c < KP ? c : 0));   // beyond k: valid, never read
   }
   const char* Vb = reinterpret_cast<const char*>(V);
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sH + (hp + p) * (KP * 64), 16 * nt + i, chunk);
       } else {
         const int chunk = 4 * (s - NSN) + kq;
-        fa[buf] = lds_read4(sW, i, chunk);
+        fa[buf] = vtile_read4(sW, i, chunk);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[buf][nt] = lds_read4(sG, 16 * nt + i, chunk);
       }
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int row = 4 * kq + j, col = NT * i + nt;
-            sW[swz_off(row, col >> 2) + (col & 3)] = num[nt][j];
+            sW[vtile_off(row, col >> 2) + (col & 3)] = num[nt][j];
           }
         load_step(NSN, NSN & 1);
       }
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int row = 4 * kq + j, col = NT * i + nt;       // NT consecutive floats per (lane, j)
-          wold[nt][j] = sW[swz_off(row, col >> 2) + (col & 3)];
+          wold[nt][j] = sW[vtile_off(row, col >> 2) + (col & 3)];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (more) {
