@@ -73,3 +73,24 @@ def test_bnmf_fused_and_tiled_agree(pm):
         b.update_h()
     assert a.get_lambda() == b.get_lambda()
     assert rel_fro(a.get_w(), b.get_w()) < 5e-6 and rel_fro(a.get_h(), b.get_h()) < 5e-6
+
+
+@pytest.mark.parametrize("shape,k", [((3000, 512), 32), ((2000, 384), 17), ((2500, 500), 9), ((4000, 190), 64),
+                                     ((1500, 320), 30)])
+def test_bnmf_every_fused_shape_class_vs_oracle(pm, shape, k):
+    """BNMF on the shape classes of the fused kernel beyond the 4-panel one: 3/5/6 panels and the
+    two-waves-per-block form (n up to 512 for k <= 32)."""
+    from oracle import BNMFOracle
+    from pymf_amd import _lib
+    rs = np.random.RandomState(shape[1] + k)
+    V = (rs.random_sample(shape) < 0.3).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    mdl = pm.BNMF(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=4)
+    assert mdl._ctx.path_name.startswith("k_nmf_fused") and mdl._ctx.path_name.endswith(",bnmf>")
+    o = BNMFOracle(V, num_bases=k)
+    o.W, o.H = W0.copy(), H0.copy()
+    o.factorize(niter=4)
+    assert rel_fro(mdl.W, o.W) < 5e-5 and rel_fro(mdl.H, o.H) < 5e-5
+    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=2e-5)

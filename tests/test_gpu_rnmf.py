@@ -58,3 +58,22 @@ def test_rnmf_hooks_and_missing_s(pm):
     assert rel_fro(mdl.W, ref.W) < 1e-4 and rel_fro(mdl.H, ref.H) < 1e-4
     assert rel_fro(mdl.S, ref.S) < 1e-2
     assert abs(mdl.frobenius_norm() - ref.frobenius_norm()) / ref.frobenius_norm() < 1e-4
+
+
+@pytest.mark.parametrize("shape,k", [((2000, 256), 64), ((1500, 512), 32), ((1200, 384), 16), ((900, 100), 20)])
+def test_rnmf_fused_shapes_vs_oracle(pm, shape, k):
+    """RNMF on the fused kernel (FUSED_RNMF epilogue over D = S - data), every shape class."""
+    from pymf_amd.rnmf import RNMF
+    from oracle import RNMFOracle
+    rs = np.random.RandomState(shape[0] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    V.flat[rs.randint(0, V.size, size=V.size // 300)] += 5.0
+    np.random.seed(5)
+    mdl = RNMF(V, num_bases=k, lamb=1.0)
+    mdl.factorize(niter=3)
+    assert mdl._ctx.path_name.startswith("k_nmf_fused") and mdl._ctx.path_name.endswith(",rnmf>")
+    np.random.seed(5)
+    o = RNMFOracle(V, num_bases=k, lamb=1.0)
+    o.factorize(niter=3)
+    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=2e-4)
+    assert rel_fro(mdl.W, o.W) < 2e-3 and rel_fro(mdl.H, o.H) < 2e-3
