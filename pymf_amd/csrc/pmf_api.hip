@@ -82,6 +82,7 @@ struct pmf_ctx {
   bool want_trace = false;      // pmf_factorize with PMF_COMPUTE_ERR: let the H-step kernel emit the trace terms
   bool trace_ready = false;     // dScal[2..3] already hold <P,H>, <S,HH^T> for the current W, H
   bool vnorm_valid = false;
+  bool vnorm_local_valid = false;   // dScal[6] = sum(V^2) over this rank's rows (formed behind the upload)
   double vnorm2 = 0.0;          // ||V||_F^2 over all ranks
   double lamb_w = 0.0, lamb_h = 0.0;   // BNMF penalty weights (bnmf.py:84-85,118-119)
   // streamed V (pmf_stream_*): row tiles pass through two device buffers, V is never resident
@@ -826,13 +827,22 @@ int frobenius_direct(pmf_ctx* c, double* out) {
   return PMF_OK;
 }
 
-int ensure_vnorm(pmf_ctx* c) {
-  if (c->vnorm_valid) return PMF_OK;
+// sum(V^2) over this rank's rows -> dScal[6]; enqueued right behind the upload of a dense V, so the
+// first error evaluation does not pay a pass over V
+int local_vnorm(pmf_ctx* c) {
   const int nb = 1024;
   hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, c->stream, c->dV, (int64_t)c->mp * c->np, c->dPart);
   HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 6);
   HIPCHK(c, hipGetLastError());
+  c->vnorm_local_valid = true;
+  return PMF_OK;
+}
+
+int ensure_vnorm(pmf_ctx* c) {
+  if (c->vnorm_valid) return PMF_OK;
+  if (!c->vnorm_local_valid) PMFCHK(local_vnorm(c));
+  HIPCHK(c, hipMemcpyAsync(c->dScal, c->dScal + 6, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->vnorm2, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1048,6 +1058,7 @@ int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   PMFCHK(ensure_dv(c));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
   c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
+  PMFCHK(local_vnorm(c));
   return PMF_OK;
 }
 
@@ -1070,7 +1081,7 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
     HIPCHK(c, hipMemcpyAsync(c->dVals, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
+  c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false;
   return PMF_OK;
 }
 
@@ -1089,6 +1100,7 @@ int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   PMFCHK(ensure_dv(c));
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
   c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
+  PMFCHK(local_vnorm(c));
   return PMF_OK;
 }
 int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
