@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     // ------- epilogue W_b <- (W_b * Num) / (Den + eps), interleaved with S += of the previous block -------
     f32x4 wn[NT];
     float* wdst = W + (size_t)blk * (16 * KP) + (4 * kq) * KP + NT * i;
-    if (MODE == FUSED_NMF) {
+    if (MODE != FUSED_SNMF) {
       // The division of the 4 NT elements in STAGES (all numerators, all reciprocals, all quotients,
       // all residuals, all corrections): a wave issues in order, so an element-by-element chain of
       // dependent VALU ops also holds up the S MFMAs queued behind it; stage by stage every
@@ -374,8 +374,18 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          tnum[nt][j] = wold[nt][j] * num[nt][j];                // nmf.py:131 (multiply first)
-          dd[nt][j] = den[nt][j] + PMF_EPS_DEN;
+          const float w0 = wold[nt][j];
+          if (MODE == FUSED_BNMF) {                              // bnmf.py:87-90, W *= W1 / W2
+            tnum[nt][j] = num[nt][j] + (3.0f * lamb) * (w0 * w0);
+            dd[nt][j] = ((den[nt][j] + (2.0f * lamb) * (w0 * w0 * w0)) + lamb * w0) + PMF_EPS_DEN;
+          } else if (MODE == FUSED_RNMF) {                       // rnmf.py:109-115 on D = S - data, no epsilon
+            const float x = num[nt][j];
+            tnum[nt][j] = fabsf(x) - x;
+            dd[nt][j] = 2.0f * den[nt][j];
+          } else {
+            tnum[nt][j] = w0 * num[nt][j];                       // nmf.py:131 (multiply first)
+            dd[nt][j] = den[nt][j] + PMF_EPS_DEN;
+          }
         }
       s_mfmas(0, NSM / 5);
       __builtin_amdgcn_sched_barrier(0);
@@ -401,7 +411,9 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float w = fmaf(tnum[nt][j], rr[nt][j], qq[nt][j]);   // pmf_div, nmf.py:132
+          float w = fmaf(tnum[nt][j], rr[nt][j], qq[nt][j]);        // pmf_div (nmf.py:132)
+          if (MODE == FUSED_BNMF) w = wold[nt][j] * w;
+          if (MODE == FUSED_RNMF) w = dd[nt][j] != 0.f ? wold[nt][j] * w : 0.f;   // 0/0 on the zero padding
           wn[nt][j] = w;
 #ifndef PMF_ABLATE_WSTORE
           if (SPLIT == 1 || half == 0) wdst[j * KP + nt] = w;
@@ -411,28 +423,15 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);
     } else {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float w;
-        if (MODE == FUSED_SNMF) {
-          w = den[nt][j];                                    // W = (V H^T) inv(H H^T), snmf.py:70
-        } else if (MODE == FUSED_RNMF) {                     // rnmf.py:109-115 on D = S - data, no epsilon
-          const float x = num[nt][j], d2 = 2.0f * den[nt][j];
-          w = d2 != 0.f ? wold[nt][j] * ((fabsf(x) - x) / d2) : 0.f;   // 0/0 on the zero padding
-        } else {                                             // bnmf.py:87-90, W *= W1 / W2
-          const float w0 = wold[nt][j];
-          const float w1 = num[nt][j] + (3.0f * lamb) * (w0 * w0);
-          const float w2 = ((den[nt][j] + (2.0f * lamb) * (w0 * w0 * w0)) + lamb * w0) + PMF_EPS_DEN;
-          w = w0 * pmf_div(w1, w2);
-        }
-        wn[nt][j] = w;
-        if (SPLIT == 1 || half == 0) {                       // one partner stores W and forms S
+        for (int j = 0; j < 4; ++j) {
+          const float w = den[nt][j];                        // W = (V H^T) inv(H H^T), snmf.py:70
+          wn[nt][j] = w;
           wdst[j * KP + nt] = w;
 #pragma unroll
           for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
         }
-      }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wp[nt] = wn[nt];
