@@ -508,3 +508,24 @@ def test_free_running_loop_matches_stepwise_loop(pm, algo_name):
         f2b, _, _ = b.factorize(3, conv_eps=0.0)
         np.testing.assert_allclose(f2a, f2b, rtol=1e-12)
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("shape,k", [((20000, 256), 64), ((9000, 512), 32), ((7000, 192), 48), ((5000, 700), 16)])
+def test_results_are_reproducible_bit_for_bit(pm, shape, k):
+    """Every reduction runs in a fixed order (per-wave chains, cross-wave sums through LDS, float64 slab
+    sums, partial Gram matrices added by workgroup index): two runs give identical bits."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(k)
+    V = rs.random_sample(shape).astype(np.float32)
+    W0 = rs.random_sample((shape[0], k)).astype(np.float32)
+    H0 = rs.random_sample((k, shape[1])).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        ctx = _lib.Context(_lib.ALGO_NMF, shape[0], shape[1], k)
+        ctx.set_v_dense(V); ctx.set_w(W0); ctx.set_h(H0)
+        ferr, _, _ = ctx.factorize(12)
+        outs.append((ctx.get_w(), ctx.get_h(), ferr.copy()))
+        ctx.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
