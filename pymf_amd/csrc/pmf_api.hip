@@ -439,7 +439,15 @@ int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2)
   return PMF_OK;
 }
 
+int nmf_fused_pass(pmf_ctx* c);
+
 int nmf_update_w(pmf_ctx* c) {
+  // The single hook on a fused-kernel shape runs the same one-pass kernel: W is updated and, for the
+  // price of the second half of the pass, (W^T V | W^T W) of the new W is already there when
+  // update_h() follows (it then costs one k x n sized kernel) -- 0.65 ms for the pair at cfg4
+  // instead of 1.12 ms as two tiled passes.
+  if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->fused_wgs > 0 && !c->fixed_h_loop && !c->v_csr)
+    return nmf_fused_pass(c);
   PMFCHK(ensure_gram(c, 0.0));
   if (c->algo == PMF_ALGO_RNMF) {
     if (!c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
@@ -579,8 +587,9 @@ int nmf_update_h(pmf_ctx* c) {
   return h_step_from_ps(c);
 }
 
-// One pass over V doing update_w AND the partials for update_h (pmf_fused.h).
-int nmf_fused_iteration(pmf_ctx* c) {
+// One pass over V doing update_w AND the partials for update_h (pmf_fused.h): W is updated and the
+// all-rank (P | S) of the NEW W is left in dPS.
+int nmf_fused_pass(pmf_ctx* c) {
   c->ps_valid = false;
   const float* Gsrc = c->dG;
   int ngp = 0;
@@ -604,8 +613,13 @@ int nmf_fused_iteration(pmf_ctx* c) {
   }
   PMFCHK(allreduce_ps(c));
   c->ps_valid = true;
+  return PMF_OK;
+}
+
+int nmf_fused_iteration(pmf_ctx* c) {
+  PMFCHK(nmf_fused_pass(c));
   PMFCHK(h_step_from_ps(c));
-  if (rn) {                                     // rnmf.py:107: update_h ends with update_s
+  if (c->algo == PMF_ALGO_RNMF) {               // rnmf.py:107: update_h ends with update_s
     c->ps_valid = false;                        // (P | S) were built from D, not from V
     return rnmf_update_s(c);
   }
@@ -623,7 +637,10 @@ int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan 
   return PMF_OK;
 }
 
+int snmf_fused_pass(pmf_ctx* c);
+
 int snmf_update_w(pmf_ctx* c) {
+  if (c->fused_wgs > 0 && !c->v_csr) return snmf_fused_pass(c);   // as nmf_update_w: one pass, (P | S) kept for update_h
   PMFCHK(snmf_inverse(c));
   if (c->v_csr) return csr_w(c);
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
@@ -633,7 +650,7 @@ int snmf_update_w(pmf_ctx* c) {
 int snmf_inverse(pmf_ctx* c);
 
 // SNMF: update_w and the partials of update_h in ONE pass over V (dense data, fused shapes).
-int snmf_fused_iteration(pmf_ctx* c) {
+int snmf_fused_pass(pmf_ctx* c) {
   c->ps_valid = false;
   PMFCHK(snmf_inverse(c));
   stat_begin(c);
@@ -651,6 +668,11 @@ int snmf_fused_iteration(pmf_ctx* c) {
   }
   PMFCHK(allreduce_ps(c));
   c->ps_valid = true;
+  return PMF_OK;
+}
+
+int snmf_fused_iteration(pmf_ctx* c) {
+  PMFCHK(snmf_fused_pass(c));
   return h_step_from_ps(c);
 }
 
