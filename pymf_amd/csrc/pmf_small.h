@@ -259,33 +259,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
 // SNMF H step (pymf/snmf.py:72-91) with XW = P^T (P = W^T V) and WW = S = W^T W:
 //   H1 = pos(XW)^T + (H^T neg(WW))^T,  H2 = neg(XW)^T + (H^T pos(WW))^T + 1e-9,
 //   H *= sqrt(H1 / H2).
-__global__ __launch_bounds__(256) void k_snmf_h(float* __restrict__ H, int64_t ldh, int np, int KP,
-                                                const float* __restrict__ PS) {
-  extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
-  const int tid = threadIdx.x;
-  const int c = tid & 15;
-  const int col = blockIdx.x * 16 + c;
-  const int64_t ldp = (int64_t)np + KP;
-  for (int kk = tid >> 4; kk < KP; kk += 16) hs[kk * 16 + c] = H[(int64_t)kk * ldh + col];
-  __syncthreads();
-  for (int kk = tid >> 4; kk < KP; kk += 16) {
-    float a1 = 0.f, a2 = 0.f;
-    for (int j = 0; j < KP; ++j) {
-      const float ww = PS[(int64_t)j * ldp + np + kk];     // WW[j][kk]
-      const float hj = hs[j * 16 + c];
-      const float wp = (fabsf(ww) + ww) * 0.5f;            // snmf.py:73-74
-      const float wn = (fabsf(ww) - ww) * 0.5f;            // snmf.py:76-77
-      a1 = fmaf(hj, wn, a1);
-      a2 = fmaf(hj, wp, a2);
-    }
-    const float xw = PS[(int64_t)kk * ldp + col];
-    const float h1 = (fabsf(xw) + xw) * 0.5f + a1;
-    const float h2 = (fabsf(xw) - xw) * 0.5f + a2 + PMF_EPS_DEN;
-    H[(int64_t)kk * ldh + col] *= sqrtf(h1 / h2);
-  }
-}
-
-// The same H step on MFMA, one workgroup per 64-column panel (columns are independent): wave w owns
+// On MFMA, one workgroup per 64-column panel (columns are independent): wave w owns
 // tiles (mt, ct) = (q / 4, q % 4), q = w, w + 16, ...; S is split into its positive and negative
 // parts in registers as the A fragments are read, so pos(WW) H and neg(WW) H are two accumulator
 // chains over the same operands.  LDS layout and staging as in k_nmf_h_gram.
