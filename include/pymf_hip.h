@@ -4,8 +4,9 @@
  *
  * Plain C, no C++ or torch types.  One pmf_ctx drives ONE GPU from one host
  * thread (thread-compatible, not thread-safe); multi-GPU = one process (ctx)
- * per GPU, rows of V/W sharded, RCCL all-reduce inside pmf_update_h /
- * pmf_factorize.  The caller owns every host buffer; the library owns all
+ * per GPU, rows of V/W sharded, one RCCL all-reduce of (W^T V | W^T W) per iteration
+ * inside pmf_factorize (for the single hooks: inside whichever of pmf_update_w /
+ * pmf_update_h forms those sums -- all ranks make the same calls in the same order).  The caller owns every host buffer; the library owns all
  * device memory, its HIP stream and its RCCL communicator.
  *
  * Reference interface each entry point replaces (paths into nils-werner/pymf):
@@ -22,6 +23,9 @@
  *   pmf_frobenius         NMF.frobenius_norm           pymf/nmf.py:100-114
  *   pmf_factorize         NMF.factorize loop body      pymf/nmf.py:182-202
  *                         (incl. NMF.converged         pymf/nmf.py:134-139)
+ *   pmf_rnmf_update_s     RNMF.update_s                pymf/rnmf.py:96-98   (algo 4, 'next' row)
+ *   pmf_nndsvd_init       NNDSVD.update_w + SVD        pymf/nndsvd.py:78-106, pymf/svd.py:105-148
+ *   pmf_stream_*          the data[:,:] reads of       pymf/nmf.py:123,129 for data that is not resident
  *
  * Every function returns PMF_OK (0) or a negative status and never throws;
  * pmf_last_error() gives a human-readable message for the last failure.
@@ -90,7 +94,8 @@ int pmf_get_h_f32(pmf_ctx* ctx, float* H);
 int pmf_fill_w_uniform(pmf_ctx* ctx, uint64_t seed, int64_t row0);
 int pmf_fill_h_uniform(pmf_ctx* ctx, uint64_t seed);
 
-/* One hook each (blocking until done on the device). */
+/* One hook each (blocking until done on the device).  On shapes the one-pass kernel takes,
+ * pmf_update_w also leaves (W^T V | W^T W) of the new W cached for the pmf_update_h that follows. */
 int pmf_update_w(pmf_ctx* ctx);
 int pmf_update_h(pmf_ctx* ctx);
 int pmf_frobenius(pmf_ctx* ctx, double* out);   /* sqrt(sum((V - W H)^2)), all ranks' rows */
