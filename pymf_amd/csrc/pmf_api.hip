@@ -185,8 +185,10 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)(rows_p / 64)), dim3(256), smem, c->stream,
-                     A, lda, kdimA, B, ldb, W, G, C, lamb, mvalid, c->k);
+  const int ntiles = (int)(rows_p / 64);
+  const int tpw = ntiles >= 8192 ? 8 : ntiles >= 2048 ? 4 : ntiles >= 1024 ? 2 : 1;   // consecutive tiles per workgroup
+  hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), smem, c->stream,
+                     A, lda, kdimA, B, ldb, W, G, C, lamb, mvalid, c->k, ntiles, tpw);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }

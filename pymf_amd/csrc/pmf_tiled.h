@@ -45,30 +45,63 @@ struct PanelStage {
   }
 };
 
+#ifdef PMF_RG_STAMPS   // diagnostic build only (tools/stamp_rowgemm.hip)
+#define PMF_RG_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ unsigned long long g_rg_acc[4];   // store, barrier, issue loads, reads+MFMA  (wave 0 of block 0 only)
+#else
+#define PMF_RG_STAMP(var) do { } while (0)
+#endif
+
 // acc[nt] (+)= A_tile[64 x kdim] * B[KP x kdim]^T for this wave's 16 rows.
 // sa: 2 x [64][64] floats, sb: 2 x [KP][64] floats.  kdim % 4 == 0.
+// Register stages of tile_gemm_nt: panels p (stage 0/1 alternating) on their way global -> LDS.
+template <int NT>
+struct GemmStages {
+  PanelStage<64> pa0, pa1;
+  PanelStage<16 * NT> pb0, pb1;
+  // request panels 0 and 1 of the product A[64 x kdim] * B[KP x kdim]^T
+  __device__ __forceinline__ void prefetch(const float* __restrict__ A, int64_t lda,
+                                           const float* __restrict__ B, int64_t ldb, int kdim, int tid) {
+    pa0.load(A, lda, 0, kdim, tid);
+    pb0.load(B, ldb, 0, kdim, tid);
+    if (kdim > 64) {
+      pa1.load(A, lda, 64, kdim, tid);
+      pb1.load(B, ldb, 64, kdim, tid);
+    }
+  }
+};
+
+// acc[nt] (+)= A_tile[64 x kdim] * B[KP x kdim]^T for this wave's 16 rows; st.prefetch(A, B) has been
+// called.  sa: 2 x [64][64] floats, sb: 2 x [KP][64] floats.  kdim % 4 == 0.
+// Panels travel global -> registers -> LDS.  TWO register stages: panel p + 2 is requested while
+// panel p is multiplied, so a request has two panel times (not one) to come back -- measured with
+// in-kernel stamps, one was not enough: the stores to LDS waited ~1 000 cycles per panel.
 template <int NT>
 __device__ __forceinline__ void tile_gemm_nt(f32x4 (&acc)[NT], const float* __restrict__ A,
                                              int64_t lda, const float* __restrict__ B,
-                                             int64_t ldb, int kdim, float* sa, float* sb) {
+                                             int64_t ldb, int kdim, float* sa, float* sb,
+                                             GemmStages<NT>& st) {
   constexpr int KP = 16 * NT;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  PanelStage<64> pa;
-  PanelStage<KP> pb;
   const int npan = (kdim + 63) >> 6;
-  pa.load(A, lda, 0, kdim, tid);
-  pb.load(B, ldb, 0, kdim, tid);
-  for (int p = 0; p < npan; ++p) {
+  auto panel = [&](int p, PanelStage<64>& pa, PanelStage<KP>& pb) {
     float* ca = sa + (p & 1) * (64 * 64);
     float* cb = sb + (p & 1) * (KP * 64);
+#ifdef PMF_RG_STAMPS
+    unsigned long long t0, t1, t2, t3, t4;
+#endif
+    PMF_RG_STAMP(t0);
     pa.store(ca, tid);
     pb.store(cb, tid);
+    PMF_RG_STAMP(t1);
     __syncthreads();
-    if (p + 1 < npan) {
-      pa.load(A, lda, 64 * (p + 1), kdim, tid);
-      pb.load(B, ldb, 64 * (p + 1), kdim, tid);
+    PMF_RG_STAMP(t2);
+    if (p + 2 < npan) {
+      pa.load(A, lda, 64 * (p + 2), kdim, tid);
+      pb.load(B, ldb, 64 * (p + 2), kdim, tid);
     }
+    PMF_RG_STAMP(t3);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int chunk = 4 * t + kq;
@@ -81,6 +114,14 @@ __device__ __forceinline__ void tile_gemm_nt(f32x4 (&acc)[NT], const float* __re
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a4[e], b4[nt][e], acc[nt]);
     }
+#ifdef PMF_RG_STAMPS
+    PMF_RG_STAMP(t4);
+    if (blockIdx.x == 100 && tid == 0) { g_rg_acc[0] += t1 - t0; g_rg_acc[1] += t2 - t1; g_rg_acc[2] += t3 - t2; g_rg_acc[3] += t4 - t3; }
+#endif
+  };
+  for (int p = 0; p < npan; p += 2) {
+    panel(p, st.pa0, st.pb0);
+    if (p + 1 < npan) panel(p + 1, st.pa1, st.pb1);
   }
 }
 
@@ -92,63 +133,83 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
                                                  const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ W, const float* __restrict__ G,
                                                  float* __restrict__ C, float lamb,
-                                                 int64_t mvalid, int kvalid) {
+                                                 int64_t mvalid, int kvalid, int ntiles, int tpw) {
   constexpr int KP = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sa = smem;
   float* sb = smem + 2 * 64 * 64;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  // A workgroup takes tpw consecutive 64-row tiles: a tile on its own spends ~40 % of its life on the
+  // first requests' latency, the epilogue's loads and the workgroup turnover (in-kernel stamps), so the
+  // first two panels of tile t + 1 are requested before tile t's epilogue and its old W rows before
+  // its Den product.
+  const int t_begin = blockIdx.x * tpw;
+  int t_end = t_begin + tpw;
+  if (t_end > ntiles) t_end = ntiles;
+  GemmStages<NT> st;
+  if (EPI != EPI_NMF_W_CACHED && t_begin < t_end) st.prefetch(A + (int64_t)t_begin * 64 * lda, lda, B, ldb, kdimA, tid);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int64_t row0 = (int64_t)tile * 64;
+    f32x4 num[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) num[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t rbase = row0 + 16 * wv + 4 * kq;   // + reg index j
+    if (EPI == EPI_NMF_W_CACHED) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) num[nt][j] = C[(rbase + j) * KP + 16 * nt + i];
+    } else {
+      tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb, st);
+    }
+    if (EPI == EPI_NMF_W_SAVE) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+    }
 
-  f32x4 num[NT];
+    if (EPI != EPI_STORE) {
+      f32x4 den[NT];
+      float wold[NT][4];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) num[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int64_t rbase = row0 + 16 * wv + 4 * kq;   // + reg index j
-  if (EPI == EPI_NMF_W_CACHED) {
+      for (int nt = 0; nt < NT; ++nt) {
+        den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) num[nt][j] = C[(rbase + j) * KP + 16 * nt + i];
-  } else {
-    tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb);
-  }
-  if (EPI == EPI_NMF_W_SAVE) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
-  }
-
-  if (EPI != EPI_STORE) {
-    f32x4 den[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI != EPI_NMF_W_CACHED) __syncthreads();
-    tile_gemm_nt<NT>(den, W + row0 * KP, KP, G, KP, KP, sa, sb);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float* p = W + (rbase + j) * KP + 16 * nt + i;
-        const float w = *p;
-        if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
-          const float x = num[nt][j];
-          const float r = w * ((fabsf(x) - x) / (2.0f * den[nt][j]));
-          *p = ((rbase + j) < mvalid && (16 * nt + i) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
-        } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
-          const float w1 = num[nt][j] + (3.0f * lamb) * (w * w);
-          const float w2 = ((den[nt][j] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
-          *p = w * (w1 / w2);
-        } else {
-          *p = (w * num[nt][j]) / (den[nt][j] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:131-132)
-        }
+        for (int j = 0; j < 4; ++j) wold[nt][j] = W[(rbase + j) * KP + 16 * nt + i];   // lands during Den
       }
-  } else {
+      __syncthreads();                                     // the LDS panels of the previous product are free
+      st.prefetch(W + row0 * KP, KP, G, KP, KP, tid);
+      tile_gemm_nt<NT>(den, W + row0 * KP, KP, G, KP, KP, sa, sb, st);
+      if (EPI != EPI_NMF_W_CACHED && tile + 1 < t_end)     // next tile's first panels, under the epilogue
+        st.prefetch(A + (row0 + 64) * lda, lda, B, ldb, kdimA, tid);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+        for (int j = 0; j < 4; ++j) {
+          float* p = W + (rbase + j) * KP + 16 * nt + i;
+          const float w = wold[nt][j];
+          if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
+            const float x = num[nt][j];
+            const float r = w * ((fabsf(x) - x) / (2.0f * den[nt][j]));
+            *p = ((rbase + j) < mvalid && (16 * nt + i) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
+          } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
+            const float w1 = num[nt][j] + (3.0f * lamb) * (w * w);
+            const float w2 = ((den[nt][j] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
+            *p = w * (w1 / w2);
+          } else {
+            *p = (w * num[nt][j]) / (den[nt][j] + PMF_EPS_DEN);   // multiply, then divide (nmf.py:131-132)
+          }
+        }
+    } else {
+      if (tile + 1 < t_end) st.prefetch(A + (row0 + 64) * lda, lda, B, ldb, kdimA, tid);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+    }
+    __syncthreads();                                       // LDS panels free for the next tile
   }
 }
 
