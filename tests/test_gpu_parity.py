@@ -529,3 +529,26 @@ def test_results_are_reproducible_bit_for_bit(pm, shape, k):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 300), 128), ("NMF", (2000, 700), 40), ("BNMF", (2500, 200), 100),
+                                              ("SNMF", (3000, 400), 100), ("NMF", (1500, 1100), 20)])
+def test_tiled_kernels_vs_oracle(pm, cls_name, shape, k):
+    """Shapes the one-pass kernel does not take (k > 64, or wider than its LDS budget) run on the
+    two-pass tiled kernels (k_rowgemm / k_colgemm): same tolerances against the oracle."""
+    import oracle
+    rs = np.random.RandomState(shape[1] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    if cls_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    mdl = getattr(pm, cls_name)(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=4)
+    assert mdl._ctx.path_name == "tiled"
+    o = getattr(oracle, cls_name + "Oracle")(V, num_bases=k)
+    o.W, o.H = W0.copy(), H0.copy()
+    o.factorize(niter=4)
+    tol = 5e-4 if cls_name == "SNMF" else 5e-5
+    assert rel_fro(mdl.W, o.W) < tol and rel_fro(mdl.H, o.H) < tol
+    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=2e-5)
