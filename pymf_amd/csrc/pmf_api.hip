@@ -1315,6 +1315,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_loop_ms = ms;
+  if (ce) for (int q = done; q < niter; ++q) ferr[q] = 0.0;   // as np.zeros(niter) leaves them (nmf.py:179-180)
   if (iters_done) *iters_done = done;
   return PMF_OK;
 }
