@@ -48,6 +48,8 @@ struct pmf_ctx {
   int algo = 0;
   int64_t m = 0, n = 0;
   int k = 0, device = 0, rank = 0, nranks = 1;
+  int nb = 1;                   // > 1: num_bases > 128 (NMF): KP = 128 nb, bases handled in blocks of 128
+  float* dW2 = nullptr;         // ... Den = W (H H^T), [mp][KP] (dW1 holds Num = V H^T)
   int64_t mp = 0;
   int np = 0, KP = 0, NT = 0;
   hipStream_t stream = nullptr;
@@ -174,8 +176,9 @@ void stat_end(pmf_ctx* c) {
 // ---- kernel launch helpers --------------------------------------------------------------
 template <int NT, int EPI>
 int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
-                   float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
+                   float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1, int64_t ldc = 0) {
   if (rows_p < 0) { rows_p = c->mp; mvalid = c->m; }
+  if (ldc == 0) ldc = 16 * NT;
   const float lamb = (float)c->lamb_w;
   const size_t smem = rowgemm_smem_bytes<NT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
@@ -188,7 +191,7 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
   const int ntiles = (int)(rows_p / 64);
   const int tpw = ntiles >= 8192 ? 8 : ntiles >= 2048 ? 4 : ntiles >= 1024 ? 2 : 1;   // consecutive tiles per workgroup
   hipLaunchKernelGGL((k_rowgemm<NT, EPI>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), smem, c->stream,
-                     A, lda, kdimA, B, ldb, W, G, C, lamb, mvalid, c->k, ntiles, tpw);
+                     A, lda, kdimA, B, ldb, W, G, C, ldc, lamb, mvalid, c->k, ntiles, tpw);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -313,6 +316,7 @@ int talloc(pmf_ctx* c, DevTemps& t, T** out, size_t count) {
 
 int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: dense V only");
+  if (c->nb > 1) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases <= 128");
   if (c->n > 1024) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= 1024 (the Gram matrix is n x n; pass the transposed problem for wide data)");
   if (c->k > c->n) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases exceeds the number of columns");
   const int n = (int)c->n, np = c->np, KP = c->KP, ld = np;
@@ -441,9 +445,48 @@ int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2)
   return PMF_OK;
 }
 
+
+// ---- num_bases > 128 (NMF only): the update rules in blocks of 128 bases on the NT = 8 kernels -------
+// W step (nmf.py:128-132): Num = V H^T and Den = W (H H^T) block by block into [mp][KP] buffers, then
+// one elementwise pass.  (P | S) (nmf.py:122-124 operands): per base block W_b^T V, and W_b^T W by the
+// same kernel with W in the place of V.
+int bigk_update_w(pmf_ctx* c) {
+  PMFCHK(ensure_gram(c, 0.0));
+  for (int b = 0; b < c->nb; ++b)
+    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dV, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
+                                         c->dW1 + b * 128, -1, -1, c->KP)));
+  for (int b = 0; b < c->nb; ++b)
+    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dW, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
+                                         c->dW2 + b * 128, -1, -1, c->KP)));
+  const int64_t count = c->mp * c->KP;
+  hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dW1, c->dW2, count);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+int bigk_ps(pmf_ctx* c) {
+  const int64_t ldp = (int64_t)c->np + c->KP;
+  for (int b = 0; b < c->nb; ++b) {
+    for (int pass = 0; pass < 2; ++pass) {                 // 0: W_b^T V -> P rows,  1: W_b^T W -> S rows
+      const float* X = pass == 0 ? c->dV : c->dW;
+      const int xn = pass == 0 ? c->np : c->KP;
+      dim3 grid((unsigned)c->nchunks, (unsigned)((xn + 255) / 256));
+      hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, c->dW + b * 128, (int64_t)c->KP,
+                         c->mp, c->rows_per_chunk, c->dSlab);
+      HIPCHK(c, hipGetLastError());
+      const int64_t cnt = (int64_t)128 * xn;
+      hipLaunchKernelGGL(k_reduce_slabs_block, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->dSlab,
+                         c->nchunks, 128, xn + 128, xn, c->dPS + (size_t)b * 128 * ldp + (pass == 0 ? 0 : c->np), ldp);
+      HIPCHK(c, hipGetLastError());
+    }
+  }
+  return PMF_OK;
+}
+
 int nmf_fused_pass(pmf_ctx* c);
 
 int nmf_update_w(pmf_ctx* c) {
+  if (c->nb > 1) return bigk_update_w(c);
   // The single hook on a fused-kernel shape runs the same one-pass kernel: W is updated and, for the
   // price of the second half of the pass, (W^T V | W^T W) of the new W is already there when
   // update_h() follows (it then costs one k x n sized kernel) -- 0.65 ms for the pair at cfg4
@@ -496,6 +539,7 @@ int launch_h_gram(pmf_ctx* c) {
 // NMF / BNMF: H step and G = H H^T in one launch.  false: not for this algorithm.
 bool nmf_h_gram(pmf_ctx* c, int* rc) {
   if (c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) return false;   // RNMF: generic k_nmf_h
+  if (c->nb > 1) return false;                                              // num_bases > 128: generic k_nmf_h
   const bool b = c->algo == PMF_ALGO_BNMF;
   switch (c->NT) {
     case 1: *rc = b ? launch_h_gram<1, true>(c) : launch_h_gram<1, false>(c); return true;
@@ -563,6 +607,7 @@ int h_step_from_ps(pmf_ctx* c) {
 }
 
 int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
+  if (c->nb > 1) return bigk_ps(c);
   if (c->v_csr) return csr_ps(c);
   PMFCHK(colgemm(c));
   return reduce_slabs(c, c->nchunks);
@@ -902,7 +947,17 @@ int trace_e2(pmf_ctx* c, double* e2_out) {   // needs ps_valid and vnorm_valid
   return PMF_OK;
 }
 
+int ensure_ps(pmf_ctx* c);
+
 int do_frobenius(pmf_ctx* c, double* out) {
+  if (c->nb > 1) {            // num_bases > 128: the residual through the trace identity (no MFMA residual kernel at that width)
+    PMFCHK(ensure_ps(c));
+    PMFCHK(ensure_vnorm(c));
+    double e2 = 0.0;
+    PMFCHK(trace_e2(c, &e2));
+    *out = std::sqrt(e2 > 0.0 ? e2 : 0.0);
+    return PMF_OK;
+  }
   if (c->v_csr || !c->ps_valid) return frobenius_direct(c, out);
   PMFCHK(ensure_vnorm(c));
   double e2 = 0.0;
@@ -976,7 +1031,9 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   *out = nullptr;
   if (algo < 0 || algo > 4) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF), 3 (BNMF) or 4 (RNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
-  if (k > 128) return fail(nullptr, PMF_EINVAL, "num_bases > 128 is not supported by this build");
+  if (k > 128 && algo != PMF_ALGO_NMF)
+    return fail(nullptr, PMF_EINVAL, "num_bases > 128 is supported for NMF only in this build");
+  if (k > 1024) return fail(nullptr, PMF_EINVAL, "num_bases > 1024 is not supported by this build");
   if (algo == PMF_ALGO_NMFALS && k > 64)
     return fail(nullptr, PMF_EINVAL, "NMFALS: num_bases > 64 is not supported by this build");
   if (n > (1 << 24)) return fail(nullptr, PMF_EINVAL, "n too large");
@@ -989,6 +1046,10 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   c->np = (int)round_up(n, 64);
   c->NT = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
   c->KP = 16 * c->NT;
+  if (k > 128) {                // blocks of 128 bases on the NT = 8 tiled kernels (bigk_* below)
+    c->nb = (int)((k + 127) / 128);
+    c->KP = 128 * c->nb;
+  }
   // 448 columns are not a panel count the wide (two waves per block) fused kernel takes: pad to 512
   if ((algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF) && c->NT <= 2 && c->np == 448) c->np = 512;
   int rc = [&]() -> int {
@@ -1008,7 +1069,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->nchunks = (int)std::min<int64_t>(want, blocks16);
     c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
-    c->fused_wgs = (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF)
+    c->fused_wgs = (c->nb == 1 && (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF))
                        ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     // dV [mp][np] is allocated by the first pmf_set_v_dense_f32 / pmf_fill_v_uniform: CSR and
@@ -1018,7 +1079,13 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     PMFCHK(dalloc(c, &c->dG, (size_t)c->KP * c->KP));
     PMFCHK(dalloc(c, &c->dGd, (size_t)c->KP * c->KP));
     PMFCHK(dalloc(c, &c->dPS, (size_t)ps_elems(c)));
-    PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
+    if (c->nb == 1) {
+      PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
+    } else {                    // one 128-base block at a time: [chunk][128][max(np, KP) + 128]
+      PMFCHK(dalloc(c, &c->dSlab, (size_t)c->nchunks * 128 * (std::max(c->np, c->KP) + 128)));
+      PMFCHK(dalloc(c, &c->dW1, (size_t)c->mp * c->KP));
+      PMFCHK(dalloc(c, &c->dW2, (size_t)c->mp * c->KP));
+    }
     PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
     PMFCHK(dalloc(c, &c->dScal, 8));
     PMFCHK(dalloc(c, &c->dGpart, (size_t)PMF_HGRAM_MAX_WGS * c->KP * c->KP));
@@ -1060,7 +1127,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
-                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm})
+                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);
@@ -1363,7 +1430,7 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
 // stream into two device tiles, so the copy of tile t+1 overlaps the kernels of tile t.
 int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
   if (!c) return PMF_EINVAL;
-  if (c->algo != PMF_ALGO_NMF) return fail(c, PMF_EINVAL, "pmf_stream_*: NMF contexts only");
+  if (c->algo != PMF_ALGO_NMF || c->nb > 1) return fail(c, PMF_EINVAL, "pmf_stream_*: NMF contexts with num_bases <= 128 only");
   if (!c->have_w || !c->have_h) return fail(c, PMF_EINVAL, "pmf_stream_begin: W and H must be set");
   if (max_tile_rows < 1) return fail(c, PMF_EINVAL, "pmf_stream_begin: max_tile_rows must be >= 1");
   HIPCHK(c, hipSetDevice(c->device));

@@ -132,7 +132,7 @@ template <int NT, int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, int64_t lda, int kdimA,
                                                  const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ W, const float* __restrict__ G,
-                                                 float* __restrict__ C, float lamb,
+                                                 float* __restrict__ C, int64_t ldc, float lamb,
                                                  int64_t mvalid, int kvalid, int ntiles, int tpw) {
   constexpr int KP = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) num[nt][j] = C[(rbase + j) * KP + 16 * nt + i];
+        for (int j = 0; j < 4; ++j) num[nt][j] = C[(rbase + j) * ldc + 16 * nt + i];
     } else {
       tile_gemm_nt<NT>(num, A + row0 * lda, lda, B, ldb, kdimA, sa, sb, st);
     }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+        for (int j = 0; j < 4; ++j) C[(rbase + j) * ldc + 16 * nt + i] = num[nt][j];
     }
 
     if (EPI != EPI_STORE) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) C[(rbase + j) * KP + 16 * nt + i] = num[nt][j];
+        for (int j = 0; j < 4; ++j) C[(rbase + j) * ldc + 16 * nt + i] = num[nt][j];
     }
     __syncthreads();                                       // LDS panels free for the next tile
   }
@@ -474,4 +474,24 @@ __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int6
   if (lane == 0) wsum[wv] = tot;
   __syncthreads();
   if (tid == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---- num_bases > 128 (NMF): the bases are handled in blocks of 128 by the NT = 8 kernels above ----
+// out[r * out_ld + c] = sum over slabs of slab[s][r][c]  (r < rows, c < ncols; slab rows have src_ld floats)
+__global__ __launch_bounds__(256) void k_reduce_slabs_block(const float* __restrict__ slab, int nslabs, int rows,
+                                                            int src_ld, int ncols, float* __restrict__ out,
+                                                            int64_t out_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * ncols) return;
+  const int r = (int)(idx / ncols), c = (int)(idx % ncols);
+  double s = 0.0;
+  for (int sl = 0; sl < nslabs; ++sl) s += (double)slab[((int64_t)sl * rows + r) * src_ld + c];
+  out[(int64_t)r * out_ld + c] = (float)s;
+}
+
+// W <- (W * Num) / (Den + 1e-9), elementwise over [rows][ld] (pymf/nmf.py:128-132); the zero padding stays 0
+__global__ __launch_bounds__(256) void k_nmf_w_elem(float* __restrict__ W, const float* __restrict__ Num,
+                                                    const float* __restrict__ Den, int64_t count) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < count) W[q] = (W[q] * Num[q]) / (Den[q] + PMF_EPS_DEN);
 }

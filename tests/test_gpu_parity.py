@@ -552,3 +552,24 @@ def test_tiled_kernels_vs_oracle(pm, cls_name, shape, k):
     tol = 5e-4 if cls_name == "SNMF" else 5e-5
     assert rel_fro(mdl.W, o.W) < tol and rel_fro(mdl.H, o.H) < tol
     np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=2e-5)
+
+
+@pytest.mark.parametrize("shape,k", [((2000, 300), 200), ((1500, 500), 129), ((700, 900), 300), ((3000, 64), 256)])
+def test_nmf_more_than_128_bases(pm, shape, k):
+    """num_bases > 128 (NMF): blocks of 128 bases on the tiled kernels; error through the trace identity."""
+    from oracle import NMFOracle
+    rs = np.random.RandomState(k)
+    V = rs.random_sample(shape).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    mdl = pm.NMF(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=4)
+    o = NMFOracle(V, num_bases=k)
+    o.W, o.H = W0.copy(), H0.copy()
+    o.factorize(niter=4)
+    assert rel_fro(mdl.W, o.W) < TOL_X and rel_fro(mdl.H, o.H) < TOL_X
+    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=5e-5)       # trace identity only at this width
+    mdl.update_w(); o.update_w()
+    mdl.update_h(); o.update_h()
+    assert rel_fro(mdl.W, o.W) < TOL_X and rel_fro(mdl.H, o.H) < TOL_X
+    assert abs(mdl.frobenius_norm() - o.frobenius_norm()) <= 5e-5 * o.frobenius_norm()
