@@ -459,7 +459,8 @@ int bigk_update_w(pmf_ctx* c) {
     PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dW, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
                                          c->dW2 + b * 128, -1, -1, c->KP)));
   const int64_t count = c->mp * c->KP;
-  hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dW1, c->dW2, count);
+  hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dW1, c->dW2, count,
+                     c->algo == PMF_ALGO_BNMF ? 1 : 0, (float)c->lamb_w);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -1031,8 +1032,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   *out = nullptr;
   if (algo < 0 || algo > 4) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF), 3 (BNMF) or 4 (RNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
-  if (k > 128 && algo != PMF_ALGO_NMF)
-    return fail(nullptr, PMF_EINVAL, "num_bases > 128 is supported for NMF only in this build");
+  if (k > 128 && algo != PMF_ALGO_NMF && algo != PMF_ALGO_BNMF)
+    return fail(nullptr, PMF_EINVAL, "num_bases > 128 is supported for NMF and BNMF only in this build");
   if (k > 1024) return fail(nullptr, PMF_EINVAL, "num_bases > 1024 is not supported by this build");
   if (algo == PMF_ALGO_NMFALS && k > 64)
     return fail(nullptr, PMF_EINVAL, "NMFALS: num_bases > 64 is not supported by this build");
@@ -1095,7 +1096,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->ferr_cap = 4096;
     PMFCHK(dalloc(c, &c->dFerr, (size_t)c->ferr_cap));
     if (algo == PMF_ALGO_RNMF) PMFCHK(dalloc(c, &c->dD, (size_t)c->mp * c->np));
-    if (algo != PMF_ALGO_NMF) {
+    if (algo != PMF_ALGO_NMF && !c->dW1) {
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dGinvT, (size_t)c->KP * c->KP));
     }

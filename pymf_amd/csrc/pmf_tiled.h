@@ -490,8 +490,18 @@ __global__ __launch_bounds__(256) void k_reduce_slabs_block(const float* __restr
 }
 
 // W <- (W * Num) / (Den + 1e-9), elementwise over [rows][ld] (pymf/nmf.py:128-132); the zero padding stays 0
+// bnmf != 0: the BNMF rule W *= (Num + 3 l W^2) / (Den + 2 l W^3 + l W + 1e-9) (bnmf.py:87-90)
 __global__ __launch_bounds__(256) void k_nmf_w_elem(float* __restrict__ W, const float* __restrict__ Num,
-                                                    const float* __restrict__ Den, int64_t count) {
+                                                    const float* __restrict__ Den, int64_t count, int bnmf,
+                                                    float lamb) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q < count) W[q] = (W[q] * Num[q]) / (Den[q] + PMF_EPS_DEN);
+  if (q >= count) return;
+  const float w = W[q];
+  if (bnmf) {
+    const float w1 = Num[q] + (3.0f * lamb) * (w * w);
+    const float w2 = ((Den[q] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
+    W[q] = w * (w1 / w2);
+  } else {
+    W[q] = (w * Num[q]) / (Den[q] + PMF_EPS_DEN);
+  }
 }

@@ -94,3 +94,19 @@ def test_bnmf_every_fused_shape_class_vs_oracle(pm, shape, k):
     o.factorize(niter=4)
     assert rel_fro(mdl.W, o.W) < 5e-5 and rel_fro(mdl.H, o.H) < 5e-5
     np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=2e-5)
+
+
+def test_bnmf_more_than_128_bases(pm):
+    from oracle import BNMFOracle
+    rs = np.random.RandomState(12)
+    V = (rs.random_sample((1200, 260)) < 0.3).astype(np.float32)
+    W0, H0 = rs.random_sample((1200, 200)), rs.random_sample((200, 260))
+    mdl = pm.BNMF(V, num_bases=200)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=4)
+    o = BNMFOracle(V, num_bases=200)
+    o.W, o.H = W0.copy(), H0.copy()
+    o.factorize(niter=4)
+    assert rel_fro(mdl.W, o.W) < 5e-5 and rel_fro(mdl.H, o.H) < 5e-5
+    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=5e-5)
+    assert abs(mdl._lamb_W - o._lamb_W) < 1e-12
