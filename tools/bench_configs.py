@@ -37,6 +37,8 @@ if __name__ == "__main__":
         run("cfg2 NMF 65536x512 k=32", _lib.ALGO_NMF, 65536, 512, 32, 200)
     if "cfg3" in which:
         run("cfg3 NMFALS 262144x1024 k=64", _lib.ALGO_NMFALS, 262144, 1024, 64, 3)
+    if "cfg5shard" in which:
+        run("cfg5 SNMF CSR 524288x128 k=128 (1/8 shard)", _lib.ALGO_SNMF, 524288, 128, 128, 20, csr_density=0.01)
     if "cfg5" in which:
         run("cfg5 SNMF CSR 524288x128 k=128 (1/8 shard)", _lib.ALGO_SNMF, 524288, 128, 128, 20, csr_density=0.01)
         run("cfg5 SNMF CSR 4194304x128 k=128 (1 GPU)", _lib.ALGO_SNMF, 4194304, 128, 128, 10, csr_density=0.01)
