@@ -44,8 +44,20 @@ for trial in range(ntrial):
             tolw, tolf = 5e-3, 5e-4          # the soft threshold is discontinuous at float32 rounding
         else:
             cls = getattr(pymf_amd, name); orc = {"NMF": NMFOracle, "SNMF": SNMFOracle, "BNMF": BNMFOracle}[name]
-            a = cls(V, num_bases=k); a.W, a.H = W0.copy(), H0.copy(); a.factorize(niter=3)
-            o = orc(Vo, num_bases=k); o.W, o.H = W0.copy(), H0.copy(); o.factorize(niter=3)
+            a = cls(V, num_bases=k); a.W, a.H = W0.copy(), H0.copy()
+            o = orc(Vo, num_bases=k); o.W, o.H = W0.copy(), H0.copy()
+            # two calls with random niter / flags (the reference's implicit resume)
+            for call in range(2):
+                niter = int(rs.randint(1, 13))
+                flags = dict(compute_w=bool(rs.random_sample() < 0.8), compute_h=bool(rs.random_sample() < 0.8),
+                             compute_err=bool(call == 1 or rs.random_sample() < 0.7))
+                a.factorize(niter=niter, **flags)
+                o.factorize(niter=niter, **flags)
+                if flags["compute_err"] and len(a.ferr) != len(o.ferr):
+                    # a convergence decision on |ferr[i] - ferr[i-1]| / n < 1e-8 taken at float32 resolution
+                    print(m, n, k, kind, name, "note: stopped after %d vs %d iterations" % (len(a.ferr), len(o.ferr)))
+                    o.W, o.H = a.W.copy().astype(o.W.dtype), a.H.copy().astype(o.H.dtype)
+                    o.ferr = np.asarray(a.ferr).copy()
             tolw, tolf = (2e-5, 2e-6) if name != "SNMF" else (2e-3, 2e-5)
         if not (np.isfinite(o.W).all() and np.isfinite(o.H).all()) or np.linalg.norm(Vo) == 0:
             print(m, n, k, kind, name, "skipped: the reference itself divides by zero here (no epsilon) / V = 0")
