@@ -639,6 +639,7 @@ int nmf_update_h(pmf_ctx* c) {
 // all-rank (P | S) of the NEW W is left in dPS.
 int nmf_fused_pass(pmf_ctx* c) {
   c->ps_valid = false;
+  c->trace_ready = false;       // <P,H>, <S,G> belong to the old W
   const float* Gsrc = c->dG;
   int ngp = 0;
   if (c->g_valid && c->g_parts > 0) { Gsrc = c->dGpart; ngp = c->g_parts; }   // partial sums, added by the kernel
@@ -700,6 +701,7 @@ int snmf_inverse(pmf_ctx* c);
 // SNMF: update_w and the partials of update_h in ONE pass over V (dense data, fused shapes).
 int snmf_fused_pass(pmf_ctx* c) {
   c->ps_valid = false;
+  c->trace_ready = false;
   PMFCHK(snmf_inverse(c));
   stat_begin(c);
   const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dH, c->dGinvT, c->mp,
@@ -861,6 +863,7 @@ int als_update_h(pmf_ctx* c) {
 
 int do_update_w(pmf_ctx* c) {
   c->ps_valid = false;
+  c->trace_ready = false;
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_w(c);
     case PMF_ALGO_BNMF: return nmf_update_w(c);

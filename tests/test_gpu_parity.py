@@ -573,3 +573,27 @@ def test_nmf_more_than_128_bases(pm, shape, k):
     mdl.update_h(); o.update_h()
     assert rel_fro(mdl.W, o.W) < TOL_X and rel_fro(mdl.H, o.H) < TOL_X
     assert abs(mdl.frobenius_norm() - o.frobenius_norm()) <= 5e-5 * o.frobenius_norm()
+
+
+@pytest.mark.parametrize("cls_name", ["NMF", "BNMF", "SNMF"])
+def test_error_after_a_w_only_step_is_not_stale(pm, cls_name):
+    """factorize() leaves the trace terms of its last H step behind; a later update_w() / W-only loop
+    changes W (and, on fused shapes, recomputes W^T V | W^T W): the error must come from the NEW state."""
+    import oracle
+    rs = np.random.RandomState(2)
+    V = rs.random_sample((200, 65)).astype(np.float32)
+    if cls_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    k = 12
+    W0, H0 = rs.random_sample((200, k)), rs.random_sample((k, 65))
+    a = getattr(pm, cls_name)(V, num_bases=k); a.W, a.H = W0.copy(), H0.copy()
+    o = getattr(oracle, cls_name + "Oracle")(V, num_bases=k); o.W, o.H = W0.copy(), H0.copy()
+    a.factorize(niter=5); o.factorize(niter=5)
+    a.factorize(niter=7, compute_h=False); o.factorize(niter=7, compute_h=False)
+    # SNMF's W step with H fixed is a closed form: the error repeats and the loop stops at i == 2
+    assert len(a.ferr) == len(o.ferr) == (2 if cls_name == "SNMF" else 7)
+    np.testing.assert_allclose(a.ferr, o.ferr, rtol=2e-5)
+    tol = 5e-4 if cls_name == "SNMF" else 5e-5
+    assert rel_fro(a.W, o.W) < tol
+    a.update_w(); o.update_w()
+    assert abs(a.frobenius_norm() - o.frobenius_norm()) <= 2e-5 * o.frobenius_norm()
