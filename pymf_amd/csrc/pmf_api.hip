@@ -959,7 +959,22 @@ int do_frobenius(pmf_ctx* c, double* out) {
     PMFCHK(ensure_vnorm(c));
     double e2 = 0.0;
     PMFCHK(trace_e2(c, &e2));
-    *out = std::sqrt(e2 > 0.0 ? e2 : 0.0);
+    if (e2 > 1e-3 * c->vnorm2) { *out = std::sqrt(e2); return PMF_OK; }
+    // the identity cancels: direct pass (plain FMAs; num_bases > 128 has no MFMA residual kernel)
+    const int gx = c->np / 64, gy = (int)(c->mp / 64);
+    const int nb2 = gx * gy;
+    double* part = nullptr;
+    HIPCHK(c, hipMalloc(&part, (size_t)nb2 * sizeof(double)));
+    hipLaunchKernelGGL(k_resid_bigk, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
+                       c->KP, c->dH, (int64_t)c->np, part);
+    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, part, nb2, c->dScal);
+    if (c->comm) ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream);
+    double ss = 0.0;
+    hipError_t e1 = hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2s = hipStreamSynchronize(c->stream);
+    (void)hipFree(part);
+    if (e1 != hipSuccess || e2s != hipSuccess) return fail(c, PMF_EHIP, "direct residual (num_bases > 128) failed");
+    *out = std::sqrt(ss);
     return PMF_OK;
   }
   if (c->v_csr || !c->ps_valid) return frobenius_direct(c, out);

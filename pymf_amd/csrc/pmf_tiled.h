@@ -505,3 +505,52 @@ __global__ __launch_bounds__(256) void k_nmf_w_elem(float* __restrict__ W, const
     W[q] = (w * Num[q]) / (Den[q] + PMF_EPS_DEN);
   }
 }
+
+// Direct residual for num_bases > 128: part[block] = sum((V - W H)^2) over a 64 x 64 tile, plain float32
+// FMAs with LDS staging (a fallback for nearly exact fits, where the trace identity cancels -- not a hot path).
+__global__ __launch_bounds__(256) void k_resid_bigk(const float* __restrict__ V, int64_t ldv,
+                                                    const float* __restrict__ W, int KP,
+                                                    const float* __restrict__ H, int64_t ldh,
+                                                    double* __restrict__ part) {
+  __shared__ float Ws[64][17];
+  __shared__ float Hs[16][64];
+  __shared__ double wsum[4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t r0 = (int64_t)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int k0 = 0; k0 < KP; k0 += 16) {
+    for (int q = tid; q < 64 * 16; q += 256) Ws[q >> 4][q & 15] = W[(r0 + (q >> 4)) * KP + k0 + (q & 15)];
+    for (int q = tid; q < 16 * 64; q += 256) Hs[q >> 6][q & 63] = H[(int64_t)(k0 + (q >> 6)) * ldh + c0 + (q & 63)];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float wv[4], hv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wv[a] = Ws[ty + 16 * a][kk];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) hv[b] = Hs[kk][tx + 16 * b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(wv[a], hv[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float r = V[(r0 + ty + 16 * a) * ldv + c0 + tx + 16 * b] - acc[a][b];
+      s += (double)r * (double)r;
+    }
+  s = wave_sum_f64(s);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
