@@ -39,8 +39,9 @@ for trial in range(ntrial):
     W0 = rs.random_sample((m, k)); H0 = rs.random_sample((k, n))
     try:
         if name == "RNMF":
-            np.random.seed(trial); a = RNMF(V, num_bases=k, lamb=0.7); a.factorize(niter=3)
-            np.random.seed(trial); o = RNMFOracle(Vo, num_bases=k, lamb=0.7); o.factorize(niter=3)
+            fl = dict(compute_w=bool(rs.random_sample() < 0.8), compute_h=bool(rs.random_sample() < 0.8))
+            np.random.seed(trial); a = RNMF(V, num_bases=k, lamb=0.7); a.factorize(niter=3); a.factorize(niter=4, **fl)
+            np.random.seed(trial); o = RNMFOracle(Vo, num_bases=k, lamb=0.7); o.factorize(niter=3); o.factorize(niter=4, **fl)
             tolw, tolf = 5e-3, 5e-4          # the soft threshold is discontinuous at float32 rounding
         else:
             cls = getattr(pymf_amd, name); orc = {"NMF": NMFOracle, "SNMF": SNMFOracle, "BNMF": BNMFOracle}[name]
