@@ -22,7 +22,7 @@ def nnqp_solve(HA, FA, max_outer=None):
 
     Lawson-Hanson NNLS expressed on the Gram matrix (HA = A'A, -FA = A'b).
     """
-    HA = np.asarray(HA, dtype=np.float64)
+    HA = np.atleast_2d(np.asarray(HA, dtype=np.float64))   # np.float64(1 x 1 array) is a scalar (num_bases = 1)
     f = -np.asarray(FA, dtype=np.float64).ravel()      # A'b
     k = f.shape[0]
     x = np.zeros(k)
