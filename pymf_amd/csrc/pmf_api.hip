@@ -1288,7 +1288,11 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   // the convergence test of nmf.py:134-139 run on the device (k_conv_check) and a raised stop flag
   // turns every later launch of the chunk into a no-op, so the results are those of the ordinary
   // loop while the host reads back once per chunk instead of once per iteration.
-  const bool can_free_run = fused && ce && c->algo != PMF_ALGO_RNMF;   // NMF, BNMF, SNMF on the fused kernel
+  // ... and the fixed-basis loop (compute_w = False, nmf.py:56-65: coefficients for an existing basis):
+  // (W^T V | W^T W) is formed once, every further iteration is the H-step kernel alone
+  const bool h_only = !cw && ch && ce && c->nb == 1 && !c->v_csr &&
+                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF);
+  const bool can_free_run = (fused && ce && c->algo != PMF_ALGO_RNMF) || h_only;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
@@ -1299,7 +1303,12 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       int lrc = PMF_OK;
       for (int j = 0; j < chunk && lrc == PMF_OK; ++j) {
         c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + j + 1 < niter;
-        lrc = c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c);
+        if (h_only) {
+          lrc = ensure_ps(c);                               // current since the first iteration (W is fixed)
+          if (lrc == PMF_OK) lrc = h_step_from_ps(c);
+        } else {
+          lrc = c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c);
+        }
         const double* tt = c->dScal + 2;                  // k_nmf_h_gram left <P,H>, <S,G> there ...
         int ntt = 1;
         if (lrc == PMF_OK && c->trace_ready && c->trace_parts > 0) { tt = c->dT1part; ntt = c->trace_parts; }   // ... or as pairs

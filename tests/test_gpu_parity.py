@@ -597,3 +597,43 @@ def test_error_after_a_w_only_step_is_not_stale(pm, cls_name):
     assert rel_fro(a.W, o.W) < tol
     a.update_w(); o.update_w()
     assert abs(a.frobenius_norm() - o.frobenius_norm()) <= 2e-5 * o.frobenius_norm()
+
+
+@pytest.mark.parametrize("algo_name", ["NMF", "BNMF"])
+def test_free_running_fixed_basis_loop_matches_stepwise_loop(pm, algo_name):
+    """factorize(compute_w=False) -- coefficients for an existing basis (nmf.py:56-65) -- free-runs as well
+    (one H-step kernel per iteration): same outcome as one C call per iteration."""
+    from pymf_amd import _lib
+    algo = getattr(_lib, "ALGO_" + algo_name)
+    rs = np.random.RandomState(5)
+    m, n, k = 3000, 192, 24
+    V = rs.random_sample((m, n)).astype(np.float32)
+    if algo_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    for niter, eps in ((30, 1e-8), (80, 1e-4), (300, 1e-6)):
+        outs = []
+        for stepwise in (False, True):
+            c = _lib.Context(algo, m, n, k)
+            c.set_v_dense(V); c.set_w(W0); c.set_h(H0)
+            if algo_name == "BNMF":
+                c.set_lambda(1.0 / niter, 1.0 / niter)
+            if not stepwise:
+                f, done, conv = c.factorize(niter, compute_w=False, conv_eps=eps)
+                f = list(f[:done])
+            else:
+                f, done, conv = [], 0, -1
+                for i in range(niter):
+                    f1, _, _ = c.factorize(1, compute_w=False, conv_eps=0.0)
+                    f.append(f1[0]); done += 1
+                    if i > 1 and abs(f[i] - f[i - 1]) / n < eps:
+                        conv = i
+                        break
+            outs.append((done, conv, np.array(f), c.get_h(), c.get_w(), c.get_lambda() if algo_name == "BNMF" else None))
+            c.close()
+        assert outs[0][:2] == outs[1][:2], (niter, eps, outs[0][:2], outs[1][:2])
+        np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-12)
+        np.testing.assert_array_equal(outs[0][3], outs[1][3])
+        np.testing.assert_array_equal(outs[0][4], W0)
+        assert outs[0][5] == outs[1][5]
