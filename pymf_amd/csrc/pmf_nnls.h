@@ -70,10 +70,20 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {   // src
   return __hiloint2double(hi, lo);
 }
 
+// min / max over the wave, as wave_sum_f64: DPP butterfly inside the rows of 16, the four row results as scalars
 __device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmin(v, dpp_mov_f64<0xB1>(v));
+  v = fmin(v, dpp_mov_f64<0x4E>(v));
+  v = fmin(v, dpp_mov_f64<0x141>(v));
+  v = fmin(v, dpp_mov_f64<0x140>(v));
+  return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  v = fmax(v, dpp_mov_f64<0xB1>(v));
+  v = fmax(v, dpp_mov_f64<0x4E>(v));
+  v = fmax(v, dpp_mov_f64<0x141>(v));
+  v = fmax(v, dpp_mov_f64<0x140>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 template <int KR>   // variable slots per problem: 16, 32 or 64 (k <= KR)
@@ -93,8 +103,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
   // stopping tolerance on the dual: 10 eps k max|HA| (same scale as the float64 oracle)
   double hmax = 0.0;
   if (t < k) hmax = sH[t * KR + t];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) hmax = fmax(hmax, __shfl_xor(hmax, o, 64));
+  hmax = wave_max_f64(hmax);
   const double tol = 2.220446049250313e-15 * (double)k * hmax;
   const bool active = t < k;
   const unsigned long long tbit = 1ull << t;
@@ -174,9 +183,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
         if (!(alpha >= 0.0)) alpha = 0.0;
         if (alpha > 1.0) alpha = 1.0;
         x = pin ? fma(alpha, s - x, x) : 0.0;
-        double xmax = x;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o, 64));
+        const double xmax = wave_max_f64(x);
         const double tiny = 1e-15 * fmax(1.0, xmax);
         // leave: everything that hit zero (at least the variable that defined alpha)
         unsigned long long rm = __ballot(pin && (x <= tiny || (bad && ratio == alpha)));
@@ -239,16 +246,10 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
 
     for (int outer = 0; outer < 3 * k + 3; ++outer) {
       // ---- most violated dual: j = argmax w over the active (zero) set ----
-      double best = (active && !((pm | ban) & tbit)) ? w : -1.0e300;
-      int bi = t;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      }
+      const double mine = (active && !((pm | ban) & tbit)) ? w : -1.0e300;
+      const double best = wave_max_f64(mine);
       if (!(best > tol)) break;
-      const int j = __builtin_amdgcn_readfirstlane(bi);
+      const int j = (int)__builtin_ctzll(__ballot(mine == best));      // lowest index among ties
       PMF_NNQP_TICK(0);
       if (!border(j, 1e-13)) { PMF_NNQP_TICK(3); continue; }
       inner();
