@@ -18,6 +18,9 @@ for t in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     try:
         a = cls(V, num_bases=k); a.W, a.H = W0.copy(), H0.copy(); a.factorize(niter=niter)
         o = NMFALSOracle(V, num_bases=k); o.W, o.H = W0.copy(), H0.copy(); o.factorize(niter=niter)
+        if max(np.linalg.cond(o.W.T @ o.W), np.linalg.cond(o.H @ o.H.T)) > 1e8:
+            print(m, n, k, cls.__name__, niter, "skipped: a Gram matrix is singular, the QP minimisers are not unique")
+            continue
         ew = np.abs(a.W - o.W).max() / max(1.0, np.abs(o.W).max()); eh = np.abs(a.H - o.H).max() / max(1.0, np.abs(o.H).max())
         rec = np.linalg.norm(a.W @ a.H - o.W @ o.H) / max(np.linalg.norm(o.W @ o.H), 1e-30)
         flag = "" if (rec < 1e-4 and (max(ew, eh) < 2e-3)) else "  <<<<<"
