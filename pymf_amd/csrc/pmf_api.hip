@@ -241,7 +241,7 @@ int allreduce_ps(pmf_ctx* c) {
 // ---- CSR (SNMF) ----------------------------------------------------------------------------
 int csr_w(pmf_ctx* c) {   // W = V (H^T inv(H H^T)); dGinvT is ready, dW1 holds M (np x KP)
   const int E = c->np * c->KP;
-  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dH,
+  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
                      (int64_t)c->np, c->np, c->KP, c->dGinvT, c->dW1);
   HIPCHK(c, hipGetLastError());
   const unsigned blocks = (unsigned)std::min<int64_t>((c->mp + 3) / 4, 256 * 16);
@@ -785,7 +785,7 @@ int snmf_csr_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
   PMFCHK(snmf_inverse(c));
   const int E = c->np * c->KP;
-  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dH,
+  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
                      (int64_t)c->np, c->np, c->KP, c->dGinvT, c->dW1);
   HIPCHK(c, hipGetLastError());
   int dev = 0, cus = 256;

@@ -9,14 +9,24 @@
 #include "pmf_dev.h"
 
 // M[col][kk'] = sum_kk H[kk][col] * GinvT[kk'][kk]      (GinvT[a][b] = inv[b][a])
-__global__ void k_snmf_m(const float* __restrict__ H, int64_t ldh, int n_cols, int KP,
-                         const float* __restrict__ GinvT, float* __restrict__ M) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n_cols * KP) return;
-  const int col = q / KP, kp = q % KP;
-  float s = 0.f;
-  for (int kk = 0; kk < KP; ++kk) s = fmaf(H[(int64_t)kk * ldh + col], GinvT[kp * KP + kk], s);
-  M[(int64_t)col * KP + kp] = s;
+// grid = (n_cols / 16, KP / 16), 256 threads = one 16 x 16 tile of M; both operands go through LDS in
+// 16 x 16 tiles read along their contiguous dimension.
+__global__ __launch_bounds__(256) void k_snmf_m(const float* __restrict__ H, int64_t ldh, int n_cols, int KP,
+                                                const float* __restrict__ GinvT, float* __restrict__ M) {
+  __shared__ float hs[16][17];     // [kk][col]
+  __shared__ float gs[16][17];     // [kp][kk]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int col0 = blockIdx.x * 16, kp0 = blockIdx.y * 16;
+  float s = 0.f;                   // M[col0 + ty][kp0 + tx]
+  for (int k0 = 0; k0 < KP; k0 += 16) {
+    hs[ty][tx] = H[(int64_t)(k0 + ty) * ldh + col0 + tx];
+    gs[ty][tx] = GinvT[(kp0 + ty) * KP + k0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) s = fmaf(hs[kk][ty], gs[tx][kk], s);
+    __syncthreads();
+  }
+  M[(int64_t)(col0 + ty) * KP + kp0 + tx] = s;
 }
 
 // W[row][:] = sum over the row's non-zeros of val * M[col][:]; one wave per row, lanes <-> bases.
