@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 M_FULL, N_FULL, K_FULL = 1048576, 256, 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
+PREROLL_MS_DEFAULT = 300.0   # measured (gpurun_out/r2a, profiles/r02_ramp.md): a fresh box needs ~30 launches to reach its clock
 
 
 def gen_rows(seed_state, m_total, ncols, lo, hi, chunk=65536):
@@ -119,6 +120,10 @@ def main():
     ap.add_argument("--cols", dest="n", type=int, default=N_FULL)
     ap.add_argument("--bases", dest="k", type=int, default=K_FULL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-ms", type=float, default=PREROLL_MS_DEFAULT,
+                    help="disclosed device pre-conditioning: untimed iterations of the same loop for about this "
+                         "many ms of device time BEFORE the W counted warm-up steps (the chip's clock/power "
+                         "state needs more than 5 launches to settle on a fresh box); 0 disables")
     ap.add_argument("--fill", choices=["numpy", "device"], default="numpy",
                     help="numpy: BASELINE.md protocol; device: counter-based fill (fast start-up)")
     ap.add_argument("--debug-share-gpu", action="store_true",
@@ -152,6 +157,16 @@ def main():
         ctx.fill_w_uniform(42, lo)
         ctx.fill_h_uniform(43)
 
+    # ---- disclosed pre-conditioning (untimed, reported as "preroll_ms" / "preroll_iters") ----
+    preroll_iters, preroll_ms = 0, 0.0
+    if args.preroll_ms > 0:
+        ctx.factorize(2, compute_err=False)
+        per = max(ctx.last_loop_ms() / 2.0, 1e-3)
+        preroll_iters = int(min(max(args.preroll_ms / per, 1), 20000))
+        ctx.factorize(preroll_iters, compute_err=False)
+        preroll_ms = ctx.last_loop_ms()
+        preroll_iters += 2
+
     # ---- warm-up (untimed) ----
     _, done, _ = ctx.factorize(args.warmup, compute_err=False)
     assert done == args.warmup
@@ -168,6 +183,8 @@ def main():
     assert done == args.steps and conv < 0, "timed run was shortened (%d of %d)" % (done, args.steps)
     dt = dist.allreduce_max(dt)
     stats = ctx.kernel_stats()
+    launch_ms = np.sort(ctx.kernel_launch_ms())
+    first_ms = [round(float(x), 4) for x in ctx.kernel_launch_ms()[:5]]
     ctx.profile_enable(False)
 
     # secondary: the API-default compute_err=True rate (not the headline value)
@@ -198,6 +215,8 @@ def main():
             "n_gpus": w.size,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preroll_ms": preroll_ms,
+            "preroll_iters": preroll_iters,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
@@ -214,6 +233,10 @@ def main():
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": stats["name"], "launches": stats["launches"],
                          "mean_kernel_ms": stats["mean_ms"],
+                         "min_kernel_ms": float(launch_ms[0]) if len(launch_ms) else None,
+                         "median_kernel_ms": float(np.median(launch_ms)) if len(launch_ms) else None,
+                         "max_kernel_ms": float(launch_ms[-1]) if len(launch_ms) else None,
+                         "first_launches_ms": first_ms,
                          "flops_per_launch": stats["flops_per_launch"],
                          "algorithmic_bytes_per_launch": stats["bytes_per_launch"],
                          "achieved_hbm_GBs": stats["bytes_per_launch"] / (stats["mean_ms"] * 1e-3) / 1e9

@@ -162,6 +162,10 @@ int pmf_profile_enable(pmf_ctx* ctx, int32_t on);
 int pmf_kernel_stats(pmf_ctx* ctx, const char** name, int64_t* launches, double* mean_ms,
                      double* flops_per_launch, double* bytes_per_launch);
 
+/* The individual launch durations behind pmf_kernel_stats' mean, in launch order: out_ms[0..min(cap,*count))
+ * (ms, HIP events on the library's stream); *count = launches recorded since the last pmf_profile_enable. */
+int pmf_kernel_launch_ms(pmf_ctx* ctx, double* out_ms, int64_t cap, int64_t* count);
+
 int pmf_synchronize(pmf_ctx* ctx);
 
 /* Introspection used by tests: which code path update_w/update_h take for this shape.

@@ -61,6 +61,7 @@ SYMBOLS = [
     ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
                                     _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                                     _c.POINTER(_c.c_double)]),
+    ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
     ("pmf_path_name", _c.c_char_p, [_ctx]),
 ]
@@ -274,6 +275,13 @@ class Context(object):
                                              ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
         return dict(name=(name.value or b"").decode(), launches=int(n.value), mean_ms=float(ms.value),
                     flops_per_launch=float(fl.value), bytes_per_launch=float(by.value))
+
+    def kernel_launch_ms(self, cap=65536):
+        """Durations (ms) of the dominant kernel's launches since profile_enable(), in launch order."""
+        out = np.zeros(int(cap), dtype=np.float64)
+        n = ctypes.c_int64(0)
+        self._chk(self._lib.pmf_kernel_launch_ms(self._h, out.ctypes.data, int(cap), ctypes.byref(n)))
+        return out[:min(int(n.value), int(cap))]
 
     def synchronize(self):
         self._chk(self._lib.pmf_synchronize(self._h))

@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "pmf_api.hip")
 OUT = os.path.join(HERE, "libpymf_hip.so")
-DEPS = ["pmf_api.hip", "pmf_dev.h", "pmf_small.h", "pmf_tiled.h", "pmf_fused.h", "pmf_nnls.h",
-        "pmf_csr.h", os.path.join("..", "..", "include", "pymf_hip.h")]
+DEPS = sorted(f for f in os.listdir(HERE) if f.endswith((".h", ".hip"))) + \
+       [os.path.join("..", "..", "include", "pymf_hip.h")]
 
 
 def up_to_date():

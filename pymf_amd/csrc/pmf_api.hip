@@ -1643,6 +1643,20 @@ int pmf_kernel_stats(pmf_ctx* c, const char** name, int64_t* launches, double* m
   return PMF_OK;
 }
 
+int pmf_kernel_launch_ms(pmf_ctx* c, double* out_ms, int64_t cap, int64_t* count) {
+  if (!c || (cap > 0 && !out_ms)) return PMF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int64_t pairs = (int64_t)(c->stat.used / 2);
+  for (int64_t q = 0; q < pairs && q < cap; ++q) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->stat.ev[2 * q], c->stat.ev[2 * q + 1]));
+    out_ms[q] = ms;
+  }
+  if (count) *count = pairs;
+  return PMF_OK;
+}
+
 int pmf_synchronize(pmf_ctx* c) {
   if (!c) return PMF_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
