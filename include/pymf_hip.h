@@ -162,6 +162,16 @@ int pmf_profile_enable(pmf_ctx* ctx, int32_t on);
 int pmf_kernel_stats(pmf_ctx* ctx, const char** name, int64_t* launches, double* mean_ms,
                      double* flops_per_launch, double* bytes_per_launch);
 
+/* Host-only helper of the boundary (touches no device): an order-dependent 128-bit digest of `nbytes`
+ * bytes of caller memory, out2[0..1].  The reference always computes from the CURRENT contents of
+ * self.data / self.W / self.H (nmf.py:122-132); a host class that keeps device copies uses this to notice
+ * in-place edits (permutations included) and re-upload.  Multi-threaded, memory speed. */
+int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
+
+/* Forget everything derived from V (||V||^2, cached partial sums): for streamed `data` that the caller
+ * rebound or edited between calls. */
+int pmf_invalidate_v(pmf_ctx* ctx);
+
 /* The individual launch durations behind pmf_kernel_stats' mean, in launch order: out_ms[0..min(cap,*count))
  * (ms, HIP events on the library's stream); *count = launches recorded since the last pmf_profile_enable. */
 int pmf_kernel_launch_ms(pmf_ctx* ctx, double* out_ms, int64_t cap, int64_t* count);

@@ -17,7 +17,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PMF_LIB") or os.path.join(_HERE, "csrc", "libpymf_hip.so")   # PMF_LIB: A/B builds
 
-PMF_OK = 0
+PMF_OK, PMF_EINVAL, PMF_EHIP, PMF_ENCCL, PMF_ENOMEM = 0, -1, -2, -3, -4
 ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF, ALGO_RNMF = 0, 1, 2, 3, 4
 COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
 STREAM_RESID = 8
@@ -61,6 +61,8 @@ SYMBOLS = [
     ("pmf_kernel_stats", _c.c_int, [_ctx, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_int64),
                                     _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                                     _c.POINTER(_c.c_double)]),
+    ("pmf_host_checksum", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("pmf_invalidate_v", _c.c_int, [_ctx]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
     ("pmf_path_name", _c.c_char_p, [_ctx]),
@@ -70,7 +72,8 @@ _lib = None
 
 
 class PmfError(RuntimeError):
-    pass
+    """A negative status from libpymf_hip; `.code` is the PMF_E* value (include/pymf_hip.h)."""
+    code = None
 
 
 def load():
@@ -93,7 +96,9 @@ def load():
 def check(rc, ctx=None):
     if rc != PMF_OK:
         msg = load().pmf_last_error(ctx)
-        raise PmfError("libpymf_hip error %d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))
+        err = PmfError("libpymf_hip error %d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))
+        err.code = int(rc)
+        raise err
 
 
 def device_count():
@@ -108,6 +113,17 @@ def nccl_unique_id():
     buf = ctypes.create_string_buffer(NCCL_ID_BYTES)
     check(load().pmf_nccl_unique_id(buf))
     return buf.raw
+
+
+def host_checksum(a):
+    """(shape, dtype, 128-bit digest of the bytes) of a host array: the change detector of the host
+    classes (pmf_host_checksum; runs without a GPU).  Non-contiguous input is digested through a
+    contiguous copy."""
+    a = np.asarray(a)
+    c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    out = (ctypes.c_uint64 * 2)()
+    check(load().pmf_host_checksum(c.ctypes.data if c.size else None, c.nbytes, out))
+    return (a.shape, a.dtype.str, int(out[0]), int(out[1]))
 
 
 def _f32c(a):
@@ -275,6 +291,9 @@ class Context(object):
                                              ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
         return dict(name=(name.value or b"").decode(), launches=int(n.value), mean_ms=float(ms.value),
                     flops_per_launch=float(fl.value), bytes_per_launch=float(by.value))
+
+    def invalidate_v(self):
+        self._chk(self._lib.pmf_invalidate_v(self._h))
 
     def kernel_launch_ms(self, cap=65536):
         """Durations (ms) of the dominant kernel's launches since profile_enable(), in launch order."""

@@ -15,6 +15,7 @@ __all__ = ["BNMF"]
 
 
 class BNMF(NMF):
+    _SHIPPED = True
     _ALGO = _lib.ALGO_BNMF
     _LAMB_INCREASE_W = 1.1       # bnmf.py:76
     _LAMB_INCREASE_H = 1.1       # bnmf.py:77

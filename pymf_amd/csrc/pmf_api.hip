@@ -18,6 +18,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pymf_hip.h"
@@ -1640,6 +1641,88 @@ int pmf_kernel_stats(pmf_ctx* c, const char** name, int64_t* launches, double* m
   if (mean_ms) *mean_ms = pairs ? tot / (double)pairs : 0.0;
   if (flops_per_launch) *flops_per_launch = c->stat.flops;
   if (bytes_per_launch) *bytes_per_launch = c->stat.bytes;
+  return PMF_OK;
+}
+
+// ---- host-side change detector for the caller's arrays (no device involved) -------------------
+// The reference computes from whatever self.W / self.H / self.data hold at the time of the call
+// (nmf.py:122-132); the host class keeps device copies and must notice ANY in-place edit of the host
+// arrays.  A sum misses permutations; this is an order-dependent 128-bit digest of the raw bytes:
+// 8 interleaved multiply-rotate lanes per 64-byte line (memory speed), 8 MiB chunks hashed by up to
+// 16 threads and folded in chunk order.
+static inline uint64_t pmf_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t pmf_fmix64(uint64_t h) {
+  h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+  return h;
+}
+static void pmf_hash_chunk(const unsigned char* p, size_t n, uint64_t seed, uint64_t out[2]) {
+  constexpr uint64_t P1 = 0x9e3779b185ebca87ull, P2 = 0xc2b2ae3d27d4eb4full;
+  uint64_t a[8];
+  for (int l = 0; l < 8; ++l) a[l] = pmf_fmix64(seed + P1 * (uint64_t)(l + 1));
+  const size_t lines = n / 64;
+  for (size_t i = 0; i < lines; ++i) {
+    uint64_t w[8];
+    std::memcpy(w, p + 64 * i, 64);
+    for (int l = 0; l < 8; ++l) a[l] = (pmf_rotl64(a[l], 31) ^ w[l]) * P1;
+  }
+  if (n % 64) {
+    uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::memcpy(w, p + 64 * lines, n % 64);
+    for (int l = 0; l < 8; ++l) a[l] = (pmf_rotl64(a[l], 31) ^ w[l]) * P1;
+  }
+  uint64_t h1 = (uint64_t)n * P2, h2 = seed ^ P2;
+  for (int l = 0; l < 8; ++l) {
+    h1 = pmf_rotl64(h1, 27) * P1 + pmf_fmix64(a[l]);
+    h2 = (pmf_rotl64(h2, 29) ^ pmf_fmix64(a[l] + P2 * (uint64_t)(l + 1))) * P2;
+  }
+  out[0] = pmf_fmix64(h1);
+  out[1] = pmf_fmix64(h2);
+}
+
+int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2) {
+  if (!out2 || (nbytes && !data)) return PMF_EINVAL;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  constexpr size_t CH = (size_t)8 << 20;
+  const size_t nch = nbytes ? (size_t)((nbytes + CH - 1) / CH) : 1;
+  std::vector<uint64_t> dig(2 * nch);
+  auto work = [&](size_t c0, size_t c1) {
+    for (size_t q = c0; q < c1; ++q) {
+      const size_t off = q * CH;
+      pmf_hash_chunk(p + off, (size_t)std::min<uint64_t>(CH, nbytes - off), 0x243f6a8885a308d3ull + q, &dig[2 * q]);
+    }
+  };
+  unsigned nthr = std::min<unsigned>(std::min<size_t>(nch, 16), std::max(1u, std::thread::hardware_concurrency()));
+  if (nthr <= 1) {
+    work(0, nch);
+  } else {
+    std::vector<std::thread> th;
+    bool spawned_all = true;
+    size_t next = 0;
+    try {
+      for (unsigned t = 0; t < nthr; ++t) {
+        const size_t c0 = nch * t / nthr, c1 = nch * (t + 1) / nthr;
+        th.emplace_back(work, c0, c1);
+        next = c1;
+      }
+    } catch (...) { spawned_all = false; }
+    for (auto& t : th) t.join();
+    if (!spawned_all) work(next, nch);
+  }
+  uint64_t h1 = 0x13198a2e03707344ull ^ nbytes, h2 = 0xa4093822299f31d0ull;
+  for (size_t q = 0; q < nch; ++q) {
+    h1 = pmf_fmix64(pmf_rotl64(h1, 23) * 0x9e3779b185ebca87ull + dig[2 * q]);
+    h2 = pmf_fmix64((pmf_rotl64(h2, 37) ^ dig[2 * q + 1]) * 0xc2b2ae3d27d4eb4full);
+  }
+  out2[0] = h1;
+  out2[1] = h2;
+  return PMF_OK;
+}
+
+// The caller changed V behind the library's back (a streamed `data` object was rebound or edited): forget
+// everything derived from it -- ||V||^2, (W^T V | W^T W), the cached V H^T.
+int pmf_invalidate_v(pmf_ctx* c) {
+  if (!c) return PMF_EINVAL;
+  c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
   return PMF_OK;
 }
 

@@ -1,15 +1,28 @@
 """One-process-per-GPU world description and the rendezvous plumbing.
 
 The data path never touches this module's transport: ranks exchange ONE
-128-byte RCCL unique id at start-up (and bench barriers / a max-reduce of
-timings); everything per iteration is an ncclAllReduce inside libpymf_hip.
-The transport is torch.distributed with the gloo backend (CPU) -- plumbing
-only, as the launch contract (`python -m torch.distributed.run ...`) provides
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT for it.
+128-byte RCCL unique id at start-up, the row counts of their blocks, rank 0's
+NumPy RNG state for the lazy init_w / init_h draws, bench barriers and a
+max-reduce of timings; everything per iteration is an ncclAllReduce inside
+libpymf_hip.  The transport is a few lines of TCP (standard library only, no
+torch): rank 0 listens on MASTER_ADDR at the first free port of
+[PYMF_DIST_PORT or MASTER_PORT + 1, +32), the other ranks connect to it, and
+every collective is a gather to rank 0 followed by a broadcast (a star: the
+payloads are a few hundred bytes).  The launch contract
+(`python -m torch.distributed.run ...`) provides RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT; nothing else of torch is used.
 """
+import hashlib
+import json
 import os
+import socket
+import struct
+import time
 
 import numpy as np
+
+_MAGIC = b"PYMFAMD1"
+_PORT_SPAN = 32
 
 
 class World(object):
@@ -30,68 +43,242 @@ def shard_rows(m_global, rank, size):
 
 
 _WORLD = World()
+_PEERS = None        # rank 0: {rank: socket};  other ranks: {0: socket}
+_LISTENER = None
 
 
 def world():
     return _WORLD
 
 
-def _pg():
-    import torch.distributed as dist
-    return dist
+# ---- framing ---------------------------------------------------------------------------------
+def _send(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
-def init_from_env(make_nccl_id=None):
-    """Read the torchrun env, bring up gloo, broadcast rank 0's RCCL unique id."""
-    global _WORLD
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError("pymf_amd.dist: peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+def _token(addr, port, size):
+    s = "%s|%s|%d|%s" % (addr, port, size, os.environ.get("TORCHELASTIC_RUN_ID", ""))
+    return hashlib.sha256(s.encode()).digest()[:16]
+
+
+# ---- rendezvous ------------------------------------------------------------------------------
+def _serve(addr, base_port, size, token, timeout):
+    global _LISTENER
+    lst = None
+    for port in range(base_port, base_port + _PORT_SPAN):
+        s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        try:
+            s.bind(("" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+            s.listen(size + 8)
+            lst = s
+            break
+        except OSError:
+            s.close()
+    if lst is None:
+        raise RuntimeError("pymf_amd.dist: no free port in [%d, %d); set PYMF_DIST_PORT" %
+                           (base_port, base_port + _PORT_SPAN))
+    _LISTENER = lst
+    peers = {}
+    deadline = time.time() + timeout
+    while len(peers) < size - 1:
+        lst.settimeout(max(0.1, deadline - time.time()))
+        try:
+            conn, _ = lst.accept()
+        except socket.timeout:
+            raise RuntimeError("pymf_amd.dist: only %d of %d ranks joined within %.0f s" %
+                               (len(peers) + 1, size, timeout))
+        try:
+            conn.settimeout(5.0)
+            hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
+            if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):len(_MAGIC) + 16] != token:
+                conn.close()                         # not one of this job's ranks
+                continue
+            (r,) = struct.unpack("<i", hello[-4:])
+            if r < 1 or r >= size or r in peers:
+                conn.close()
+                continue
+            conn.sendall(_MAGIC + token)
+            conn.settimeout(None)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            peers[r] = conn
+        except (OSError, ConnectionError, struct.error):
+            conn.close()
+    return peers
+
+
+def _join(addr, base_port, rank, token, timeout):
+    deadline = time.time() + timeout
+    hello = _MAGIC + token + struct.pack("<i", rank)
+    while time.time() < deadline:
+        for port in range(base_port, base_port + _PORT_SPAN):
+            try:
+                s = socket.create_connection((addr, port), timeout=2.0)
+            except OSError:
+                continue
+            try:
+                s.settimeout(5.0)
+                s.sendall(hello)
+                ack = _recv_exact(s, len(_MAGIC) + 16)
+                if ack == _MAGIC + token:
+                    s.settimeout(None)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    return {0: s}
+            except (OSError, ConnectionError):
+                pass
+            s.close()
+        time.sleep(0.05)
+    raise RuntimeError("pymf_amd.dist: rank %d could not reach rank 0 at %s:[%d,%d) within %.0f s" %
+                       (rank, addr, base_port, base_port + _PORT_SPAN, timeout))
+
+
+def init_from_env(make_nccl_id=None, timeout=None):
+    """Read the launcher's env, connect the ranks, hand rank 0's RCCL unique id to every rank."""
+    global _WORLD, _PEERS
     size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if size == 1:
         _WORLD = World(0, 1, local_rank, None)
         return _WORLD
-    import torch
-    dist = _pg()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=size)
+    if _PEERS is not None:
+        return _WORLD
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    mport = os.environ.get("MASTER_PORT", "29500")
+    base = int(os.environ.get("PYMF_DIST_PORT", "0") or 0) or int(mport) + 1
+    timeout = float(timeout if timeout is not None else os.environ.get("PYMF_DIST_TIMEOUT", "300"))
+    token = _token(addr, mport, size)
+    _WORLD = World(rank, size, local_rank, None)
+    _PEERS = _serve(addr, base, size, token, timeout) if rank == 0 else _join(addr, base, rank, token, timeout)
     if make_nccl_id is None:
         from . import _lib
         make_nccl_id = _lib.nccl_unique_id
-    buf = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        buf = torch.frombuffer(bytearray(make_nccl_id()), dtype=torch.uint8).clone()
-    dist.broadcast(buf, src=0)
-    _WORLD = World(rank, size, local_rank, bytes(buf.numpy().tobytes()))
+    ident = broadcast_bytes(bytes(make_nccl_id()) if rank == 0 else b"")
+    _WORLD.nccl_id = ident
     return _WORLD
+
+
+# ---- collectives (star through rank 0; every rank must make the same calls in the same order) --
+def allgather_bytes(payload):
+    """list of every rank's payload, in rank order, on every rank."""
+    w = _WORLD
+    if w.size == 1:
+        return [bytes(payload)]
+    if w.rank == 0:
+        parts = [bytes(payload)] + [_recv(_PEERS[r]) for r in range(1, w.size)]
+        blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+        for r in range(1, w.size):
+            _send(_PEERS[r], blob)
+        return parts
+    _send(_PEERS[0], bytes(payload))
+    blob = _recv(_PEERS[0])
+    parts, off = [], 0
+    while off < len(blob):
+        (n,) = struct.unpack_from("<Q", blob, off)
+        parts.append(blob[off + 8:off + 8 + n])
+        off += 8 + n
+    return parts
+
+
+def broadcast_bytes(payload, src=0):
+    return allgather_bytes(payload if _WORLD.rank == src else b"")[src]
 
 
 def barrier():
     if _WORLD.size > 1:
-        _pg().barrier()
+        allgather_bytes(b"")
 
 
 def allreduce_max(x):
     if _WORLD.size == 1:
         return float(x)
-    import torch
-    t = torch.tensor([float(x)], dtype=torch.float64)
-    _pg().all_reduce(t, op=_pg().ReduceOp.MAX)
-    return float(t.item())
+    return max(struct.unpack("<d", p)[0] for p in allgather_bytes(struct.pack("<d", float(x))))
+
+
+def allgather_int(x):
+    return [struct.unpack("<q", p)[0] for p in allgather_bytes(struct.pack("<q", int(x)))]
 
 
 def allreduce_sum_array(a):
-    """CPU all-reduce (gloo) of a float array: used by tests of the sharded formulation."""
+    """Sum of a float array over the ranks, added in rank order (the same bits on every rank)."""
+    a = np.ascontiguousarray(a)
+    if _WORLD.size == 1:
+        return a
+    parts = allgather_bytes(a.tobytes())
+    out = np.zeros(a.shape, dtype=a.dtype)
+    for p in parts:
+        out += np.frombuffer(p, dtype=a.dtype).reshape(a.shape)
+    return out
+
+
+def broadcast_array(a, src=0):
+    """rank `src`'s array (any shape/dtype) on every rank."""
     if _WORLD.size == 1:
         return np.asarray(a)
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(a).copy())
-    _pg().all_reduce(t)
-    return t.numpy()
+    if _WORLD.rank == src:
+        a = np.ascontiguousarray(a)
+        head = json.dumps({"dtype": a.dtype.str, "shape": list(a.shape)}).encode()
+        blob = struct.pack("<I", len(head)) + head + a.tobytes()
+    else:
+        blob = b""
+    blob = broadcast_bytes(blob, src)
+    (hl,) = struct.unpack_from("<I", blob, 0)
+    head = json.loads(blob[4:4 + hl].decode())
+    return np.frombuffer(blob[4 + hl:], dtype=np.dtype(head["dtype"])).reshape(head["shape"]).copy()
+
+
+def share_rng_state(src=0):
+    """Give every rank rank `src`'s state of NumPy's global legacy stream (np.random.random, the
+    generator the reference's init_w / init_h draw from, nmf.py:116-120): after this call every rank
+    draws the same numbers, so each can draw the GLOBAL W0 and keep its own rows, and H0 is
+    identical everywhere without moving either matrix."""
+    if _WORLD.size == 1:
+        return
+    if _WORLD.rank == src:
+        name, keys, pos, has_gauss, cached = np.random.get_state()
+        head = json.dumps({"name": name, "pos": int(pos), "has_gauss": int(has_gauss),
+                           "cached": float(cached)}).encode()
+        blob = struct.pack("<I", len(head)) + head + np.asarray(keys, dtype=np.uint32).tobytes()
+    else:
+        blob = b""
+    blob = broadcast_bytes(blob, src)
+    (hl,) = struct.unpack_from("<I", blob, 0)
+    head = json.loads(blob[4:4 + hl].decode())
+    keys = np.frombuffer(blob[4 + hl:], dtype=np.uint32).copy()
+    np.random.set_state((head["name"], keys, head["pos"], head["has_gauss"], head["cached"]))
 
 
 def shutdown():
-    global _WORLD
-    if _WORLD.size > 1 and _pg().is_initialized():
-        _pg().destroy_process_group()
+    global _WORLD, _PEERS, _LISTENER
+    if _PEERS is not None:
+        try:
+            barrier()                    # nobody closes while another rank still reads
+        except Exception:
+            pass
+        for s in _PEERS.values():
+            try:
+                s.close()
+            except OSError:
+                pass
+    if _LISTENER is not None:
+        try:
+            _LISTENER.close()
+        except OSError:
+            pass
+    _PEERS, _LISTENER = None, None
     _WORLD = World()

@@ -3,14 +3,23 @@
 Same class surface as the reference (`NMF(data, num_bases=4)`,
 `.factorize(niter, show_progress, compute_w, compute_h, compute_err)`, `.W`,
 `.H`, `.ferr`, `.frobenius_norm()`, the overridable hooks `init_w / init_h /
-update_w / update_h / converged`, `_EPS`), but every update runs as HIP kernels
-in libpymf_hip.so through a ctypes C ABI: `factorize()` is ONE C call.
+update_w / update_h / frobenius_norm / converged`, `_EPS`), but every update
+runs as HIP kernels in libpymf_hip.so through a ctypes C ABI.
 There is no NumPy fallback: without the library (or a GPU) the calls raise.
+
+Template method (nmf.py:182-202): `factorize()` of an unmodified shipped class is
+ONE C call (`pmf_factorize`).  When a subclass (or the instance) overrides any of
+`update_w / update_h / frobenius_norm / converged`, or `show_progress=True` asks
+for live log lines, `factorize()` runs the reference's loop hook by hook -- every
+shipped hook is itself one C call -- so user plug-ins behave as in the reference.
 
 Host-visible state follows the reference: W/H are created lazily, W first
 (nmf.py:173-177), default float64 (nmf.py:117,120); NMF writes results back IN
 PLACE into the existing arrays (nmf.py:125-126,131-132) keeping their dtype;
-the arithmetic on the device is float32.
+the arithmetic on the device is float32.  The device copies of data / W / H are
+refreshed whenever the host arrays changed (an order-dependent digest of their
+bytes, `pmf_host_checksum`), because the reference always computes from the
+current host arrays.
 """
 import logging
 import os
@@ -32,13 +41,26 @@ def _is_sparse(x):
 
 
 def _fingerprint(a):
-    """Change detector for a host array: identity, layout and the float64 sum of ALL elements (one
-    pass at memory speed, cheaper than the float32 conversion + upload it saves).  A single-element
-    poke between two factorize() calls changes the sum, so the device copy is refreshed -- the
-    reference always computes from the current host arrays."""
-    flat = np.asarray(a).reshape(-1)
-    return (id(a), a.shape, a.dtype.str, float(np.sum(flat, dtype=np.float64)),
-            float(flat[-1]) if flat.shape[0] else 0.0)
+    """Change detector for a host array: shape, dtype and a position-sensitive 128-bit digest of
+    its bytes (one multi-threaded pass at memory speed).  Any in-place edit -- a poke, a swap of two
+    rows, a permutation of the bases -- changes it, so the device copy is refreshed."""
+    return _lib.host_checksum(a)
+
+
+def _draw_rows(m_total, ncols, lo, hi, chunk=65536):
+    """rows [lo, hi) of np.random.random((m_total, ncols)) from the global legacy stream, drawn in
+    chunks (a rank never holds the whole matrix) and leaving the stream exactly where the full draw
+    would (so the H0 drawn next is the reference's, nmf.py:173-177)."""
+    out = np.empty((hi - lo, ncols))
+    r = 0
+    while r < m_total:
+        c = min(chunk, m_total - r)
+        blk = np.random.random((c, ncols))
+        a, b = max(r, lo), min(r + c, hi)
+        if a < b:
+            out[a - lo:b - lo] = blk[a - r:b - r]
+        r += c
+    return out
 
 
 class NMF(object):
@@ -46,16 +68,24 @@ class NMF(object):
 
     Parameters mirror the reference (pymf/nmf.py:23-66): data is m x n
     (m = _data_dimension rows, n = _num_samples columns), W is m x num_bases,
-    H is num_bases x n.
+    H is num_bases x n.  Under a multi-rank world (one process per GPU, launched
+    with RANK / WORLD_SIZE / MASTER_* set and `pymf_amd.dist.init_from_env()` called) `data`
+    and W are THIS rank's contiguous block of rows; H is replicated.
     """
 
     _EPS = 10 ** -8          # nmf.py:69
     _ALGO = _lib.ALGO_NMF
     _REBIND_W = False        # SNMF rebinds self.W (snmf.py:70); NMF mutates in place
+    _SHIPPED = True          # marks the classes whose hooks are the built-in C calls
+    _HOOKS = ("update_w", "update_h", "frobenius_norm", "converged")
     #: rows per tile for out-of-core data: when set (or env PYMF_STREAM_ROWS), `data` is never made
     #: resident -- every iteration reads it tile by tile through `data[r0:r1, :]` (an h5py dataset,
     #: a np.memmap, anything with that slicing) and streams the tiles through the device.
     stream_rows = None
+    #: True: before every factorize() / single hook call the bytes of `data` are digested and V is
+    #: uploaded again when they changed (the reference reads self.data[:,:] afresh every time).
+    #: False: `data` is uploaded once per object; call invalidate_data() after editing it in place.
+    check_data = True
 
     def __init__(self, data, num_bases=4):
         def setup_logging():                                   # nmf.py:73-90
@@ -72,16 +102,60 @@ class NMF(object):
         (self._data_dimension, self._num_samples) = self.data.shape   # nmf.py:97
         self._ctx = None
         self._v_src = None       # the `data` object currently resident on the device
-        self._w_fp = None        # fingerprint of the host W/H the device copies equal
+        self._v_fp = None        # ... and the digest of its bytes at upload time
+        self._w_fp = None        # digest of the host W/H the device copies equal
         self._h_fp = None
+        self._host_stale = set() # factors whose DEVICE copy is newer than the host array (hook loop)
+        self._defer_pull = False
+        self._in_loop = False
+
+    # ---- W / H: plain attributes to the user, lazily refreshed from the device in the hook loop ----
+    def _factor_get(self, name):
+        try:
+            arr = self.__dict__["_" + name]
+        except KeyError:
+            raise AttributeError("'%s' object has no attribute '%s'" % (type(self).__name__, name))
+        if name in self.__dict__.get("_host_stale", ()):
+            self._refresh_host(name)
+            arr = self.__dict__["_" + name]
+        return arr
+
+    def _factor_set(self, name, value):
+        self.__dict__["_" + name] = value
+        self.__dict__.setdefault("_host_stale", set()).discard(name)
+        self.__dict__["_%s_fp" % name.lower()] = None          # host is newer: upload at the next call
+
+    def _factor_del(self, name):
+        try:
+            del self.__dict__["_" + name]
+        except KeyError:
+            raise AttributeError(name)
+        self.__dict__.setdefault("_host_stale", set()).discard(name)
+
+    W = property(lambda self: self._factor_get("W"), lambda self, v: self._factor_set("W", v),
+                 lambda self: self._factor_del("W"))
+    H = property(lambda self: self._factor_get("H"), lambda self, v: self._factor_set("H", v),
+                 lambda self: self._factor_del("H"))
 
     # ---- device plumbing ---------------------------------------------------------
     def _world(self):
         return _dist.world()
 
+    def _row_span(self):
+        """(first global row, one past the last, rows of the whole matrix) of this rank's block:
+        `data` holds the local rows, the global picture comes from one exchange of the row counts."""
+        w = self._world()
+        if w.size == 1:
+            return 0, self._data_dimension, self._data_dimension
+        if getattr(self, "_span", None) is None:
+            counts = _dist.allgather_int(self._data_dimension)
+            lo = int(sum(counts[:w.rank]))
+            self._span = (lo, lo + int(counts[w.rank]), int(sum(counts)))
+        return self._span
+
     def _global_rows(self):
         """Rows of the whole matrix: under a multi-rank world `data` is this rank's block."""
-        return getattr(self, "_m_global", self._data_dimension)
+        return self._row_span()[2]
 
     def _context(self):
         if self._ctx is None:
@@ -91,14 +165,31 @@ class NMF(object):
                                      nranks=w.size, nccl_id=w.nccl_id)
         return self._ctx
 
+    def invalidate_data(self):
+        """Tell the object that `data` was edited in place (needed only with check_data = False)."""
+        self._v_src = None
+        self._v_fp = None
+        if self._ctx is not None:
+            self._ctx.invalidate_v()
+
     def _upload_data(self, ctx):
-        if self._v_src is self.data:
+        same_obj = self._v_src is self.data
+        if same_obj and not self.check_data:
             return
         if _is_sparse(self.data):
+            csr = self.data.tocsr()
+            fp = tuple(_fingerprint(x) for x in (csr.indptr, csr.indices, csr.data)) if self.check_data else None
+            if same_obj and fp == self._v_fp:
+                return
             self._upload_sparse(ctx)
         else:
-            ctx.set_v_dense(np.asarray(self.data[:, :]))        # data[:,:] idiom, nmf.py:123,129
+            arr = np.asarray(self.data[:, :])                   # data[:,:] idiom, nmf.py:123,129
+            fp = _fingerprint(arr) if self.check_data else None
+            if same_obj and fp == self._v_fp:
+                return
+            ctx.set_v_dense(arr)
         self._v_src = self.data
+        self._v_fp = fp
 
     def _upload_sparse(self, ctx):
         raise TypeError("scipy.sparse data is not supported by %s (the reference fails "
@@ -128,10 +219,18 @@ class NMF(object):
 
     def _sync_to_device(self, with_data=True):
         ctx = self._context()
-        if with_data and not self._stream_rows():
-            self._upload_data(ctx)
+        if with_data and not self._in_loop:
+            # inside factorize()'s loop `data` was checked once, when the loop started
+            if self._stream_rows():
+                if self._v_src is not self.data or self.check_data:
+                    ctx.invalidate_v()            # streamed data is re-read every pass; ||V||^2 with it
+                    self._v_src = self.data
+            else:
+                self._upload_data(ctx)
         for name, fp_attr, setter in (("W", "_w_fp", ctx.set_w), ("H", "_h_fp", ctx.set_h)):
-            arr = getattr(self, name)
+            if name in self._host_stale:          # the device copy is the newer one
+                continue
+            arr = self.__dict__["_" + name] if ("_" + name) in self.__dict__ else getattr(self, name)
             if not np.issubdtype(np.asarray(arr).dtype, np.floating):
                 # reference: `W *= dot(...)` on an integer W raises UFuncTypeError
                 raise TypeError("%s must be a floating-point array" % name)
@@ -141,17 +240,33 @@ class NMF(object):
                 setattr(self, fp_attr, fp)
         return ctx
 
-    def _pull(self, ctx, want_w, want_h):
-        if want_w:
+    def _refresh_host(self, name):
+        """Bring the host array of W or H up to date with the device (the deferred half of _pull)."""
+        ctx = self._context()
+        self._host_stale.discard(name)
+        if name == "W":
             w = ctx.get_w()
+            cur = self.__dict__["_W"]
             if self._REBIND_W:
-                self.W = w.astype(self.W.dtype, copy=False) if self.W.dtype != np.float32 else w
+                self.__dict__["_W"] = w.astype(cur.dtype, copy=False) if cur.dtype != np.float32 else w
             else:
-                np.copyto(self.W, w, casting="same_kind")       # in place, nmf.py:131-132
-            self._w_fp = _fingerprint(self.W)
-        if want_h:
-            np.copyto(self.H, ctx.get_h(), casting="same_kind")  # in place, nmf.py:125-126
-            self._h_fp = _fingerprint(self.H)
+                np.copyto(cur, w, casting="same_kind")          # in place, nmf.py:131-132
+            self._w_fp = _fingerprint(self.__dict__["_W"])
+        else:
+            np.copyto(self.__dict__["_H"], ctx.get_h(), casting="same_kind")  # in place, nmf.py:125-126
+            self._h_fp = _fingerprint(self.__dict__["_H"])
+
+    def _pull(self, ctx, want_w, want_h):
+        for name, want in (("W", want_w), ("H", want_h)):
+            if not want:
+                continue
+            self._host_stale.add(name)
+            if not self._defer_pull:
+                self._refresh_host(name)
+
+    def _flush_host(self):
+        for name in sorted(self._host_stale):
+            self._refresh_host(name)
 
     # ---- reference surface ----------------------------------------------------------
     def frobenius_norm(self):
@@ -166,12 +281,17 @@ class NMF(object):
     def init_w(self):                                          # nmf.py:116-117
         w = self._world()
         if w.size > 1:
-            lo, hi = w.row_range(self._global_rows())
-            self.W = np.random.random((self._global_rows(), self._num_bases))[lo:hi].copy()
+            # every rank continues rank 0's stream: each draws the GLOBAL W0 and keeps its own rows,
+            # and the H0 drawn afterwards is the same everywhere
+            _dist.share_rng_state()
+            lo, hi, mg = self._row_span()
+            self.W = _draw_rows(mg, self._num_bases, lo, hi)
         else:
             self.W = np.random.random((self._data_dimension, self._num_bases))
 
     def init_h(self):                                          # nmf.py:119-120
+        if self._world().size > 1:
+            _dist.share_rng_state()                            # H is replicated: one stream, one H0
         self.H = np.random.random((self._num_bases, self._num_samples))
 
     def update_h(self):                                        # nmf.py:122-126
@@ -196,9 +316,22 @@ class NMF(object):
         derr = np.abs(self.ferr[i] - self.ferr[i - 1]) / self._num_samples
         return bool(derr < self._EPS)
 
+    def _hooks_overridden(self):
+        """True when update_w / update_h / frobenius_norm / converged are not the shipped class's own
+        (a user subclass or an instance attribute): factorize() must then call them, as the
+        reference's template-method loop does (nmf.py:182-202)."""
+        cls = type(self)
+        base = next((c for c in cls.__mro__ if c.__dict__.get("_SHIPPED", False)), None)
+        if base is None:
+            return True
+        for name in self._HOOKS:
+            if name in self.__dict__ or getattr(cls, name) is not getattr(base, name):
+                return True
+        return False
+
     def factorize(self, niter=1, show_progress=False,
                   compute_w=True, compute_h=True, compute_err=True):
-        """Factorize s.t. WH = data (nmf.py:141-202); one call into libpymf_hip."""
+        """Factorize s.t. WH = data (nmf.py:141-202)."""
         if show_progress:                                      # nmf.py:166-169
             self._logger.setLevel(logging.INFO)
         else:
@@ -214,8 +347,17 @@ class NMF(object):
 
         ctx = self._sync_to_device()
         rows = self._stream_rows()
-        if rows:
+        if self._hooks_overridden() or (show_progress and not rows):
+            return self._factorize_by_hooks(niter, compute_w, compute_h, compute_err)
+        if rows:                                               # a Python loop already: logs as it runs
             ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
+            self._last_iters = done
+            self._pull(ctx, compute_w and done > 0, compute_h and done > 0)
+            if compute_err:
+                self.ferr[:done] = ferr[:done]
+                if conv_at >= 0:                               # nmf.py:198-202
+                    self.ferr = self.ferr[:conv_at]
+            return
         else:
             ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
                                                 conv_eps=self._EPS)
@@ -232,6 +374,35 @@ class NMF(object):
         if compute_err and conv_at >= 0:                       # nmf.py:198-202
             self.ferr = self.ferr[:conv_at]
 
+    def _factorize_by_hooks(self, niter, compute_w, compute_h, compute_err):
+        """The reference's loop (nmf.py:182-202), one hook call at a time, log lines as it runs.
+        W and H stay on the device between the hooks; the host arrays are refreshed when a hook (or
+        the user) reads `.W` / `.H`, and in any case before factorize() returns."""
+        self._defer_pull = True
+        self._in_loop = True
+        done = 0
+        try:
+            for i in range(niter):
+                if compute_w:
+                    self.update_w()
+                if compute_h:
+                    self.update_h()
+                done = i + 1
+                if compute_err:
+                    self.ferr[i] = self.frobenius_norm()
+                    self._logger.info('Iteration ' + str(i + 1) + '/' + str(niter) +
+                                      ' FN:' + str(self.ferr[i]))
+                else:
+                    self._logger.info('Iteration ' + str(i + 1) + '/' + str(niter))
+                if i > 1 and compute_err:
+                    if self.converged(i):
+                        self.ferr = self.ferr[:i]
+                        break
+        finally:
+            self._defer_pull = False
+            self._in_loop = False
+            self._last_iters = done
+            self._flush_host()
 
     def _factorize_streamed(self, ctx, rows, niter, compute_w, compute_h, compute_err):
         """The loop of nmf.py:182-202 with one streamed pass per iteration; same return triple as
@@ -243,11 +414,10 @@ class NMF(object):
             done = i + 1
             if compute_err:
                 ferr[i] = e
+                self._logger.info('Iteration ' + str(i + 1) + '/' + str(niter) + ' FN:' + str(ferr[i]))
                 if i > 1 and abs(ferr[i] - ferr[i - 1]) / self._num_samples < self._EPS:   # nmf.py:134-139,198
                     conv_at = i
                     break
+            else:
+                self._logger.info('Iteration ' + str(i + 1) + '/' + str(niter))
         return ferr, done, conv_at
-
-
-def _setup_module():      # keep `python -m doctest`-style entry harmless
-    return None

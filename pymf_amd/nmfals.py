@@ -14,4 +14,5 @@ __all__ = ["NMFALS"]
 
 
 class NMFALS(NMF):
+    _SHIPPED = True
     _ALGO = _lib.ALGO_NMFALS

@@ -11,4 +11,4 @@ __all__ = ["NMFNNLS"]
 
 
 class NMFNNLS(NMFALS):
-    pass
+    _SHIPPED = True

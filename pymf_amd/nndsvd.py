@@ -22,6 +22,7 @@ __all__ = ["NNDSVD"]
 
 
 class NNDSVD(NMF):
+    _SHIPPED = True
     def init_w(self):                                           # nndsvd.py:69-70
         self.W = np.zeros((self._data_dimension, self._num_bases))
 

@@ -11,6 +11,7 @@ On the device the state is D = S - data, the matrix both contractions use (rnmf.
 import numpy as np
 
 from . import _lib
+from . import dist
 from .nmf import NMF
 
 __all__ = ["RNMF"]
@@ -18,17 +19,18 @@ __all__ = ["RNMF"]
 
 class RNMF(NMF):
     _ALGO = _lib.ALGO_RNMF
+    _SHIPPED = True
 
     def __init__(self, data, num_bases=4, lamb=2.0):            # rnmf.py:70-73
         NMF.__init__(self, data, num_bases=num_bases)
         self._lamb = lamb
         self._has_s = False
 
-    def soft_thresholding(self, X, lamb):                       # rnmf.py:75-79 (host helper, as in the reference)
-        X = np.where(np.abs(X) <= lamb, 0.0, X)
-        X = np.where(X > lamb, X - lamb, X)
-        X = np.where(X < -1.0 * lamb, X + lamb, X)
-        return X
+    def soft_thresholding(self, X, lamb):
+        """The shrinkage operator of rnmf.py:75-79: entries within [-lamb, lamb] become 0, the others
+        move towards 0 by lamb.  Host helper for users; the device thresholds inside `k_resid`."""
+        X = np.asarray(X)
+        return np.sign(X) * np.maximum(np.abs(X) - lamb, 0.0)
 
     @property
     def S(self):
@@ -37,15 +39,17 @@ class RNMF(NMF):
         return self._sync_to_device().rnmf_get_s()
 
     def init_h(self):                                           # rnmf.py:84-94
-        self.H = np.random.random((self._num_bases, self._num_samples))
-        self.H[:, :] = 1.0
-        Wnorm = np.sqrt(np.sum(self.W ** 2.0, axis=0))
+        # the reference draws a random H and overwrites it with ones (rnmf.py:85-86): the draw is kept
+        # so that the global NumPy stream stays where the reference leaves it
+        if self._world().size > 1:
+            dist.share_rng_state()
+        np.random.random((self._num_bases, self._num_samples))
+        col_energy = np.einsum("ij,ij->j", self.W, self.W)
         if self._world().size > 1:                              # column norms over ALL ranks' rows
-            from . import dist
-            Wnorm = np.sqrt(dist.allreduce_sum_array(np.sum(self.W ** 2.0, axis=0)))
-        self.W /= Wnorm
-        for i in range(self.H.shape[0]):
-            self.H[i, :] *= Wnorm[i]
+            col_energy = dist.allreduce_sum_array(col_energy)
+        Wnorm = np.sqrt(col_energy)
+        self.W /= Wnorm                                         # unit-norm bases, their scale moves into H
+        self.H = np.ones((self._num_bases, self._num_samples)) * Wnorm[:, None]
         self.update_s()
 
     def _push_lambda(self):

@@ -15,6 +15,7 @@ __all__ = ["SNMF"]
 
 
 class SNMF(NMF):
+    _SHIPPED = True
     _ALGO = _lib.ALGO_SNMF
     _REBIND_W = True
 

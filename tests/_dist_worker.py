@@ -1,4 +1,4 @@
-"""world_size-2 worker (gloo, CPU): the rendezvous plumbing of pymf_amd.dist and the
+"""world_size-N worker (CPU, socket rendezvous of pymf_amd.dist): the rendezvous plumbing of pymf_amd.dist and the
 row-sharded formulation of one NMF iteration: rows of V/W are independent
 given H; update_h needs only the SUM over ranks of (W_r^T V_r | W_r^T W_r)."""
 import os
@@ -44,6 +44,21 @@ def main():
     dist.barrier()
     t = dist.allreduce_max(float(w.rank + 1))
     assert t == float(w.size)
+    # the class-level plumbing: row counts -> global span, rank 0's RNG stream on every rank
+    counts = dist.allgather_int(hi - lo)
+    assert sum(counts) == m and counts[w.rank] == hi - lo
+    np.random.seed(1000 + w.rank)                      # ranks start with DIFFERENT streams
+    dist.share_rng_state()
+    from pymf_amd.nmf import _draw_rows
+    Wl = _draw_rows(m, k, lo, hi)
+    Hl = np.random.random((k, n))
+    np.random.seed(1000)
+    assert np.array_equal(Wl, np.random.random((m, k))[lo:hi])
+    assert np.array_equal(Hl, np.random.random((k, n)))
+    got = dist.broadcast_array(np.arange(6, dtype=np.float32).reshape(2, 3) * (w.rank + 1), src=w.size - 1)
+    assert np.array_equal(got, np.arange(6, dtype=np.float32).reshape(2, 3) * w.size)
+    if "--assert-no-torch" in sys.argv:
+        assert "torch" not in sys.modules, "the product must not import torch"
     dist.shutdown()
     print("rank %d ok" % w.rank)
 

@@ -65,14 +65,70 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
-                assert "import torch" not in txt or f == "dist.py", f
+                assert "import torch" not in txt, f        # north_star: no PyTorch in the product
+
+
+def _create_code(lib, *args):
+    try:
+        lib.Context(*args).close()
+    except lib.PmfError as e:
+        return e.code
+    return lib.PMF_OK
 
 
 def test_bad_arguments_return_einval(lib):
+    """pmf_ctx_create validates its arguments BEFORE it touches a device, so the status is PMF_EINVAL
+    with or without a GPU -- and a valid shape without a GPU is PMF_EHIP, not EINVAL."""
     lib.load()
-    with pytest.raises(lib.PmfError):
-        lib.Context(lib.ALGO_NMF, 0, 4, 2)          # m < 1
-    with pytest.raises(lib.PmfError):
-        lib.Context(lib.ALGO_NMF, 4, 4, 129)        # num_bases > 128
-    with pytest.raises(lib.PmfError):
-        lib.Context(7, 4, 4, 2)                     # unknown algo
+    assert _create_code(lib, lib.ALGO_NMF, 0, 4, 2) == lib.PMF_EINVAL          # m < 1
+    assert _create_code(lib, lib.ALGO_NMF, 4, 0, 2) == lib.PMF_EINVAL          # n < 1
+    assert _create_code(lib, lib.ALGO_NMF, 4, 4, 0) == lib.PMF_EINVAL          # k < 1
+    assert _create_code(lib, 7, 4, 4, 2) == lib.PMF_EINVAL                     # unknown algo
+    assert _create_code(lib, lib.ALGO_NMF, 4, 4, 1025) == lib.PMF_EINVAL       # num_bases beyond the build's limit
+    assert _create_code(lib, lib.ALGO_NMF, 4, 4, 2, 0, 3, 2) == lib.PMF_EINVAL  # rank >= nranks
+    assert _create_code(lib, lib.ALGO_NMF, 4, 4, 2, 0, 0, 2, None) == lib.PMF_EINVAL   # nranks > 1 without an id
+    valid = _create_code(lib, lib.ALGO_NMF, 4, 4, 129)                         # num_bases > 128 is a supported NMF shape
+    if lib.device_count() > 0:
+        assert valid == lib.PMF_OK
+    else:
+        assert valid == lib.PMF_EHIP                                           # no device: a HIP error, never EINVAL
+
+
+@pytest.mark.gpu
+def test_bad_arguments_on_the_gpu_box(lib):
+    """The same status codes with a device present, plus the call-order errors of a live context."""
+    test_bad_arguments_return_einval(lib)
+    ctx = lib.Context(lib.ALGO_NMF, 8, 6, 2)
+    for call in (ctx.update_w, ctx.update_h, ctx.frobenius, lambda: ctx.factorize(1)):
+        with pytest.raises(lib.PmfError) as ei:
+            call()                                                             # V / W / H not set yet
+        assert ei.value.code == lib.PMF_EINVAL
+    ctx.close()
+
+
+def test_host_checksum_is_position_sensitive(lib):
+    """The change detector of the host classes (pmf_host_checksum, no device needed): any in-place
+    edit -- sum-preserving ones included -- must change the digest; equal bytes must not."""
+    rs = np.random.RandomState(0)
+    W = rs.random_sample((5000, 64))
+    base = lib.host_checksum(W)
+    assert lib.host_checksum(W.copy()) == base
+    X = W.copy(); X[[3, 4000]] = X[[4000, 3]]                  # swap two rows: same sum, same last element
+    assert lib.host_checksum(X) != base
+    X = W.copy(); X[0, 0] += 1.0; X[1, 0] -= 1.0               # sum-preserving poke
+    assert lib.host_checksum(X) != base
+    X = W.copy(); X[:] = X[:, ::-1]                            # permute the bases in place
+    assert lib.host_checksum(X) != base
+    X = W.copy(); X[17, 5] = np.nextafter(X[17, 5], 2.0)       # one ulp
+    assert lib.host_checksum(X) != base
+    assert lib.host_checksum(W.astype(np.float32)) != base
+    assert lib.host_checksum(W.reshape(64, 5000))[2:] == base[2:]      # same bytes, other shape: digest equal ...
+    assert lib.host_checksum(W.reshape(64, 5000)) != base              # ... the shape is part of the fingerprint
+    big = rs.random_sample(5 * (1 << 20) + 13).astype(np.float32)      # several 8 MiB chunks + a ragged tail: threaded path
+    d0 = lib.host_checksum(big)
+    assert lib.host_checksum(big.copy()) == d0
+    big[3 * (1 << 20) + 7], big[3 * (1 << 20) + 8] = big[3 * (1 << 20) + 8], big[3 * (1 << 20) + 7]
+    assert lib.host_checksum(big) != d0
+    nc = W[::2, ::3]                                                   # non-contiguous view: digest of its contents
+    assert lib.host_checksum(nc) == lib.host_checksum(np.ascontiguousarray(nc))
+    assert lib.host_checksum(np.zeros((0, 4)))[0] == (0, 4)

@@ -1,4 +1,6 @@
-"""N > 1 path on CPU: two gloo ranks exercise pymf_amd.dist and the sharded formulation."""
+"""N > 1 path on CPU: world_size-2 (and 4) ranks exercise pymf_amd.dist -- the socket rendezvous that
+replaced torch.distributed/gloo in the product -- and the row-sharded formulation; once under the
+driver's own launcher (`python -m torch.distributed.run`, which only provides the env)."""
 import os
 import socket
 import subprocess
@@ -27,11 +29,15 @@ def _free_port():
     return p
 
 
-def test_two_rank_gloo_world():
+import pytest
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_rank_world(size):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+    for rank in range(size):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py")],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -46,3 +52,17 @@ def test_two_rank_gloo_world():
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
         assert "rank %d ok" % rank in out
+
+
+def test_world_under_the_torchrun_launcher():
+    """The driver launches bench.py with `python -m torch.distributed.run`: the workers must find
+    each other from the env it sets (and never import torch themselves)."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), "--assert-no-torch"]
+    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert "rank 0 ok" in out and "rank 1 ok" in out

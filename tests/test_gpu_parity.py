@@ -6,7 +6,7 @@ Tolerances (float32 device arithmetic vs the float64-default reference, SURVEY 8
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_fro
+from conftest import load_golden, rel_fro, close
 
 pytestmark = pytest.mark.gpu
 
@@ -39,9 +39,9 @@ def test_nmf_vs_reference_golden(pm, name):
     mdl = _run(pm.NMF, g["V"], int(g["k"]), int(g["niter"]), g["W0"], g["H0"])
     assert mdl.W.dtype == g["W"].dtype and mdl.H.dtype == g["H"].dtype
     assert len(mdl.ferr) == len(g["ferr"])
-    assert rel_fro(mdl.W, g["W"]) < TOL_X
-    assert rel_fro(mdl.H, g["H"]) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=TOL_F)
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < TOL_X
+    assert rel_fro(mdl.H, g["H"], what="mdl.H") < TOL_X
+    close(mdl.ferr, g["ferr"], rtol=TOL_F, what="mdl.ferr")
 
 
 SNMF_GOLD = ["snmf_cfg1_f64", "snmf_cfg1_f32", "snmf_512x128_k16", "snmf_cfg4s", "snmf_cfg2s",
@@ -58,9 +58,9 @@ def test_snmf_vs_reference_golden(pm, name):
     assert mdl.W is not W_before                     # snmf.py:70 rebinds self.W
     assert len(mdl.ferr) == len(g["ferr"])
     # W crosses zero: Frobenius-relative only
-    assert rel_fro(mdl.W, g["W"]) < 5e-5
-    assert rel_fro(mdl.H, g["H"]) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, g["ferr"], rtol=2e-5)
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-5
+    assert rel_fro(mdl.H, g["H"], what="mdl.H") < TOL_X
+    close(mdl.ferr, g["ferr"], rtol=2e-5, what="mdl.ferr")
 
 
 @pytest.mark.parametrize("m,n,k", [(64, 64, 16), (100, 70, 3), (257, 130, 33), (1000, 256, 64),
@@ -74,9 +74,9 @@ def test_nmf_vs_oracle_shapes(pm, m, n, k):
     ref = NMFOracle(V, num_bases=k)
     ref.W, ref.H = W0.copy(), H0.copy()
     ref.factorize(niter=6)
-    assert rel_fro(mdl.W, ref.W) < TOL_X
-    assert rel_fro(mdl.H, ref.H) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X
+    assert rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
+    close(mdl.ferr, ref.ferr, rtol=TOL_F, what="mdl.ferr")
 
 
 def test_single_hooks_match_oracle(pm):
@@ -90,10 +90,10 @@ def test_single_hooks_match_oracle(pm):
     assert abs(mdl.frobenius_norm() - frobenius_norm(V, W, H)) / frobenius_norm(V, W, H) < TOL_F
     mdl.update_w()
     nmf_update_w(V, W, H)
-    assert rel_fro(mdl.W, W) < 2e-6
+    assert rel_fro(mdl.W, W, what="mdl.W") < 2e-6
     mdl.update_h()
     nmf_update_h(V, W, H)
-    assert rel_fro(mdl.H, H) < 2e-6
+    assert rel_fro(mdl.H, H, what="mdl.H") < 2e-6
     assert abs(mdl.frobenius_norm() - frobenius_norm(V, W, H)) / frobenius_norm(V, W, H) < TOL_F
 
 
@@ -103,17 +103,17 @@ def test_flag_sequence_and_resume(pm):
     np.random.seed(int(g["seed"]))
     mdl = pm.NMF(g["V"], num_bases=int(g["k"]))
     mdl.factorize(niter=5)
-    assert rel_fro(mdl.W, g["W_a"]) < TOL_X and rel_fro(mdl.H, g["H_a"]) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, g["ferr_a"], rtol=TOL_F)
+    assert rel_fro(mdl.W, g["W_a"], what="mdl.W") < TOL_X and rel_fro(mdl.H, g["H_a"], what="mdl.H") < TOL_X
+    close(mdl.ferr, g["ferr_a"], rtol=TOL_F, what="mdl.ferr")
     mdl.factorize(niter=5, compute_h=False)
-    assert rel_fro(mdl.W, g["W_b"]) < TOL_X and rel_fro(mdl.H, g["H_b"]) < TOL_X
+    assert rel_fro(mdl.W, g["W_b"], what="mdl.W") < TOL_X and rel_fro(mdl.H, g["H_b"], what="mdl.H") < TOL_X
     mdl.factorize(niter=5, compute_w=False)
-    assert rel_fro(mdl.W, g["W_c"]) < TOL_X and rel_fro(mdl.H, g["H_c"]) < TOL_X
+    assert rel_fro(mdl.W, g["W_c"], what="mdl.W") < TOL_X and rel_fro(mdl.H, g["H_c"], what="mdl.H") < TOL_X
     before = mdl.ferr.copy()
     mdl.factorize(niter=5, compute_err=False)
-    assert rel_fro(mdl.W, g["W_d"]) < TOL_X and rel_fro(mdl.H, g["H_d"]) < TOL_X
+    assert rel_fro(mdl.W, g["W_d"], what="mdl.W") < TOL_X and rel_fro(mdl.H, g["H_d"], what="mdl.H") < TOL_X
     np.testing.assert_array_equal(mdl.ferr, before)          # nmf.py:179-180
-    np.testing.assert_allclose(mdl.ferr, g["ferr_d"], rtol=TOL_F)
+    close(mdl.ferr, g["ferr_d"], rtol=TOL_F, what="mdl.ferr")
 
 
 def test_early_exit_truncates_ferr(pm):
@@ -123,7 +123,7 @@ def test_early_exit_truncates_ferr(pm):
     mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
     mdl.factorize(niter=20, compute_w=False)
     assert len(mdl.ferr) == len(g["ferr"]) == 2
-    np.testing.assert_allclose(mdl.H, g["H"], rtol=1e-5, atol=1e-6)
+    close(mdl.H, g["H"], rtol=1e-5, atol=1e-6, what="mdl.H")
 
 
 def test_sentinel_and_errors(pm):
@@ -150,12 +150,12 @@ def test_user_assigned_factors_are_reuploaded(pm):
     ref = NMFOracle(V, num_bases=8)
     ref.W, ref.H = W1.copy(), H1.copy()
     ref.factorize(niter=3)
-    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
     mdl.H *= 0.5                                             # in-place edit must be noticed
     ref.H *= 0.5
     mdl.factorize(niter=1)
     ref.factorize(niter=1)
-    assert rel_fro(mdl.H, ref.H) < TOL_X
+    assert rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
 
 
 def test_linearity_property_large(pm):
@@ -171,7 +171,7 @@ def test_linearity_property_large(pm):
     b = pm.NMF(V, num_bases=k)
     b.W, b.H = W0.copy(), (2.0 * H0)
     b.update_w()
-    assert rel_fro(2.0 * b.W, a.W) < 1e-6
+    assert rel_fro(2.0 * b.W, a.W, what="2.0 * b.W") < 1e-6
 
 
 def test_rccl_path_single_rank_communicator(pm):
@@ -214,8 +214,8 @@ def test_fused_and_tiled_paths_agree(pm):
     for _ in range(3):                               # hooks -> tiled kernels
         b.update_w()
         b.update_h()
-    assert rel_fro(a.get_w(), b.get_w()) < 2e-6
-    assert rel_fro(a.get_h(), b.get_h()) < 2e-6
+    assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < 2e-6
+    assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < 2e-6
 
 
 def test_full_size_properties_cfg4(pm):
@@ -240,15 +240,15 @@ def test_full_size_properties_cfg4(pm):
         b.update_h()
         b.set_w(b.get_w())                                        # "new" W invalidates (W^T V | W^T W): forces the direct pass
         fb.append(b.frobenius())
-    np.testing.assert_allclose(ferr, np.array(fb), rtol=2e-6)     # (2) + (3)
+    close(ferr, np.array(fb), rtol=2e-6, what="ferr")     # (2) + (3)
     Ha, Hb = a.get_h(), b.get_h()                                 # H depends on every row of W
-    assert rel_fro(Ha, Hb) < 5e-6
+    assert rel_fro(Ha, Hb, what="Ha") < 5e-6
     assert np.isfinite(Ha).all() and Ha.min() >= 0                # (4)
     Wa = a.get_w()
     assert float(Wa.min()) >= 0.0 and np.isfinite(float(Wa.sum(dtype=np.float64)))
     Wb = b.get_w()
     sl = slice(0, m, 4097)
-    assert rel_fro(Wa[sl], Wb[sl]) < 5e-6
+    assert rel_fro(Wa[sl], Wb[sl], what="Wa[sl]") < 5e-6
     a.close(); b.close()
 
 
@@ -265,9 +265,9 @@ def test_ragged_and_tiny_shapes(pm, m, n, k):
     ref.W, ref.H = W0.copy(), H0.copy()
     ref.factorize(niter=4)
     assert mdl.W.shape == (m, k) and mdl.H.shape == (k, n)
-    assert rel_fro(mdl.W, ref.W) < 5e-5 and rel_fro(mdl.H, ref.H) < 5e-5
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < 5e-5 and rel_fro(mdl.H, ref.H, what="mdl.H") < 5e-5
     if ref.ferr[-1] > 1e-5 * np.linalg.norm(V):
-        np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=2e-4, atol=1e-6)
+        close(mdl.ferr, ref.ferr, rtol=2e-4, atol=1e-6, what="mdl.ferr")
     else:
         # rank(V) <= k: the fit is exact and the residual is pure rounding noise (float32 here,
         # float64 in the reference), so neither its digits nor the early-exit iteration are comparable
@@ -287,7 +287,7 @@ def test_zero_rows_and_columns(pm):
     ref.W, ref.H = W0.copy(), H0.copy()
     ref.factorize(niter=5)
     assert np.all(mdl.W[10:20] == 0.0) and np.all(mdl.H[:, 5] == 0.0)
-    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
 
 
 def test_snmf_fused_and_tiled_paths_agree(pm):
@@ -307,8 +307,8 @@ def test_snmf_fused_and_tiled_paths_agree(pm):
     for _ in range(3):
         b.update_w()
         b.update_h()
-    assert rel_fro(a.get_w(), b.get_w()) < 1e-5
-    assert rel_fro(a.get_h(), b.get_h()) < 1e-5
+    assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < 1e-5
+    assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < 1e-5
 
 
 def test_bitwise_reproducible(pm):
@@ -367,10 +367,10 @@ def test_fused_vs_tiled_random_shapes(pm):
                 b.set_w(b.get_w())             # stale (P | S): direct residual pass
                 fb.append(b.frobenius())
             tol = 2e-5 if algo == _lib.ALGO_NMF else 5e-4     # SNMF: inv(H H^T) amplifies for k ~ n
-            assert rel_fro(a.get_h(), b.get_h()) < tol, (algo, m, n, k)
-            assert rel_fro(a.get_w(), b.get_w()) < tol, (algo, m, n, k)
+            assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < tol, (algo, m, n, k)
+            assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < tol, (algo, m, n, k)
             if fb[-1] > 1e-3 * np.linalg.norm(V):
-                np.testing.assert_allclose(fa, np.array(fb), rtol=1e-4, err_msg=str((algo, m, n, k)))
+                close(fa, np.array(fb), rtol=1e-4, err_msg=str((algo, m, n, k)), what="fa")
             a.close(); b.close()
 
 
@@ -387,9 +387,9 @@ def test_fifty_iterations_drift(pm):
     ref.W, ref.H = W0.copy(), H0.copy()
     ref.factorize(niter=50)
     assert len(mdl.ferr) == len(ref.ferr) == 50
-    assert rel_fro(mdl.W, ref.W) < TOL_X
-    assert rel_fro(mdl.H, ref.H) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X
+    assert rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
+    close(mdl.ferr, ref.ferr, rtol=TOL_F, what="mdl.ferr")
 
 
 def test_fixed_basis_loop_reuses_partials(pm):
@@ -407,14 +407,14 @@ def test_fixed_basis_loop_reuses_partials(pm):
         ref = ocls(V, num_bases=40)
         ref.W, ref.H = W0.copy(), H0.copy()
         ref.factorize(niter=25, compute_w=False)
-        assert rel_fro(mdl.H, ref.H) < TOL_X
-        np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+        assert rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
+        close(mdl.ferr, ref.ferr, rtol=TOL_F, what="mdl.ferr")
         np.testing.assert_array_equal(mdl.W, W0)                 # W untouched
         mdl.W = W0 * 1.5                                         # a new basis must invalidate the cache
         ref.W = W0 * 1.5
         mdl.factorize(niter=3, compute_w=False)
         ref.factorize(niter=3, compute_w=False)
-        assert rel_fro(mdl.H, ref.H) < TOL_X
+        assert rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
 
 
 def test_fixed_coefficients_loop_reuses_numerator(pm):
@@ -430,17 +430,17 @@ def test_fixed_coefficients_loop_reuses_numerator(pm):
     ref = NMFOracle(V, num_bases=24)
     ref.W, ref.H = W0.copy(), H0.copy()
     ref.factorize(niter=12, compute_h=False)
-    assert rel_fro(mdl.W, ref.W) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, ref.ferr, rtol=TOL_F)
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X
+    close(mdl.ferr, ref.ferr, rtol=TOL_F, what="mdl.ferr")
     np.testing.assert_array_equal(mdl.H, H0)
     mdl.H = H0 * 0.7                                         # new coefficients invalidate the cache
     ref.H = H0 * 0.7
     mdl.factorize(niter=4, compute_h=False)
     ref.factorize(niter=4, compute_h=False)
-    assert rel_fro(mdl.W, ref.W) < TOL_X
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X
     mdl.factorize(niter=3)                                   # and the full loop still works afterwards
     ref.factorize(niter=3)
-    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
 
 
 def test_single_element_edit_is_noticed(pm):
@@ -457,7 +457,7 @@ def test_single_element_edit_is_noticed(pm):
     mdl.factorize(niter=2)
     ref.factorize(niter=2)
     assert mdl.W[12345, 3] == 0.0                            # multiplicative updates keep a zero at zero
-    assert rel_fro(mdl.W, ref.W) < TOL_X and rel_fro(mdl.H, ref.H) < TOL_X
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
 
 
 @pytest.mark.parametrize("algo_name", ["NMF", "SNMF", "BNMF"])
@@ -493,7 +493,7 @@ def test_free_running_loop_matches_stepwise_loop(pm, algo_name):
                 conv_b = i
                 break
         assert (done_a, conv_a) == (done_b, conv_b), (niter, eps)
-        np.testing.assert_allclose(fa[:done_a], fb, rtol=1e-12)
+        close(fa[:done_a], fb, rtol=1e-12, what="fa[:done_a]")
         np.testing.assert_array_equal(a.get_w(), b.get_w())
         np.testing.assert_array_equal(a.get_h(), b.get_h())
         if algo_name == "BNMF":
@@ -506,7 +506,7 @@ def test_free_running_loop_matches_stepwise_loop(pm, algo_name):
         np.testing.assert_array_equal(a.get_h(), b.get_h())
         f2a, _, _ = a.factorize(3, conv_eps=0.0)
         f2b, _, _ = b.factorize(3, conv_eps=0.0)
-        np.testing.assert_allclose(f2a, f2b, rtol=1e-12)
+        close(f2a, f2b, rtol=1e-12, what="f2a")
         a.close(); b.close()
 
 
@@ -550,8 +550,8 @@ def test_tiled_kernels_vs_oracle(pm, cls_name, shape, k):
     o.W, o.H = W0.copy(), H0.copy()
     o.factorize(niter=4)
     tol = 5e-4 if cls_name == "SNMF" else 5e-5
-    assert rel_fro(mdl.W, o.W) < tol and rel_fro(mdl.H, o.H) < tol
-    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=2e-5)
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < tol and rel_fro(mdl.H, o.H, what="mdl.H") < tol
+    close(mdl.ferr, o.ferr, rtol=2e-5, what="mdl.ferr")
 
 
 @pytest.mark.parametrize("shape,k", [((2000, 300), 200), ((1500, 500), 129), ((700, 900), 300), ((3000, 64), 256)])
@@ -567,11 +567,11 @@ def test_nmf_more_than_128_bases(pm, shape, k):
     o = NMFOracle(V, num_bases=k)
     o.W, o.H = W0.copy(), H0.copy()
     o.factorize(niter=4)
-    assert rel_fro(mdl.W, o.W) < TOL_X and rel_fro(mdl.H, o.H) < TOL_X
-    np.testing.assert_allclose(mdl.ferr, o.ferr, rtol=5e-5)       # trace identity only at this width
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, o.H, what="mdl.H") < TOL_X
+    close(mdl.ferr, o.ferr, rtol=5e-5, what="mdl.ferr")       # trace identity only at this width
     mdl.update_w(); o.update_w()
     mdl.update_h(); o.update_h()
-    assert rel_fro(mdl.W, o.W) < TOL_X and rel_fro(mdl.H, o.H) < TOL_X
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, o.H, what="mdl.H") < TOL_X
     assert abs(mdl.frobenius_norm() - o.frobenius_norm()) <= 5e-5 * o.frobenius_norm()
 
 
@@ -592,9 +592,9 @@ def test_error_after_a_w_only_step_is_not_stale(pm, cls_name):
     a.factorize(niter=7, compute_h=False); o.factorize(niter=7, compute_h=False)
     # SNMF's W step with H fixed is a closed form: the error repeats and the loop stops at i == 2
     assert len(a.ferr) == len(o.ferr) == (2 if cls_name == "SNMF" else 7)
-    np.testing.assert_allclose(a.ferr, o.ferr, rtol=2e-5)
+    close(a.ferr, o.ferr, rtol=2e-5, what="a.ferr")
     tol = 5e-4 if cls_name == "SNMF" else 5e-5
-    assert rel_fro(a.W, o.W) < tol
+    assert rel_fro(a.W, o.W, what="a.W") < tol
     a.update_w(); o.update_w()
     assert abs(a.frobenius_norm() - o.frobenius_norm()) <= 2e-5 * o.frobenius_norm()
 
@@ -633,7 +633,158 @@ def test_free_running_fixed_basis_loop_matches_stepwise_loop(pm, algo_name):
             outs.append((done, conv, np.array(f), c.get_h(), c.get_w(), c.get_lambda() if algo_name == "BNMF" else None))
             c.close()
         assert outs[0][:2] == outs[1][:2], (niter, eps, outs[0][:2], outs[1][:2])
-        np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-12)
+        close(outs[0][2], outs[1][2], rtol=1e-12, what="outs[0][2]")
         np.testing.assert_array_equal(outs[0][3], outs[1][3])
         np.testing.assert_array_equal(outs[0][4], W0)
         assert outs[0][5] == outs[1][5]
+
+
+# ---- the plugin API: overridden hooks are called (nmf.py:182-202 is a template method) -----------
+def _plugin_classes(base, obase):
+    """The same user plug-in written against the product class and against the oracle class."""
+    def make(b):
+        class Plugin(b):
+            def __init__(self, *a, **kw):
+                b.__init__(self, *a, **kw)
+                self.calls = {"update_w": 0, "update_h": 0, "frobenius_norm": 0, "converged": 0}
+
+            def update_w(self):
+                self.calls["update_w"] += 1
+                b.update_w(self)
+                self.W[:, 0] *= 0.5                       # a user rule on top of the built-in step (in place)
+
+            def update_h(self):
+                self.calls["update_h"] += 1
+                b.update_h(self)
+
+            def frobenius_norm(self):
+                self.calls["frobenius_norm"] += 1
+                return b.frobenius_norm(self)
+
+            def converged(self, i):
+                self.calls["converged"] += 1
+                return i >= 4                            # user stopping rule: stop at the fifth iteration
+        return Plugin
+    return make(base), make(obase)
+
+
+@pytest.mark.parametrize("cls_name", ["NMF", "SNMF", "BNMF"])
+def test_overridden_hooks_are_called_like_the_reference(pm, cls_name):
+    import oracle
+    P, O = _plugin_classes(getattr(pm, cls_name), getattr(oracle, cls_name + "Oracle"))
+    rs = np.random.RandomState(31)
+    V = rs.random_sample((700, 256)).astype(np.float32)
+    if cls_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    W0, H0 = rs.random_sample((700, 24)), rs.random_sample((24, 256))
+    a, o = P(V, num_bases=24), O(V, num_bases=24)
+    a.W, a.H = W0.copy(), H0.copy()
+    o.W, o.H = W0.copy(), H0.copy()
+    a.factorize(niter=9)
+    o.factorize(niter=9)
+    assert a.calls == o.calls == {"update_w": 5, "update_h": 5, "frobenius_norm": 5, "converged": 2}
+    assert len(a.ferr) == len(o.ferr) == 4                   # the user's converged() fired at i == 4
+    tol = 5e-5 if cls_name == "SNMF" else TOL_X
+    assert rel_fro(a.W, o.W, what="a.W") < tol and rel_fro(a.H, o.H, what="a.H") < tol
+    close(a.ferr, o.ferr, rtol=2e-5, what="a.ferr")
+
+
+def test_hook_loop_equals_one_call_loop(pm):
+    """A subclass that overrides a hook WITHOUT changing it must get the bits of the one-call path
+    (the hook loop runs the same kernels; W and H stay on the device between the hooks)."""
+    class Same(pm.NMF):
+        n_w = 0
+
+        def update_w(self):
+            Same.n_w += 1
+            pm.NMF.update_w(self)
+
+    rs = np.random.RandomState(5)
+    V = rs.random_sample((9000, 256)).astype(np.float32)
+    W0, H0 = rs.random_sample((9000, 64)), rs.random_sample((64, 256))
+    a, b = pm.NMF(V, num_bases=64), Same(V, num_bases=64)
+    for mdl in (a, b):
+        mdl.W, mdl.H = W0.copy(), H0.copy()
+        w_obj = mdl.W
+        mdl.factorize(niter=7)
+        assert mdl.W is w_obj                                    # still the user's array, updated in place
+    assert Same.n_w == 7
+    np.testing.assert_array_equal(a.W, b.W)
+    np.testing.assert_array_equal(a.H, b.H)
+    np.testing.assert_array_equal(a.ferr, b.ferr)
+
+
+def test_instance_level_hook_and_show_progress(pm, caplog):
+    """A hook replaced on the INSTANCE is honoured too; show_progress=True logs every iteration as it
+    runs (nmf.py:191-194) -- the reference's message format."""
+    import logging
+    from oracle import NMFOracle
+    rs = np.random.RandomState(6)
+    V = rs.random_sample((300, 64)).astype(np.float32)
+    W0, H0 = rs.random_sample((300, 8)), rs.random_sample((8, 64))
+    mdl = pm.NMF(V, num_bases=8)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    seen = []
+    mdl.converged = lambda i: seen.append(i) or False
+    with caplog.at_level(logging.INFO, logger="pymf"):
+        mdl.factorize(niter=5, show_progress=True)
+    assert seen == [2, 3, 4]
+    msgs = [r.getMessage() for r in caplog.records if r.name == "pymf"]
+    assert [m.split(" FN:")[0] for m in msgs] == ["Iteration %d/5" % (i + 1) for i in range(5)]
+    assert [float(m.split(" FN:")[1]) for m in msgs] == [float(x) for x in mdl.ferr]
+    ref = NMFOracle(V, num_bases=8)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=5)
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
+    close(mdl.ferr, ref.ferr, rtol=TOL_F, what="mdl.ferr")
+
+
+# ---- the device copies follow in-place edits of the host arrays -----------------------------------
+def test_row_swap_and_sum_preserving_edits_are_noticed(pm):
+    from oracle import NMFOracle
+    rs = np.random.RandomState(14)
+    V = rs.random_sample((2000, 128)).astype(np.float32)
+    mdl = pm.NMF(V, num_bases=16)
+    np.random.seed(4)
+    mdl.factorize(niter=2)
+    ref = NMFOracle(V, num_bases=16)
+    ref.W, ref.H = mdl.W.copy(), mdl.H.copy()
+    for m_ in (mdl, ref):
+        m_.W[[5, 1500]] = m_.W[[1500, 5]]                    # swap two rows: same sum, same last element
+        m_.H[[0, 9]] = m_.H[[9, 0]]                          # permute two bases of H
+        m_.W[0, 0] += 0.25
+        m_.W[1, 0] -= 0.25                                   # sum-preserving poke
+        m_.factorize(niter=3)
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, ref.H, what="mdl.H") < TOL_X
+    close(mdl.ferr, ref.ferr, rtol=TOL_F, what="mdl.ferr")
+
+
+@pytest.mark.parametrize("cls_name", ["NMF", "SNMF"])
+def test_data_edited_in_place_is_noticed(pm, cls_name):
+    """The reference reads self.data[:, :] afresh in every hook (nmf.py:123,129): editing `data` in
+    place between two calls must reach the device (V, ||V||^2 and the cached partial sums)."""
+    import oracle
+    rs = np.random.RandomState(15)
+    V = rs.random_sample((1500, 128)).astype(np.float32)
+    W0, H0 = rs.random_sample((1500, 16)), rs.random_sample((16, 128))
+    Va, Vo = V.copy(), V.copy()
+    a = getattr(pm, cls_name)(Va, num_bases=16)
+    o = getattr(oracle, cls_name + "Oracle")(Vo, num_bases=16)
+    for m_ in (a, o):
+        m_.W, m_.H = W0.copy(), H0.copy()
+        m_.factorize(niter=3)
+    for m_, X in ((a, Va), (o, Vo)):
+        X *= 1.7                                             # in place: same object, new contents
+        X[100:200, :] = 0.25
+    assert abs(a.frobenius_norm() - o.frobenius_norm()) <= 2e-5 * o.frobenius_norm()
+    a.factorize(niter=3); o.factorize(niter=3)
+    tol = 5e-5 if cls_name == "SNMF" else TOL_X
+    assert rel_fro(a.W, o.W, what="a.W") < tol and rel_fro(a.H, o.H, what="a.H") < tol
+    close(a.ferr, o.ferr, rtol=2e-5, what="a.ferr")
+    # check_data = False: the upload happens once per object until invalidate_data() is called
+    a.check_data = False
+    Va[:, 3] = 0.0; Vo[:, 3] = 0.0
+    a.invalidate_data()
+    a.update_h(); o.update_h()
+    assert rel_fro(a.H, o.H, what="a.H") < tol
+    assert np.all(a.H[:, 3] == 0.0) or cls_name == "SNMF"
