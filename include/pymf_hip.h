@@ -168,6 +168,15 @@ int pmf_kernel_stats(pmf_ctx* ctx, const char** name, int64_t* launches, double*
  * in-place edits (permutations included) and re-upload.  Multi-threaded, memory speed. */
 int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
 
+/* Host transport for the cross-rank sums, for set-ups in which the ranks cannot form an RCCL communicator
+ * (plumbing checks with several ranks sharing one GPU; ranks without a common fabric).  Contexts created
+ * with nranks == 1 and no nccl_id only.  fn(user, buf, count, is_f64) must replace the `count` floats
+ * (is_f64 = 0) or doubles (1) at host pointer `buf` by their sum over all ranks and return 0; every
+ * rank's library calls it at the same points in the same order (where the RCCL build runs
+ * ncclAllReduce).  Each call is a blocking device -> host -> device round trip: not a fast path. */
+typedef int (*pmf_host_allreduce_fn)(void* user, void* buf, int64_t count, int32_t is_f64);
+int pmf_set_host_allreduce(pmf_ctx* ctx, pmf_host_allreduce_fn fn, void* user);
+
 /* Forget everything derived from V (||V||^2, cached partial sums): for streamed `data` that the caller
  * rebound or edited between calls. */
 int pmf_invalidate_v(pmf_ctx* ctx);

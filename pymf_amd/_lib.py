@@ -62,11 +62,14 @@ SYMBOLS = [
                                     _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                                     _c.POINTER(_c.c_double)]),
     ("pmf_host_checksum", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("pmf_set_host_allreduce", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p]),
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
     ("pmf_path_name", _c.c_char_p, [_ctx]),
 ]
+
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32)
 
 _lib = None
 
@@ -291,6 +294,21 @@ class Context(object):
                                              ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
         return dict(name=(name.value or b"").decode(), launches=int(n.value), mean_ms=float(ms.value),
                     flops_per_launch=float(fl.value), bytes_per_launch=float(by.value))
+
+    def set_host_allreduce(self, reduce_array):
+        """Route the cross-rank sums through `reduce_array(ndarray) -> ndarray` (the sum over all ranks)
+        instead of RCCL: pmf_set_host_allreduce.  For plumbing checks with ranks that share one GPU."""
+        def _cb(user, buf, count, is_f64):
+            try:
+                dt = np.float64 if is_f64 else np.float32
+                a = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_double if is_f64 else ctypes.c_float)),
+                                          shape=(int(count),))
+                a[:] = np.asarray(reduce_array(a.copy()), dtype=dt)
+                return 0
+            except Exception:            # never let an exception cross the C boundary
+                return 1
+        self._host_ar_cb = HOST_ALLREDUCE_FN(_cb)      # keep the trampoline alive
+        self._chk(self._lib.pmf_set_host_allreduce(self._h, ctypes.cast(self._host_ar_cb, ctypes.c_void_p), None))
 
     def invalidate_v(self):
         self._chk(self._lib.pmf_invalidate_v(self._h))

@@ -99,6 +99,9 @@ struct pmf_ctx {
   uint32_t st_flags = 0;
   int64_t st_rows_seen = 0;
   int st_tiles = 0;
+  pmf_host_allreduce_fn host_ar = nullptr;   // host transport for the cross-rank sums (pmf_set_host_allreduce)
+  void* host_ar_user = nullptr;
+  std::vector<unsigned char> ar_buf;
   bool profile = false;
   double last_loop_ms = 0.0;
   KernelStat stat;
@@ -233,11 +236,30 @@ int reduce_slabs(pmf_ctx* c, int nslabs) {
   return PMF_OK;
 }
 
-int allreduce_ps(pmf_ctx* c) {
+// Sum `count` floats (or doubles) at device pointer `p` over all ranks, in place, in stream order.
+// Transport: the context's RCCL communicator (one ncclAllReduce on the library's stream); or, when the
+// caller installed a host transport (pmf_set_host_allreduce: plumbing checks where the ranks cannot form
+// an RCCL communicator, e.g. several ranks sharing one GPU), a blocking round trip through the host.
+int allreduce_sum(pmf_ctx* c, void* p, size_t count, bool f64) {
+  if (c->host_ar) {
+    const size_t bytes = count * (f64 ? sizeof(double) : sizeof(float));
+    c->ar_buf.resize(bytes);
+    HIPCHK(c, hipMemcpyAsync(c->ar_buf.data(), p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->host_ar(c->host_ar_user, c->ar_buf.data(), (int64_t)count, f64 ? 1 : 0) != 0)
+      return fail(c, PMF_ENCCL, "the host all-reduce callback reported a failure");
+    HIPCHK(c, hipMemcpyAsync(p, c->ar_buf.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  }
   if (c->comm)
-    NCCLCHK(c, ncclAllReduce(c->dPS, c->dPS, (size_t)ps_elems(c), ncclFloat, ncclSum, c->comm, c->stream));
+    NCCLCHK(c, ncclAllReduce(p, p, count, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
   return PMF_OK;
 }
+
+bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != nullptr; }
+
+int allreduce_ps(pmf_ctx* c) { return allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false); }
 
 // ---- CSR (SNMF) ----------------------------------------------------------------------------
 int csr_w(pmf_ctx* c) {   // W = V (H^T inv(H H^T)); dGinvT is ready, dW1 holds M (np x KP)
@@ -362,7 +384,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
     HIPCHK(c, hipGetLastError());
     c0 += wdt;
   }
-  if (c->comm) NCCLCHK(c, ncclAllReduce(Ad, Ad, (size_t)np * np, ncclDouble, ncclSum, c->comm, c->stream));
+  PMFCHK(allreduce_sum(c, Ad, (size_t)np * np, true));
   // 2./3. eigen-decomposition, top-k selection
   {
     const int64_t items = (int64_t)(nj / 2) * (nj / 2) + (int64_t)(nj / 2) * nj;
@@ -391,7 +413,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(256), 0, c->stream, part, nblk, KP, norms);
   HIPCHK(c, hipGetLastError());
-  if (c->comm) NCCLCHK(c, ncclAllReduce(norms, norms, (size_t)2 * KP, ncclDouble, ncclSum, c->comm, c->stream));
+  PMFCHK(allreduce_sum(c, norms, (size_t)2 * KP, true));
   hipLaunchKernelGGL(k_nndsvd_finalize, dim3(1), dim3(1024), 0, c->stream, QT, ld, order, sv, norms, n, c->k, KP, np,
                      c->dH, wscale, wmode);
   HIPCHK(c, hipGetLastError());
@@ -440,7 +462,7 @@ int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2)
   PMFCHK(launch_resid(c, true, lamb));
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 4);
   HIPCHK(c, hipGetLastError());
-  if (c->comm) NCCLCHK(c, ncclAllReduce(c->dScal + 4, c->dScal + 4, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  PMFCHK(allreduce_sum(c, c->dScal + 4, 1, true));
   HIPCHK(c, hipMemcpyAsync(&c->rnmf_err2, c->dScal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   c->s_valid = true;
   return PMF_OK;
@@ -892,8 +914,7 @@ int frobenius_direct(pmf_ctx* c, double* out) {
   PMFCHK(launch_resid(c, false, 0.f));
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
   HIPCHK(c, hipGetLastError());
-  if (c->comm)
-    NCCLCHK(c, ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  PMFCHK(allreduce_sum(c, c->dScal, 1, true));
   double ss = 0.0;
   HIPCHK(c, hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -917,7 +938,7 @@ int ensure_vnorm(pmf_ctx* c) {
   if (c->vnorm_valid) return PMF_OK;
   if (!c->vnorm_local_valid) PMFCHK(local_vnorm(c));
   HIPCHK(c, hipMemcpyAsync(c->dScal, c->dScal + 6, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  if (c->comm) NCCLCHK(c, ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  PMFCHK(allreduce_sum(c, c->dScal, 1, true));
   HIPCHK(c, hipMemcpyAsync(&c->vnorm2, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->vnorm_valid = true;
@@ -964,17 +985,18 @@ int do_frobenius(pmf_ctx* c, double* out) {
     // the identity cancels: direct pass (plain FMAs; num_bases > 128 has no MFMA residual kernel)
     const int gx = c->np / 64, gy = (int)(c->mp / 64);
     const int nb2 = gx * gy;
+    DevTemps tmp;                       // frees `part` on every exit
     double* part = nullptr;
-    HIPCHK(c, hipMalloc(&part, (size_t)nb2 * sizeof(double)));
+    PMFCHK(talloc(c, tmp, &part, (size_t)nb2));
     hipLaunchKernelGGL(k_resid_bigk, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
                        c->KP, c->dH, (int64_t)c->np, part);
+    HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, part, nb2, c->dScal);
-    if (c->comm) ncclAllReduce(c->dScal, c->dScal, 1, ncclDouble, ncclSum, c->comm, c->stream);
+    HIPCHK(c, hipGetLastError());
+    PMFCHK(allreduce_sum(c, c->dScal, 1, true));
     double ss = 0.0;
-    hipError_t e1 = hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    hipError_t e2s = hipStreamSynchronize(c->stream);
-    (void)hipFree(part);
-    if (e1 != hipSuccess || e2s != hipSuccess) return fail(c, PMF_EHIP, "direct residual (num_bases > 128) failed");
+    HIPCHK(c, hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     *out = std::sqrt(ss);
     return PMF_OK;
   }
@@ -1293,7 +1315,8 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   // (W^T V | W^T W) is formed once, every further iteration is the H-step kernel alone
   const bool h_only = !cw && ch && ce && c->nb == 1 && !c->v_csr &&
                       (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF);
-  const bool can_free_run = (fused && ce && c->algo != PMF_ALGO_RNMF) || h_only;   // NMF, BNMF, SNMF on the fused kernel
+  // (a host transport for the cross-rank sums blocks on the host every iteration: nothing to free-run)
+  const bool can_free_run = ((fused && ce && c->algo != PMF_ALGO_RNMF) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
@@ -1352,7 +1375,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
         c->g_parts = part ? std::min(c->np / 64, PMF_HGRAM_MAX_WGS) : 0;
       }
       c->trace_ready = false;
-      if (c->comm) { c->ps_valid = false; c->trace_ready = false; }
+      if (multi_rank(c)) { c->ps_valid = false; c->trace_ready = false; }
       if (hstop[0] == 1) {                                // nmf.py:198-202
         if (converged_at) *converged_at = s_it;
         break;
@@ -1567,7 +1590,7 @@ int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
                 std::to_string(c->m) + " rows");
   HIPCHK(c, hipSetDevice(c->device));
   if (c->st_flags & PMF_STREAM_RESID) {
-    if (c->comm) NCCLCHK(c, ncclAllReduce(c->dStAcc + 1, c->dStAcc + 1, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    PMFCHK(allreduce_sum(c, c->dStAcc + 1, 1, true));
     double ss = 0.0;
     HIPCHK(c, hipMemcpyAsync(&ss, c->dStAcc + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1575,7 +1598,7 @@ int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
     return PMF_OK;
   }
   if (c->st_vnorm_pending) {
-    if (c->comm) NCCLCHK(c, ncclAllReduce(c->dStAcc, c->dStAcc, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    PMFCHK(allreduce_sum(c, c->dStAcc, 1, true));
     HIPCHK(c, hipMemcpyAsync(&c->vnorm2, c->dStAcc, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->vnorm_valid = true;
@@ -1720,6 +1743,15 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2) {
 
 // The caller changed V behind the library's back (a streamed `data` object was rebound or edited): forget
 // everything derived from it -- ||V||^2, (W^T V | W^T W), the cached V H^T.
+int pmf_set_host_allreduce(pmf_ctx* c, pmf_host_allreduce_fn fn, void* user) {
+  if (!c) return PMF_EINVAL;
+  if (fn && c->comm) return fail(c, PMF_EINVAL, "pmf_set_host_allreduce: the context already has an RCCL communicator");
+  c->host_ar = fn;
+  c->host_ar_user = user;
+  c->ps_valid = false; c->vnorm_valid = false; c->trace_ready = false;
+  return PMF_OK;
+}
+
 int pmf_invalidate_v(pmf_ctx* c) {
   if (!c) return PMF_EINVAL;
   c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false; c->trace_ready = false;

@@ -51,6 +51,16 @@ def world():
     return _WORLD
 
 
+def transport():
+    """How the per-iteration sums cross the ranks: "rccl" (default: ncclAllReduce over xGMI inside
+    libpymf_hip) or "host" (env PYMF_DIST_TRANSPORT=host: through this module's TCP star and
+    pmf_set_host_allreduce -- for plumbing checks where several ranks share one GPU; slow)."""
+    t = os.environ.get("PYMF_DIST_TRANSPORT", "rccl").lower()
+    if t not in ("rccl", "host"):
+        raise ValueError("PYMF_DIST_TRANSPORT must be 'rccl' or 'host'")
+    return t
+
+
 # ---- framing ---------------------------------------------------------------------------------
 def _send(sock, payload):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
@@ -165,6 +175,8 @@ def init_from_env(make_nccl_id=None, timeout=None):
     token = _token(addr, mport, size)
     _WORLD = World(rank, size, local_rank, None)
     _PEERS = _serve(addr, base, size, token, timeout) if rank == 0 else _join(addr, base, rank, token, timeout)
+    if make_nccl_id is None and transport() == "host":
+        return _WORLD                                  # no RCCL communicator will be created
     if make_nccl_id is None:
         from . import _lib
         make_nccl_id = _lib.nccl_unique_id

@@ -160,9 +160,17 @@ class NMF(object):
     def _context(self):
         if self._ctx is None:
             w = self._world()
-            self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
-                                     self._num_bases, device=w.local_rank, rank=w.rank,
-                                     nranks=w.size, nccl_id=w.nccl_id)
+            if w.size > 1 and _dist.transport() == "host":
+                # ranks that cannot form an RCCL communicator (e.g. sharing one GPU): the sums of
+                # (W^T V | W^T W) cross the ranks through the host (pmf_set_host_allreduce)
+                dev = w.local_rank % max(1, _lib.device_count())
+                self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
+                                         self._num_bases, device=dev)
+                self._ctx.set_host_allreduce(_dist.allreduce_sum_array)
+            else:
+                self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
+                                         self._num_bases, device=w.local_rank, rank=w.rank,
+                                         nranks=w.size, nccl_id=w.nccl_id)
         return self._ctx
 
     def invalidate_data(self):

@@ -1,0 +1,164 @@
+"""world_size-N worker for the CLASS-level multi-rank path: pymf_amd.NMF / SNMF / RNMF / NNDSVD are
+given this rank's block of rows, initialise lazily (rank 0's RNG stream decides), factorize, and the
+gathered result must equal the UNSHARDED oracle.
+
+  --fake : no GPU -- pymf_amd._lib.Context is replaced by a test double that does the per-rank math
+           with the oracle's functions and sums (W^T V | W^T W) through pymf_amd.dist (CPU suite:
+           checks the host logic -- row spans, W0 slices, H0, shapes -- under WORLD_SIZE > 1);
+  else   : the real library on the GPU(s); with PYMF_DIST_TRANSPORT=host the ranks may share a GPU.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pymf_amd import dist, _lib          # noqa: E402
+import pymf_amd                          # noqa: E402
+import oracle                            # noqa: E402
+
+FAKE = "--fake" in sys.argv
+
+
+class FakeContext(object):
+    """Per-rank math of one context with NumPy (float64) + the cross-rank sum through dist."""
+
+    def __init__(self, algo, m, n, k, device=0, rank=0, nranks=1, nccl_id=None):
+        assert algo == _lib.ALGO_NMF
+        self.m, self.n, self.k = m, n, k
+        self.path_name = "fake"
+
+    def set_v_dense(self, V):
+        assert V.shape == (self.m, self.n)
+        self.V = np.asarray(V, dtype=np.float64)
+
+    def set_w(self, W):
+        assert W.shape == (self.m, self.k), (W.shape, self.m, self.k)
+        self.W = np.array(W, dtype=np.float64)
+
+    def set_h(self, H):
+        assert H.shape == (self.k, self.n)
+        self.H = np.array(H, dtype=np.float64)
+
+    def get_w(self):
+        return self.W.astype(np.float32)
+
+    def get_h(self):
+        return self.H.astype(np.float32)
+
+    def set_host_allreduce(self, fn):
+        pass
+
+    def invalidate_v(self):
+        pass
+
+    def update_w(self):
+        oracle.nmf_update_w(self.V, self.W, self.H)
+
+    def update_h(self):
+        ps = dist.allreduce_sum_array(np.concatenate([self.W.T.dot(self.V), self.W.T.dot(self.W)], axis=1))
+        P, S = ps[:, :self.n], ps[:, self.n:]
+        self.H = (self.H * P) / (S.dot(self.H) + 1e-9)
+
+    def frobenius(self):
+        e2 = dist.allreduce_sum_array(np.array([np.sum((self.V - self.W.dot(self.H)) ** 2)]))
+        return float(np.sqrt(e2[0]))
+
+    def factorize(self, niter, compute_w=True, compute_h=True, compute_err=True, conv_eps=1e-8):
+        ferr = np.zeros(max(niter, 1))
+        for i in range(niter):
+            if compute_w:
+                self.update_w()
+            if compute_h:
+                self.update_h()
+            if compute_err:
+                ferr[i] = self.frobenius()
+        return (ferr[:niter] if compute_err else None), niter, -1
+
+    def close(self):
+        pass
+
+
+def gather_rows(block):
+    parts = dist.allgather_bytes(np.ascontiguousarray(block, dtype=np.float64).tobytes())
+    return np.concatenate([np.frombuffer(p, dtype=np.float64).reshape(-1, block.shape[1]) for p in parts], axis=0)
+
+
+def check(name, got, want, tol):
+    err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300)
+    print("rank %d %s rel %.3g" % (dist.world().rank, name, err))
+    assert err < tol, (name, err, tol)
+
+
+def main():
+    w = dist.init_from_env()
+    assert w.size > 1
+    if FAKE:
+        _lib.Context = FakeContext
+        pymf_amd.nmf._fingerprint = lambda a: (id(a), a.shape, float(np.sum(a)))     # no library needed
+    tolx, tolf = (1e-6, 1e-6) if FAKE else (2e-5, 1e-5)   # the double hands W, H back as float32, like the library
+    m, n, k = 1003, 256, 16                    # uneven split over the ranks
+    V = np.random.RandomState(7).random_sample((m, n)).astype(np.float32)
+    lo, hi = w.row_range(m)
+
+    # ---- NMF, lazily initialised: ranks start with DIFFERENT seeds, rank 0's stream must decide ----
+    np.random.seed(100 + w.rank)
+    mdl = pymf_amd.NMF(V[lo:hi], num_bases=k)
+    mdl.factorize(niter=4)
+    assert mdl.W.shape == (hi - lo, k) and mdl.H.shape == (k, n)
+    np.random.seed(100)
+    ref = oracle.NMFOracle(V, num_bases=k)
+    ref.factorize(niter=4)
+    check("NMF W", gather_rows(mdl.W), ref.W, tolx)
+    check("NMF H", mdl.H, ref.H, tolx)
+    check("NMF ferr", mdl.ferr, ref.ferr, tolf)
+    hs = dist.allgather_bytes(np.ascontiguousarray(mdl.H).tobytes())
+    assert all(h == hs[0] for h in hs), "H must be bit-identical on every rank"
+    # single hooks and the error under the multi-rank world
+    mdl.update_w(); ref.update_w()
+    mdl.update_h(); ref.update_h()
+    check("NMF hooks W", gather_rows(mdl.W), ref.W, tolx)
+    check("NMF hooks H", mdl.H, ref.H, tolx)
+    assert abs(mdl.frobenius_norm() - ref.frobenius_norm()) <= tolf * ref.frobenius_norm()
+
+    if not FAKE:
+        # ---- SNMF (mixed-sign data) ----
+        Vs = (V - 0.4).astype(np.float32)
+        np.random.seed(200 + w.rank)
+        s = pymf_amd.SNMF(Vs[lo:hi], num_bases=k)
+        s.factorize(niter=3)
+        np.random.seed(200)
+        so = oracle.SNMFOracle(Vs, num_bases=k)
+        so.factorize(niter=3)
+        check("SNMF W", gather_rows(s.W), so.W, 5e-5)
+        check("SNMF H", s.H, so.H, 2e-5)
+        check("SNMF ferr", s.ferr, so.ferr, 2e-5)
+        # ---- RNMF: init_h normalises the columns of W over ALL ranks' rows ----
+        from pymf_amd.rnmf import RNMF
+        Vr = V.copy()
+        Vr.flat[np.random.RandomState(3).randint(0, Vr.size, size=Vr.size // 300)] += 5.0
+        np.random.seed(300 + w.rank)
+        r = RNMF(Vr[lo:hi], num_bases=k, lamb=1.0)
+        r.factorize(niter=3)
+        np.random.seed(300)
+        ro = oracle.RNMFOracle(Vr, num_bases=k, lamb=1.0)
+        ro.factorize(niter=3)
+        check("RNMF W", gather_rows(r.W), ro.W, 2e-3)
+        check("RNMF H", r.H, ro.H, 2e-3)
+        check("RNMF ferr", r.ferr, ro.ferr, 2e-4)
+        # ---- NNDSVD: Gram matrix and split norms summed over the ranks ----
+        nd = pymf_amd.NNDSVD(V[lo:hi], num_bases=6)
+        nd.factorize()
+        no = oracle.NNDSVDOracle(V, num_bases=6)
+        no.factorize()
+        check("NNDSVD W", gather_rows(nd.W), no.W, 2e-3)
+        check("NNDSVD H", nd.H, no.H, 2e-3)
+    dist.barrier()
+    dist.shutdown()
+    print("rank %d ok" % w.rank)
+
+
+if __name__ == "__main__":
+    main()

@@ -66,3 +66,42 @@ def test_world_under_the_torchrun_launcher():
     out = p.stdout.decode()
     assert p.returncode == 0, out
     assert "rank 0 ok" in out and "rank 1 ok" in out
+
+
+def _spawn_workers(script, size, extra_args=(), extra_env=None, timeout=600):
+    port = _free_port()
+    procs = []
+    for rank in range(size):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script)] + list(extra_args),
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode())
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
+        assert "rank %d ok" % rank in out
+    return outs
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_class_level_multi_rank_path_on_cpu(size):
+    """pymf_amd.NMF under WORLD_SIZE > 1 with a test double for the device context: the host logic
+    (global row span, W0 slice of rank 0's stream, replicated H0, shapes) against the unsharded oracle."""
+    _spawn_workers("_dist_class_worker.py", size, extra_args=["--fake"],
+                   extra_env={"PYMF_DIST_TRANSPORT": "host"})       # no RCCL id: there is no GPU here
+
+
+@pytest.mark.gpu
+def test_class_level_multi_rank_path_on_one_gpu():
+    """Two ranks sharing GPU 0, the real library, cross-rank sums through the host transport
+    (PYMF_DIST_TRANSPORT=host -> pmf_set_host_allreduce): NMF / SNMF / RNMF / NNDSVD objects fed
+    their row blocks must reproduce the unsharded oracle."""
+    _spawn_workers("_dist_class_worker.py", 2, extra_env={"PYMF_DIST_TRANSPORT": "host", "LOCAL_RANK": "0"})
