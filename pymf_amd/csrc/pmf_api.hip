@@ -58,6 +58,8 @@ struct pmf_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float *dV = nullptr, *dW = nullptr, *dH = nullptr, *dG = nullptr, *dPS = nullptr;
   float *dSlab = nullptr, *dW1 = nullptr, *dGinvT = nullptr;
+  float* dMT = nullptr;         // SNMF: M^T = inv(H H^T) H, [KP][np] (k_snmf_mt)
+  double* dGinvD = nullptr;     // SNMF: inv(H H^T) in float64, [KP][KP]
   float* dD = nullptr;          // RNMF: D = S - V (rnmf.py:102,111), [mp][np]
   bool s_valid = false;         // RNMF: D has been formed (update_s ran)
   double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
@@ -262,11 +264,7 @@ bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != n
 int allreduce_ps(pmf_ctx* c) { return allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false); }
 
 // ---- CSR (SNMF) ----------------------------------------------------------------------------
-int csr_w(pmf_ctx* c) {   // W = V (H^T inv(H H^T)); dGinvT is ready, dW1 holds M (np x KP)
-  const int E = c->np * c->KP;
-  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
-                     (int64_t)c->np, c->np, c->KP, c->dGinvT, c->dW1);
-  HIPCHK(c, hipGetLastError());
+int csr_w(pmf_ctx* c) {   // W = V M, M = H^T inv(H H^T) (np x KP) in dW1 (snmf_inverse formed it)
   const unsigned blocks = (unsigned)std::min<int64_t>((c->mp + 3) / 4, 256 * 16);
   if (c->KP <= 64)
     hipLaunchKernelGGL((k_csr_w<1>), dim3(blocks), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,
@@ -699,12 +697,18 @@ int nmf_fused_iteration(pmf_ctx* c) {
 }
 
 // ---- SNMF -----------------------------------------------------------------------------------
-int snmf_inverse(pmf_ctx* c) {   // dGinvT = inv(H H^T)^T (float64 Gauss-Jordan in registers), identity on the padding
+// inv(H H^T) in float64 (Gauss-Jordan in registers, identity on the padding), then M^T = inv(H H^T) H in
+// float64, rounded once: dMT [KP][np] for the dense kernels, dW1 = M [np][KP] for the CSR kernels.
+int snmf_inverse(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
   if (c->KP <= 64)
-    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
+    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
   else
-    hipLaunchKernelGGL((k_inverse_spd<8>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvT);
+    hipLaunchKernelGGL((k_inverse_spd<8>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
+                     (int64_t)c->np, c->np, c->KP, c->dGinvD, c->v_csr ? (float*)nullptr : c->dMT,
+                     c->v_csr ? c->dW1 : (float*)nullptr);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -715,8 +719,7 @@ int snmf_update_w(pmf_ctx* c) {
   if (c->fused_wgs > 0 && !c->v_csr) return snmf_fused_pass(c);   // as nmf_update_w: one pass, (P | S) kept for update_h
   PMFCHK(snmf_inverse(c));
   if (c->v_csr) return csr_w(c);
-  PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
-  return rowgemm<EPI_STORE>(c, c->dW1, c->KP, c->KP, c->dGinvT, c->KP, nullptr, nullptr, c->dW);
+  return rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dMT, c->np, nullptr, nullptr, c->dW);   // W = V M^T
 }
 
 int snmf_inverse(pmf_ctx* c);
@@ -727,7 +730,7 @@ int snmf_fused_pass(pmf_ctx* c) {
   c->trace_ready = false;
   PMFCHK(snmf_inverse(c));
   stat_begin(c);
-  const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dH, c->dGinvT, c->mp,
+  const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dMT, nullptr, c->mp,
                                c->fused_wgs, 0.f, c->dSlab, c->stop_arg);
   stat_end(c);
   if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
@@ -806,11 +809,7 @@ bool csr_fused_ok(const pmf_ctx* c) {
 
 int snmf_csr_fused_iteration(pmf_ctx* c) {
   c->ps_valid = false;
-  PMFCHK(snmf_inverse(c));
-  const int E = c->np * c->KP;
-  hipLaunchKernelGGL(k_snmf_m, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
-                     (int64_t)c->np, c->np, c->KP, c->dGinvT, c->dW1);
-  HIPCHK(c, hipGetLastError());
+  PMFCHK(snmf_inverse(c));            // leaves M = H^T inv(H H^T) in dW1
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -1036,7 +1035,9 @@ void set_stat_model(pmf_ctx* c) {
     c->stat.bytes = 4.0 * (m * n + 2.0 * m * k);
   } else if (c->algo == PMF_ALGO_SNMF && c->fused_wgs > 0) {
     c->stat.name = fused_kernel_name(c->NT, c->np, FUSED_SNMF);
-    c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;   // V H^T, (.) inv, W^T V, W^T W
+    // SURVEY 8(d) counts V H^T, (.) inv, W^T V, W^T W; the kernel EXECUTES V M^T (2mnk), W^T V (2mnk) and
+    // the upper triangle of W^T W (m k (k + 16)): 4mnk + m k^2 + 16 m k
+    c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;
     c->stat.bytes = 4.0 * (m * n + m * k);               // V read once, W written once
   } else if (c->algo == PMF_ALGO_NMFALS) {
     c->stat.name = "k_nnqp(update_w)";
@@ -1141,6 +1142,10 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dGinvT, (size_t)c->KP * c->KP));
     }
+    if (algo == PMF_ALGO_SNMF) {
+      PMFCHK(dalloc(c, &c->dMT, (size_t)c->KP * c->np));
+      PMFCHK(dalloc(c, &c->dGinvD, (size_t)c->KP * c->KP));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PMF_OK;
   }();
@@ -1169,7 +1174,8 @@ int pmf_ctx_destroy(pmf_ctx* c) {
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
-                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2})
+                  (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
+                  (void*)c->dMT, (void*)c->dGinvD})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);

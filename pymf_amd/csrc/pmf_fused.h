@@ -19,9 +19,11 @@
 // NEXT block is DMA-issued the moment phase B has finished with panel p: a single
 // LDS buffer gives a full block of prefetch distance.
 //
-// SNMF = true builds the semi-NMF W step into the same pass (pymf/snmf.py:67-70): the second
-// small product is W_b = Num inv(H H^T) instead of Den = W_b G, Num goes through the wave's W
-// image (accumulator layout -> A-fragment layout), no old W is read at all, and G holds inv^T.
+// MODE = FUSED_SNMF builds the semi-NMF W step into the same pass (pymf/snmf.py:67-70), reassociated:
+// W_b = (V_b H^T) inv(H H^T) = V_b M^T with M^T = inv(H H^T) H formed beforehand in float64
+// (k_snmf_mt): the kernel is handed M^T in the place of H, phase A's product IS the new W block
+// (already in the accumulator layout phase B wants), there is no second small product, no old W is
+// read and G is not used.
 //
 // Accumulators: P = NT x 4*NPANEL tiles and S = NT x NT tiles of 16x16 (4 VGPRs
 // each) stay in registers for the wave's whole row range; one wave per SIMD
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       const float* src = H + (size_t)bas * NP + 64 * p + 4 * (dchunk ^ (row & 15));
       PMF_GLDS16(src, sH + p * (KP * 64) + rg * 256);
     }
-    for (int rg = wv; rg < KP / 4; rg += 4) {                  // G: rows 4rg..4rg+3
+    for (int rg = wv; rg < (SNMF ? 0 : KP / 4); rg += 4) {     // G: rows 4rg..4rg+3 (SNMF: no G)
       const int row = 4 * rg + drow;
       const int bas = NT * (row & 15) + (row >> 4);
       int c = dchunk ^ (row & 15);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   for (int nt = 0; nt < NT; ++nt) wp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int NSN = 4 * NPANEL;      // Num steps (one 16-byte k-group each)
-  constexpr int NSA = NSN + NT;        // + Den steps
+  constexpr int NSA = SNMF ? NSN : NSN + NT;   // + Den steps (SNMF: phase A's product is the new W itself)
 
 #ifdef PMF_STAMPS
   PMF_STAMP(tk1);
@@ -276,19 +278,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     load_step(0, 0);
 #pragma unroll
     for (int s = 0; s < NSA; ++s) {
-      if (SNMF && s == NSN) {
-        // Num is complete: accumulator layout -> the wave's W image, then read it back as A
-        // fragments (same wave, LDS executes a wave's accesses in order)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = 4 * kq + j, col = NT * i + nt;
-            sW[vtile_off(row, col >> 2) + (col & 3)] = num[nt][j];
-          }
-        load_step(NSN, NSN & 1);
-      }
-      if (s + 1 < NSA && !(SNMF && s + 1 == NSN)) {
+      if (s + 1 < NSA) {
         if (s + 1 < NSN && ((s + 1) & 3) == 0) wait_panel((s + 1) >> 2);
         load_step(s + 1, (s + 1) & 1);
       }
@@ -308,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       // issue order inside the step: one LDS read (of step s+1) per 2 MFMAs (of step s), so a
       // read's issue slot hides under an executing MFMA and the last read is >= 6 MFMAs old when
       // the next step needs it; the DMA goes last
-      if (s + 1 < NSA && !(SNMF && (s + 1 == NSN || s == NSN))) {
+      if (s + 1 < NSA) {
 #pragma unroll
         for (int g = 0; g < NT + 1; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, NT >= 4 ? 2 : 1, 0);   // MFMA
@@ -426,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float w = den[nt][j];                        // W = (V H^T) inv(H H^T), snmf.py:70
+          const float w = num[nt][j];                        // W = V (inv(H H^T) H)^T, snmf.py:67-70 reassociated
           wn[nt][j] = w;
           wdst[j * KP + nt] = w;
 #pragma unroll
@@ -612,7 +602,7 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
   return PMF_OK;
 }
 
-// G: H H^T (NMF) or inv(H H^T)^T (SNMF), [KP][KP] float32.
+// G: H H^T [KP][KP] float32 (NMF, BNMF, RNMF).  FUSED_SNMF: H is M^T = inv(H H^T) H and G is unused.
 static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
                                const float* H, const float* G, int64_t mp, int wgs, float lamb,
                                float* slab, const int* stop = nullptr, int ngp = 0) {

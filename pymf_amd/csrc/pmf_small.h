@@ -349,7 +349,8 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
 // 128 x 128: 153 us as 1024 threads x 16 entries with per-entry case selects -> see DESIGN 3.3.
 template <int B>
 __global__ __launch_bounds__(256) void k_inverse_spd(const double* __restrict__ Gd, int ld, int k,
-                                                     float* __restrict__ GinvT) {
+                                                     float* __restrict__ GinvT,
+                                                     double* __restrict__ Ginv64 = nullptr) {
   constexpr int KP = 16 * B;
   __shared__ double prow[2][KP];
   __shared__ double pcol[2][KP];
@@ -397,8 +398,44 @@ __global__ __launch_bounds__(256) void k_inverse_spd(const double* __restrict__ 
 #pragma unroll
     for (int v = 0; v < B; ++v) {
       const int r = ty + 16 * u, c = tx + 16 * v;     // GinvT[c][r] = inv[r][c]
-      if (r < ld && c < ld) GinvT[(int64_t)c * ld + r] = (r < k && c < k) ? (float)a[u][v] : (r == c ? 1.f : 0.f);
+      if (r < ld && c < ld) {
+        if (GinvT) GinvT[(int64_t)c * ld + r] = (r < k && c < k) ? (float)a[u][v] : (r == c ? 1.f : 0.f);
+        if (Ginv64) Ginv64[(int64_t)r * ld + c] = (r < k && c < k) ? a[u][v] : (r == c ? 1.0 : 0.0);
+      }
     }
+}
+
+// SNMF W step, reassociated:  W = (V H^T) inv(H H^T) = V M^T  with  M^T = inv(H H^T) H  (k x n).
+// H H^T of a square-ish H is ill-conditioned (k = n = 128, uniform H: cond ~ 1e7); multiplying a
+// float32 V H^T by a float32 copy of the inverse loses cond * 1e-7 of W -- the reference's own
+// all-float32 path is off by 2-12 % there.  M^T is a k x n matrix: it is formed
+// HERE in float64 from the float64 inverse and only then rounded, so the big product V M^T sees
+// operands that are exact to float32 rounding and nothing is amplified; it also drops the m k^2
+// product from the pass.  Writes both layouts: MT [KP][np] (dense kernels: the "H" operand) and
+// M [np][KP] (CSR kernels gather rows of it).  grid = (np / 16, KP / 16), 256 threads.
+__global__ __launch_bounds__(256) void k_snmf_mt(const float* __restrict__ H, int64_t ldh, int np, int KP,
+                                                 const double* __restrict__ Ginv64, float* __restrict__ MT,
+                                                 float* __restrict__ M) {
+  __shared__ double gs[16][17];    // inv[kp0 + r][k0 + c]
+  __shared__ double hs[16][17];    // H[k0 + r][col0 + c]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int col0 = blockIdx.x * 16, kp0 = blockIdx.y * 16;
+  double s = 0.0;                  // MT[kp0 + ty][col0 + tx]
+  for (int k0 = 0; k0 < KP; k0 += 16) {
+    gs[ty][tx] = Ginv64[(int64_t)(kp0 + ty) * KP + k0 + tx];
+    hs[ty][tx] = (double)H[(int64_t)(k0 + ty) * ldh + col0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) s = fma(gs[ty][kk], hs[kk][tx], s);
+    __syncthreads();
+  }
+  const float r = (float)s;
+  if (MT) MT[(int64_t)(kp0 + ty) * np + col0 + tx] = r;
+  if (M) {                         // transposed through LDS so that both stores are row-contiguous
+    gs[ty][tx] = s;
+    __syncthreads();
+    M[(int64_t)(col0 + ty) * KP + kp0 + tx] = (float)gs[tx][ty];
+  }
 }
 
 // Per-block float64 partials of sum(X^2) over a padded [rows][ld] buffer (padding is zero).

@@ -33,6 +33,53 @@ def load_reference():
     return mods
 
 
+def load_reference_nmfals():
+    """pymf/nmfals.py ITSELF (nmfals.py:70-97), imported unmodified next to a stand-in for its one
+    third-party dependency: `cvxopt` is absent from this container (and un-pinned in the reference's
+    setup.py:12-16), so `cvxopt.base.matrix` is an ndarray wrapper and `cvxopt.solvers.qp(P, q, G, h)`
+    returns the EXACT minimiser of the strictly convex QP the reference poses (G = -I, h = 0: x >= 0)
+    through scipy.optimize.nnls on a square-root factor of P.  What these goldens pin is nmfals.py's own
+    data flow -- HA / FA construction with its signs and float64 casts, the per-column scatter :75 and
+    per-row scatter :90, the eager map -- NOT cvxopt's interior-point digits (still "parity unpinned",
+    SURVEY 8(c)): IPM returns ~1e-9 positives where the exact minimiser has zeros."""
+    import scipy.optimize
+
+    class _Matrix(np.ndarray):
+        pass
+
+    def matrix(x, size=None):
+        if size is not None:
+            a = np.full(size, float(x), dtype=np.float64)
+        else:
+            a = np.array(x, dtype=np.float64)
+            if a.ndim == 1:
+                a = a.reshape(-1, 1)
+        return a.view(_Matrix)
+
+    def qp(P, q, G=None, h=None):
+        P = np.asarray(P, dtype=np.float64)
+        q = np.asarray(q, dtype=np.float64).reshape(-1)
+        k = P.shape[0]
+        assert np.array_equal(np.asarray(G), -np.eye(k)) and not np.any(np.asarray(h)), "only x >= 0 is posed (nmfals.py:79-80)"
+        lam, Q = np.linalg.eigh((P + P.T) / 2.0)
+        keep = lam > lam.max() * 1e-13
+        A = (np.sqrt(lam[keep])[:, None]) * Q[:, keep].T          # A^T A = P on its range
+        b = -(Q[:, keep].T.dot(q)) / np.sqrt(lam[keep])           # 1/2|Ax - b|^2 = 1/2 x'Px + q'x + const
+        x, _ = scipy.optimize.nnls(A, b, maxiter=50 * k)
+        return {"x": matrix(x), "status": "optimal"}
+
+    cv = types.ModuleType("cvxopt")
+    cv.base = types.ModuleType("cvxopt.base")
+    cv.base.matrix = matrix
+    cv.solvers = types.ModuleType("cvxopt.solvers")
+    cv.solvers.qp = qp
+    cv.solvers.options = {}
+    sys.modules.update({"cvxopt": cv, "cvxopt.base": cv.base, "cvxopt.solvers": cv.solvers})
+    mod = importlib.import_module("pymf.nmfals")
+    mod.map = lambda f, *a: list(builtins.map(f, *a))             # Py2 eager map (nmfals.py:82,97)
+    return mod
+
+
 def run_case(cls, V, k, niter, seed, cast32, flags=None, w0=None, h0=None):
     """Run reference class; returns dict of arrays."""
     np.random.seed(seed)
@@ -129,6 +176,32 @@ def main():
     np.random.seed(400401)
     A = np.random.random((3, 50)) + 2.0
     add("nnls_reftest", NNLS, A, dict(V=A), 4, 10, 11, False)
+
+    # NMFALS through nmfals.py itself (exact-QP stand-in for cvxopt, see load_reference_nmfals)
+    ALS = load_reference_nmfals().NMFALS
+    add("nmfals_24x18_k4", ALS, V4, dict(V=V4), 4, 5, 9, False)
+    add("nmfals_reftest", ALS, A, dict(V=A), 4, 10, 11, False)
+    V5 = np.random.RandomState(12).random_sample((130, 90)).astype(np.float32)
+    add("nmfals_130x90_k33", ALS, V5, dict(V=V5), 33, 3, 5, False)
+    Vc3 = np.random.RandomState(1234).random_sample((2048, 1024)).astype(np.float32)      # cfg3's width and k
+    add("nmfals_cfg3s", ALS, Vc3, dict(V_seed=np.int64(1234), V_shape=np.array([2048, 1024], dtype=np.int64)),
+        64, 2, 42, False)
+
+    # cfg5's shape class (k = n = 128): H H^T of a square uniform H has cond ~ 1e7.  Two iterations (no
+    # convergence test can fire before i > 1, so both runs execute exactly two) of reference SNMF
+    # (snmf.py:67-91) with float64-default operands = the golden; the SAME run with all-float32 operands
+    # is kept beside it (W32, H32, ferr32): the distance between the two is what the reference's own
+    # float32 path loses at this conditioning.  Dense U[0,1) data, and cfg5's sparse pattern (1 % nnz)
+    # densified -- the reference cannot take scipy.sparse input, semantics = SNMF on V.toarray().
+    import scipy.sparse as sp
+    Vs5 = np.random.RandomState(1234).random_sample((384, 128)).astype(np.float32)
+    Vcsr = sp.random(2048, 128, density=0.01, format="csr", dtype=np.float32, random_state=np.random.RandomState(1234))
+    Vd = np.asarray(Vcsr.toarray(), dtype=np.float32)
+    for tag, Vk, desc in (("snmf_cfg5s_dense_f64", Vs5, dict(V_seed=np.int64(1234), V_shape=np.array([384, 128], dtype=np.int64))),
+                          ("snmf_csr_k128_f64", Vd, dict(V=Vd))):
+        add(tag, SNMF, Vk, desc, 128, 2, 42, False)
+        r32 = run_case(SNMF, Vk, 128, 2, 42, True)
+        cases[tag].update(W32=r32["W"], H32=r32["H"], ferr32=r32["ferr"])
 
     # BNMF ("next" row 1): binary data, the reference test's own input (tests/test_pymf.py:80)
     Vb = (np.random.RandomState(17).random_sample((96, 64)) < 0.3).astype(np.float32)

@@ -38,6 +38,25 @@ def test_nmfals_vs_reference_nnls_golden(pm, name):
     close(mdl.ferr, g["ferr"], rtol=2e-4, atol=1e-6, what="mdl.ferr")
 
 
+@pytest.mark.parametrize("name", ["nmfals_24x18_k4", "nmfals_130x90_k33", "nmfals_cfg3s", "nmfals_reftest"])
+def test_nmfals_vs_nmfals_py_golden(pm, name):
+    """Goldens produced by pymf/nmfals.py itself (nmfals.py:70-97; exact-QP stand-in for cvxopt, see
+    tests/golden/gen_golden.py) -- nmfals_cfg3s has cfg3's width and num_bases (2048 x 1024, k = 64)."""
+    g = load_golden(name)
+    mdl = pm.NMFALS(g["V"], num_bases=int(g["k"]))
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert len(mdl.ferr) == len(g["ferr"])
+    assert (mdl.W >= 0).all() and (mdl.H >= 0).all()
+    if name == "nmfals_reftest":           # singular Gram matrices: only W H and the error curve are determined
+        assert rel_fro(mdl.W.dot(mdl.H), g["W"].dot(g["H"]), what="mdl.W.dot(mdl.H)") < 1e-4
+        close(mdl.ferr, g["ferr"], rtol=2e-2, atol=1e-4, what="mdl.ferr")
+        return
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-4
+    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-4
+    close(mdl.ferr, g["ferr"], rtol=1e-4, what="mdl.ferr")
+
+
 def test_nmfnnls_class_matches_reference_golden(pm):
     """pymf.NMFNNLS (nmfnnls.py:69-80) is served by the same kernel; golden = the reference itself."""
     g = load_golden("nnls_24x18_k4")
