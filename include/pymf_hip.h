@@ -168,6 +168,13 @@ int pmf_kernel_stats(pmf_ctx* ctx, const char** name, int64_t* launches, double*
  * in-place edits (permutations included) and re-upload.  Multi-threaded, memory speed. */
 int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
 
+/* Tuning knobs (results agree to rounding whatever they say).  Known names:
+ *   "snmf_gram"  SNMF loops with both updates on iterate in Gram space -- P = M^T (V^T V), S = P M on
+ *                k x n sized data, W materialised once after the last iteration -- instead of one pass
+ *                over V per iteration: -1 automatic (default: CSR data always, dense data from about
+ *                n / 2k iterations on), 0 never, 1 whenever the shape allows (n <= 1024). */
+int pmf_set_option(pmf_ctx* ctx, const char* name, int64_t value);
+
 /* Host transport for the cross-rank sums, for set-ups in which the ranks cannot form an RCCL communicator
  * (plumbing checks with several ranks sharing one GPU; ranks without a common fabric).  Contexts created
  * with nranks == 1 and no nccl_id only.  fn(user, buf, count, is_f64) must replace the `count` floats

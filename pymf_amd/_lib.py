@@ -62,6 +62,7 @@ SYMBOLS = [
                                     _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                                     _c.POINTER(_c.c_double)]),
     ("pmf_host_checksum", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("pmf_set_option", _c.c_int, [_ctx, _c.c_char_p, _c.c_int64]),
     ("pmf_set_host_allreduce", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p]),
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
@@ -294,6 +295,9 @@ class Context(object):
                                              ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
         return dict(name=(name.value or b"").decode(), launches=int(n.value), mean_ms=float(ms.value),
                     flops_per_launch=float(fl.value), bytes_per_launch=float(by.value))
+
+    def set_option(self, name, value):
+        self._chk(self._lib.pmf_set_option(self._h, name.encode(), int(value)))
 
     def set_host_allreduce(self, reduce_array):
         """Route the cross-rank sums through `reduce_array(ndarray) -> ndarray` (the sum over all ranks)

@@ -60,6 +60,12 @@ struct pmf_ctx {
   float *dSlab = nullptr, *dW1 = nullptr, *dGinvT = nullptr;
   float* dMT = nullptr;         // SNMF: M^T = inv(H H^T) H, [KP][np] (k_snmf_mt)
   double* dGinvD = nullptr;     // SNMF: inv(H H^T) in float64, [KP][KP]
+  // Gram-space SNMF loop (snmf_gram_iteration): C = V^T V over all ranks' rows, and the float64 M^T, P
+  double *dC = nullptr, *dMTd = nullptr, *dPd = nullptr;
+  std::vector<double> hC;       // CSR data: this rank's V^T V, formed on the host by pmf_set_v_csr_f32
+  bool c_valid = false;         // dC holds the all-rank V^T V of the current V
+  int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible
+  bool w_implicit = false;      // the loop ran in Gram space: dW is stale, W = V M with the M at hand (materialize_w)
   float* dD = nullptr;          // RNMF: D = S - V (rnmf.py:102,111), [mp][np]
   bool s_valid = false;         // RNMF: D has been formed (update_s ran)
   double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
@@ -145,6 +151,7 @@ int ensure_dv(pmf_ctx* c);
 
 int csr_ps(pmf_ctx* c);
 int csr_w(pmf_ctx* c);
+int materialize_w(pmf_ctx* c);
 
 template <typename T>
 int dalloc(pmf_ctx* c, T** p, size_t count) {
@@ -335,6 +342,29 @@ int talloc(pmf_ctx* c, DevTemps& t, T** out, size_t count) {
   return PMF_OK;
 }
 
+// Ad [np][np] (float64) = V^T V of the dense V, summed over all ranks: 128 (or 64) Gram rows per pass of
+// k_colgemm with the column block of V as its "W" operand (fp32 MFMA products, float64 slab sums).
+// slab: gchunks * 128 * (np + 128) floats of scratch; rpc rows per chunk.
+int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
+  const int np = c->np;
+  for (int c0 = 0; c0 < np;) {
+    const int wdt = (np - c0 >= 128) ? 128 : 64;
+    dim3 grid((unsigned)gchunks, (unsigned)((np + 255) / 256));
+    if (wdt == 128)
+      hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
+                         (int64_t)np, c->mp, rpc, slab);
+    else
+      hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
+                         (int64_t)np, c->mp, rpc, slab);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((wdt * np + 255) / 256)), dim3(256), 0, c->stream, slab,
+                       gchunks, wdt, np, c0, Ad, np);
+    HIPCHK(c, hipGetLastError());
+    c0 += wdt;
+  }
+  return allreduce_sum(c, Ad, (size_t)np * np, true);
+}
+
 int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: dense V only");
   if (c->nb > 1) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases <= 128");
@@ -366,23 +396,8 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   PMFCHK(talloc(c, tmp, &part, (size_t)nblk * 2 * KP));
   PMFCHK(talloc(c, tmp, &norms, (size_t)2 * KP));
 
-  // 1. A = V^T V, 128 (or 64) Gram rows per pass: the column block of V is the "W" operand
-  for (int c0 = 0; c0 < np;) {
-    const int wdt = (np - c0 >= 128) ? 128 : 64;
-    dim3 grid((unsigned)gchunks, (unsigned)((np + 255) / 256));
-    if (wdt == 128)
-      hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
-                         (int64_t)np, c->mp, rpc, slab);
-    else
-      hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
-                         (int64_t)np, c->mp, rpc, slab);
-    HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((wdt * np + 255) / 256)), dim3(256), 0, c->stream, slab,
-                       gchunks, wdt, np, c0, Ad, ld);
-    HIPCHK(c, hipGetLastError());
-    c0 += wdt;
-  }
-  PMFCHK(allreduce_sum(c, Ad, (size_t)np * np, true));
+  // 1. A = V^T V over all ranks' rows
+  PMFCHK(gram_vtv(c, Ad, slab, gchunks, rpc));
   // 2./3. eigen-decomposition, top-k selection
   {
     const int64_t items = (int64_t)(nj / 2) * (nj / 2) + (int64_t)(nj / 2) * nj;
@@ -637,6 +652,7 @@ int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
 
 int ensure_ps(pmf_ctx* c) {  // two-pass path: (re)build the all-rank (P | S) unless it is current
   if (c->ps_valid) return PMF_OK;
+  PMFCHK(materialize_w(c));
   PMFCHK(ps_tiled(c));
   PMFCHK(allreduce_ps(c));
   c->ps_valid = true;
@@ -750,6 +766,94 @@ int snmf_fused_pass(pmf_ctx* c) {
 int snmf_fused_iteration(pmf_ctx* c) {
   PMFCHK(snmf_fused_pass(c));
   return h_step_from_ps(c);
+}
+
+// ---- SNMF in Gram space ---------------------------------------------------------------------------
+// snmf.py:67-70 makes W a LINEAR function of the data once H is given: W = V M, M = H^T inv(H H^T).
+// Everything update_h (snmf.py:72-91) takes from W are XW = V^T W and WW = W^T W, i.e.
+//     P = W^T V = M^T (V^T V) = M^T C,      S = W^T W = M^T C M = P M,      C = V^T V  (n x n),
+// and C does not change during factorize().  So a loop that runs update_w AND update_h needs ONE pass
+// over V (C, float64, all-reduced once across the ranks) and then iterates on k x n sized data only:
+// G = H H^T -> inv -> M^T (all float64) -> P = M^T C -> S = P M -> the H step -> the error through the
+// trace identity (same P, S).  W is materialised once, after the last iteration (W = V M with the M of
+// that iteration: exactly the W the reference holds then).  No per-iteration pass over V or W, no
+// per-iteration collective; results agree with the pass-per-iteration form to rounding (P, S now come
+// out of float64 arithmetic).  CSR data: C is formed on the host while the arrays are uploaded.
+int ensure_vgram(pmf_ctx* c) {
+  if (c->c_valid) return PMF_OK;
+  const int np = c->np;
+  if (!c->dC) PMFCHK(dalloc(c, &c->dC, (size_t)np * np));
+  if (!c->dMTd) PMFCHK(dalloc(c, &c->dMTd, (size_t)c->KP * np));
+  if (!c->dPd) PMFCHK(dalloc(c, &c->dPd, (size_t)c->KP * np));
+  if (c->v_csr) {
+    if (c->hC.size() != (size_t)np * np) return fail(c, PMF_EINVAL, "CSR Gram matrix missing");
+    HIPCHK(c, hipMemcpyAsync(c->dC, c->hC.data(), c->hC.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    PMFCHK(allreduce_sum(c, c->dC, (size_t)np * np, true));
+  } else {
+    DevTemps tmp;
+    const int64_t blocks16 = c->mp / 16;
+    int gchunks = (int)std::min<int64_t>(512, blocks16);
+    const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;
+    gchunks = (int)((c->mp + rpc - 1) / rpc);
+    float* slab = nullptr;
+    PMFCHK(talloc(c, tmp, &slab, (size_t)gchunks * 128 * (np + 128)));
+    PMFCHK(gram_vtv(c, c->dC, slab, gchunks, rpc));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the scratch is freed on return
+  }
+  c->c_valid = true;
+  return PMF_OK;
+}
+
+constexpr int PMF_GRAM_MAX_NP = 1024;   // C is np x np float64 (8 MiB at the limit)
+
+// Worth it?  CSR data: always (C costs a few ms on the host).  Dense data: forming C is 2 m n^2 flop, a
+// pass-per-iteration step 4 m n k: from about n / 2k iterations on (or when C is already there).
+bool snmf_gram_ok(const pmf_ctx* c, int niter) {
+  if (c->algo != PMF_ALGO_SNMF || c->nb > 1 || c->np > PMF_GRAM_MAX_NP) return false;
+  if (c->opt_snmf_gram == 0) return false;
+  if (c->v_csr) return c->hC.size() == (size_t)c->np * c->np;
+  return c->opt_snmf_gram == 1 || c->c_valid || (int64_t)2 * c->k * niter >= c->n;
+}
+
+int snmf_gram_iteration(pmf_ctx* c) {
+  const int np = c->np, KP = c->KP;
+  const int64_t ldp = (int64_t)np + KP;
+  c->ps_valid = false;
+  c->trace_ready = false;
+  PMFCHK(ensure_gram(c, 1.0));
+  if (KP <= 64)
+    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
+  else
+    hipLaunchKernelGGL((k_inverse_spd<8>), dim3(1), dim3(256), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dH, (int64_t)np, np, KP,
+                     c->dGinvD, c->v_csr ? (float*)nullptr : c->dMT, c->v_csr ? c->dW1 : (float*)nullptr, c->dMTd, c->stop_arg);
+  HIPCHK(c, hipGetLastError());
+  // P = M^T C  (KP x np), float64 kept for S, float32 into (P | S)
+  hipLaunchKernelGGL((k_dgemm_small<false>), dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dMTd,
+                     (int64_t)np, c->dC, (int64_t)np, np, c->dPd, (int64_t)np, c->dPS, ldp, c->stop_arg);
+  HIPCHK(c, hipGetLastError());
+  // S = P M = P (M^T)^T  (KP x KP)
+  hipLaunchKernelGGL((k_dgemm_small<true>), dim3((unsigned)(KP / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dPd,
+                     (int64_t)np, c->dMTd, (int64_t)np, np, (double*)nullptr, (int64_t)0, c->dPS + np, ldp, c->stop_arg);
+  HIPCHK(c, hipGetLastError());
+  c->w_implicit = true;       // dW is stale from here on: W = V M with the M just formed
+  c->ps_valid = true;         // (P | S) of that W, all ranks (C is all-reduced)
+  return h_step_from_ps(c);
+}
+
+// W = V M for the M the last Gram-space iteration formed (dMT dense / dW1 CSR).
+int materialize_w(pmf_ctx* c) {
+  if (!c->w_implicit) return PMF_OK;
+  c->w_implicit = false;
+  if (c->v_csr) {
+    const bool keep_ps = c->ps_valid;
+    PMFCHK(csr_w(c));
+    c->ps_valid = keep_ps;
+    return PMF_OK;
+  }
+  return rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dMT, c->np, nullptr, nullptr, c->dW);
 }
 
 // CSR SNMF: update_w and the (P | S) partials of update_h in one pass over the CSR rows.
@@ -884,6 +988,7 @@ int als_update_h(pmf_ctx* c) {
 }
 
 int do_update_w(pmf_ctx* c) {
+  c->w_implicit = false;        // about to be overwritten (SNMF) -- only SNMF loops leave it set
   c->ps_valid = false;
   c->trace_ready = false;
   switch (c->algo) {
@@ -908,6 +1013,7 @@ int do_update_h(pmf_ctx* c) {
 }
 
 int frobenius_direct(pmf_ctx* c, double* out) {
+  PMFCHK(materialize_w(c));
   if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
   const int nb = (int)(c->mp / 64);
   PMFCHK(launch_resid(c, false, 0.f));
@@ -1175,7 +1281,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);
@@ -1196,7 +1302,7 @@ int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(ensure_dv(c));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
-  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
+  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
 }
@@ -1221,6 +1327,20 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false;
+  // this rank's V^T V for the Gram-space loop, float64 on the host (sum over a row's pairs of entries,
+  // duplicates included: (a + b)^2 = aa + ab + ba + bb, the semantics of V.toarray())
+  c->c_valid = false;
+  c->hC.clear();
+  if (c->np <= PMF_GRAM_MAX_NP) {
+    const size_t np = (size_t)c->np;
+    c->hC.assign(np * np, 0.0);
+    for (int64_t r = 0; r < c->m; ++r)
+      for (int64_t e1 = indptr[r]; e1 < indptr[r + 1]; ++e1) {
+        double* crow = c->hC.data() + (size_t)indices[e1] * np;
+        const double v1 = (double)vals[e1];
+        for (int64_t e2 = indptr[r]; e2 < indptr[r + 1]; ++e2) crow[indices[e2]] += v1 * (double)vals[e2];
+      }
+  }
   return PMF_OK;
 }
 
@@ -1238,7 +1358,7 @@ int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(ensure_dv(c));
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
-  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false;
+  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
 }
@@ -1259,12 +1379,13 @@ int pmf_set_w_f32(pmf_ctx* c, const float* W) {
   if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(upload_padded(c, c->dW, c->KP, W, c->k, c->m, c->k));
-  c->have_w = true; c->ps_valid = false;
+  c->have_w = true; c->ps_valid = false; c->w_implicit = false;
   return PMF_OK;
 }
 int pmf_get_w_f32(pmf_ctx* c, float* W) {
   PMFCHK(need(c, false, true, false));
   if (!W) return fail(c, PMF_EINVAL, "W is NULL");
+  PMFCHK(materialize_w(c));
   return download_padded(c, W, c->k, c->dW, c->KP, c->m, c->k);
 }
 int pmf_set_h_f32(pmf_ctx* c, const float* H) {
@@ -1322,7 +1443,10 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   const bool h_only = !cw && ch && ce && c->nb == 1 && !c->v_csr &&
                       (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF);
   // (a host transport for the cross-rank sums blocks on the host every iteration: nothing to free-run)
-  const bool can_free_run = ((fused && ce && c->algo != PMF_ALGO_RNMF) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
+  // SNMF with both updates on: the loop runs in Gram space (snmf_gram_iteration), W materialised at the end
+  const bool gram = cw && ch && snmf_gram_ok(c, niter);
+  if (gram) PMFCHK(ensure_vgram(c));
+  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !c->v_csr)) && ce) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
@@ -1337,7 +1461,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
           lrc = ensure_ps(c);                               // current since the first iteration (W is fixed)
           if (lrc == PMF_OK) lrc = h_step_from_ps(c);
         } else {
-          lrc = c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c);
+          lrc = gram ? snmf_gram_iteration(c) : c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c);
         }
         const double* tt = c->dScal + 2;                  // k_nmf_h_gram left <P,H>, <S,G> there ...
         int ntt = 1;
@@ -1392,7 +1516,9 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       i = s_it;
       PMFCHK(frobenius_direct(c, &ferr[i]));
     } else {
-      if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
+      if (gram) {
+        PMFCHK(snmf_gram_iteration(c));                     // SNMF on k x n sized data (C = V^T V is at hand)
+      } else if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
         PMFCHK(snmf_csr_fused_iteration(c));                // CSR: one pass over the rows
       } else if (fused) {                                   // update_w + update_h, one pass over V
         c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + 1 < niter;
@@ -1435,6 +1561,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   c->want_trace = false;
   c->fixed_h_loop = false;
   c->gram_partial_ok = false;
+  PMFCHK(materialize_w(c));      // Gram-space SNMF loop: W = V M once, inside the timed loop region
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;
@@ -1749,18 +1876,29 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2) {
 
 // The caller changed V behind the library's back (a streamed `data` object was rebound or edited): forget
 // everything derived from it -- ||V||^2, (W^T V | W^T W), the cached V H^T.
+int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return PMF_EINVAL;
+  if (std::strcmp(name, "snmf_gram") == 0) {
+    if (value < -1 || value > 1) return fail(c, PMF_EINVAL, "snmf_gram: -1 (auto), 0 (off) or 1 (on)");
+    c->opt_snmf_gram = (int)value;
+    return PMF_OK;
+  }
+  return fail(c, PMF_EINVAL, std::string("pmf_set_option: unknown option '") + name + "'");
+}
+
 int pmf_set_host_allreduce(pmf_ctx* c, pmf_host_allreduce_fn fn, void* user) {
   if (!c) return PMF_EINVAL;
   if (fn && c->comm) return fail(c, PMF_EINVAL, "pmf_set_host_allreduce: the context already has an RCCL communicator");
   c->host_ar = fn;
   c->host_ar_user = user;
-  c->ps_valid = false; c->vnorm_valid = false; c->trace_ready = false;
+  c->ps_valid = false; c->vnorm_valid = false; c->trace_ready = false; c->c_valid = false;
   return PMF_OK;
 }
 
 int pmf_invalidate_v(pmf_ctx* c) {
   if (!c) return PMF_EINVAL;
   c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
+  c->c_valid = false;
   return PMF_OK;
 }
 

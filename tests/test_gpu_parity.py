@@ -507,11 +507,15 @@ def test_free_running_loop_matches_stepwise_loop(pm, algo_name):
         a.set_v_dense(V); a.set_w(W0); a.set_h(H0)
         if algo_name == "BNMF":
             a.set_lambda(1.0 / niter, 1.0 / niter)
+        if algo_name == "SNMF":
+            a.set_option("snmf_gram", 1)
         fa, done_a, conv_a = a.factorize(niter, conv_eps=eps)
         b = _lib.Context(algo, m, n, k)
         b.set_v_dense(V); b.set_w(W0); b.set_h(H0)
         if algo_name == "BNMF":
             b.set_lambda(1.0 / niter, 1.0 / niter)
+        if algo_name == "SNMF":          # one-iteration calls would pick the pass-per-iteration form: same form on both sides
+            b.set_option("snmf_gram", 1)
         fb, done_b, conv_b = [], 0, -1
         for i in range(niter):                           # the reference loop, one C call per iteration
             f1, _, _ = b.factorize(1, conv_eps=0.0)
@@ -815,3 +819,49 @@ def test_data_edited_in_place_is_noticed(pm, cls_name):
     a.update_h(); o.update_h()
     assert rel_fro(a.H, o.H, what="a.H") < tol
     assert np.all(a.H[:, 3] == 0.0) or cls_name == "SNMF"
+
+
+@pytest.mark.parametrize("shape,k,sparse", [((6000, 256), 64, False), ((3000, 320), 20, False), ((5000, 128), 128, True),
+                                            ((4000, 200), 48, True), ((2500, 700), 33, False)])
+def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
+    """SNMF factorize() in Gram space (P = M^T V^T V, S = P M; W once at the end) against the form that
+    passes over V in every iteration (option snmf_gram = 0) and against the oracle: same W, H, ferr."""
+    import scipy.sparse as sp
+    from pymf_amd import _lib
+    from oracle import SNMFOracle
+    rs = np.random.RandomState(shape[1] + k)
+    if sparse:
+        Vs = sp.random(shape[0], shape[1], density=0.02, format="csr", dtype=np.float32, random_state=rs)
+        Vd = np.asarray(Vs.toarray(), dtype=np.float32)
+    else:
+        Vd = (rs.random_sample(shape) - 0.3).astype(np.float32)
+    W0 = rs.random_sample((shape[0], k)).astype(np.float32)
+    H0 = (rs.random_sample((k, shape[1])) + 0.1).astype(np.float32)
+    outs = []
+    for gram in (1, 0):
+        c = _lib.Context(_lib.ALGO_SNMF, shape[0], shape[1], k)
+        if sparse:
+            c.set_v_csr(Vs.indptr, Vs.indices, Vs.data)
+        else:
+            c.set_v_dense(Vd)
+        c.set_w(W0); c.set_h(H0)
+        c.set_option("snmf_gram", gram)
+        ferr, done, conv = c.factorize(5, compute_err=not sparse)
+        assert done == 5
+        outs.append((c.get_w(), c.get_h(), ferr))
+        # the context stays usable hook by hook after either loop
+        c.update_w(); c.update_h()
+        outs[-1] += (c.get_w(), c.get_h())
+        c.close()
+    o = SNMFOracle(Vd, num_bases=k); o.W, o.H = W0.astype(np.float64), H0.astype(np.float64)
+    o.factorize(niter=5, compute_err=not sparse)
+    ill = 2 * k > shape[1]                         # H H^T near-singular (k ~ n): both forms carry cond(H H^T) * 1e-7
+    tol = 1e-3 if ill else 2e-5
+    assert rel_fro(outs[0][0], o.W, what="gram W vs oracle") < (tol if ill else 5e-5)
+    assert rel_fro(outs[0][1], o.H, what="gram H vs oracle") < tol
+    assert rel_fro(outs[0][0], outs[1][0], what="gram W vs pass-per-iteration W") < (tol if ill else 5e-5)
+    assert rel_fro(outs[0][1], outs[1][1], what="gram H vs pass-per-iteration H") < tol
+    assert rel_fro(outs[0][3], outs[1][3], what="W after the hooks that follow") < (tol if ill else 5e-5)
+    assert rel_fro(outs[0][4], outs[1][4], what="H after the hooks that follow") < tol
+    if not sparse:
+        close(outs[0][2], o.ferr, rtol=2e-5, what="gram ferr vs oracle")
