@@ -742,7 +742,9 @@ def test_hook_loop_equals_one_call_loop(pm):
     assert Same.n_w == 7
     np.testing.assert_array_equal(a.W, b.W)
     np.testing.assert_array_equal(a.H, b.H)
-    np.testing.assert_array_equal(a.ferr, b.ferr)
+    # the error: same (P | S), H and ||V||^2, but the trace terms are summed by k_trace_terms in the hook
+    # loop and inside k_nmf_h_gram in the one-call loop -- float64 sums in a different order
+    close(a.ferr, b.ferr, rtol=1e-8, what="a.ferr")
 
 
 def test_instance_level_hook_and_show_progress(pm, caplog):
@@ -855,8 +857,8 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
         c.close()
     o = SNMFOracle(Vd, num_bases=k); o.W, o.H = W0.astype(np.float64), H0.astype(np.float64)
     o.factorize(niter=5, compute_err=not sparse)
-    ill = 2 * k > shape[1]                         # H H^T near-singular (k ~ n): both forms carry cond(H H^T) * 1e-7
-    tol = 1e-3 if ill else 2e-5
+    ill = 2 * k > shape[1]                         # H H^T near-singular (k ~ n): cond(H H^T) ~ 1e7 amplifies the float32 H between iterations
+    tol = 5e-3 if ill else 2e-5
     assert rel_fro(outs[0][0], o.W, what="gram W vs oracle") < (tol if ill else 5e-5)
     assert rel_fro(outs[0][1], o.H, what="gram H vs oracle") < tol
     assert rel_fro(outs[0][0], outs[1][0], what="gram W vs pass-per-iteration W") < (tol if ill else 5e-5)
