@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- factorize() iterations/sec of pymf's NMF hot path on MI355X.
+"""bench.py -- factorize() iterations/sec of pymf's hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            [--config cfg4|cfg2|cfg3|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric, configs[3] = "cfg4"): NMF multiplicative update on
-a dense float32 V of 1,048,576 x 256 at k = 64; the rows of V and W are sharded over
-the N ranks (fixed total problem => "strong" scaling), H is replicated, and one RCCL
-all-reduce of (W^T V | W^T W) -- 80 KiB -- runs per iteration.  A "step" is one
-factorize() iteration: update_w + update_h (compute_err=False, the pure update
-path; the compute_err=True rate is reported alongside).  Inputs follow
-BASELINE.md section 3: V = RandomState(1234).random_sample((m, n)).astype(float32),
-np.random.seed(42), W0 then H0 from np.random.random.  All inputs are resident in
-HBM before the timed region starts.
+Default workload (BASELINE.json metric, configs[3] = "cfg4"): NMF multiplicative update on a dense
+float32 V of 1,048,576 x 256 at k = 64; the rows of V and W are sharded over the N ranks (fixed
+total problem => "strong" scaling), H is replicated, and one RCCL all-reduce of (W^T V | W^T W)
+-- 80 KiB -- runs per iteration.  A "step" is one factorize() iteration: update_w + update_h
+(compute_err=False, the pure update path; the compute_err=True rate is reported alongside).
+Inputs follow BASELINE.md section 3: V = RandomState(1234).random_sample((m, n)).astype(float32),
+np.random.seed(42), W0 then H0 from np.random.random.  All inputs are resident in HBM before the
+timed region starts.  The secondary BASELINE configs run through the same harness and schema:
+  --config cfg2   NMF     65,536 x 512,  k = 32
+  --config cfg3   NMFALS  262,144 x 1024, k = 64
+  --config cfg5   SNMF    scipy.sparse CSR 4,194,304 x 128 (1 % nnz), k = 128
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  "roofline":     live HIP-event timing of the dominant kernel vs the fp32 MFMA peak
-  "cpu_baseline": the NumPy oracle (oracle/, the reference's op order) timed on
-                  this host's cores on a bounded row sample of the same workload.
+  "roofline":     live HIP-event timing of the path's dominant m-sized kernel against the roofline
+                  that bounds it (fp32 MFMA or HBM), with SURVEY's algorithmic flops/bytes and the
+                  flops the kernel really executes
+  "cpu_baseline": the NumPy oracle (oracle/, the reference's op order) timed on this host's cores.
 """
 import argparse
 import json
@@ -34,10 +37,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-M_FULL, N_FULL, K_FULL = 1048576, 256, 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
-PREROLL_MS_DEFAULT = 300.0   # measured (gpurun_out/r2a, profiles/r02_ramp.md): a fresh box needs ~30 launches to reach its clock
+RIDGE_FLOP_PER_BYTE = PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+PREROLL_MS_DEFAULT = 300.0   # measured (profiles/r02_ramp.md): a fresh box needs ~30 launches to reach its clock
+
+CONFIGS = {
+    # name: (algo, m, n, k, BASELINE.json configs[] index, description)
+    "cfg4": ("NMF", 1048576, 256, 64, 3, "pymf.NMF multiplicative update, dense fp32 V"),
+    "cfg2": ("NMF", 65536, 512, 32, 1, "pymf.NMF multiplicative update, dense fp32 V"),
+    "cfg3": ("NMFALS", 262144, 1024, 64, 2, "pymf.NMFALS alternating least squares, dense fp32 V"),
+    "cfg5": ("SNMF", 4194304, 128, 128, 4, "pymf.SNMF on scipy.sparse CSR V (1 % nnz)"),
+}
 
 
 def gen_rows(seed_state, m_total, ncols, lo, hi, chunk=65536):
@@ -61,34 +72,26 @@ def gen_rows(seed_state, m_total, ncols, lo, hi, chunk=65536):
     return out
 
 
-def _time_oracle(V, W, H, budget_s):
-    from oracle import nmf_update_w, nmf_update_h
-    nmf_update_w(V, W, H)
-    nmf_update_h(V, W, H)                     # warm-up iteration
-    t0 = time.time()
-    it = 0
-    while True:
-        nmf_update_w(V, W, H)
-        nmf_update_h(V, W, H)
-        it += 1
-        dt = time.time() - t0
-        if (it >= 3 and dt > budget_s * 0.5) or dt > budget_s or it >= 50:
-            break
-    return it, dt
+def gen_csr(m, n, density, lo, hi, fast):
+    """BASELINE.md: scipy.sparse.random(m, n, density, 'csr', float32, random_state=1234), rows [lo, hi).
+    (about a minute and 4.4 GB of host memory at cfg5 size.)  fast=True: Poisson row lengths and uniform
+    column draws -- same density, seconds; a shape-faithful stand-in, NOT the BASELINE stream."""
+    if not fast:
+        import scipy.sparse as sp
+        V = sp.random(m, n, density=density, format="csr", dtype=np.float32, random_state=1234)
+        V = V[lo:hi]
+        return V.indptr.astype(np.int64), V.indices.astype(np.int32), V.data.astype(np.float32)
+    rs = np.random.RandomState(1234)
+    nnz_row = np.minimum(rs.poisson(density * n, size=m), n).astype(np.int64)
+    indptr = np.concatenate([[0], np.cumsum(nnz_row)])
+    nnz = int(indptr[-1])
+    indices = rs.randint(0, n, size=nnz).astype(np.int32)       # duplicates add up, as in V.toarray()
+    vals = rs.random_sample(nnz).astype(np.float32)
+    a, b = int(indptr[lo]), int(indptr[hi])
+    return (indptr[lo:hi + 1] - a).astype(np.int64), indices[a:b], vals[a:b]
 
 
-def cpu_baseline(m, n, k, budget_s=20.0):
-    """The oracle (NumPy restatement of pymf/nmf.py:122-132) on a bounded row sample, in the two
-    variants BASELINE.md section 3 asks for: reference-default (float64 W/H, float32 V) = `value`,
-    and all-float32."""
-    ms = min(m, 32768)
-    V = np.random.RandomState(1234).random_sample((ms, n)).astype(np.float32)
-    np.random.seed(42)
-    W = np.random.random((ms, k))             # float64, the reference's default init
-    H = np.random.random((k, n))
-    it, dt = _time_oracle(V, W.copy(), H.copy(), budget_s * 0.7)
-    it32, dt32 = _time_oracle(V, W.astype(np.float32), H.astype(np.float32), budget_s * 0.3)
-    rate_sample = it / dt
+def _blas_threads():
     threads = os.cpu_count() or 1
     try:
         from threadpoolctl import threadpool_info
@@ -97,18 +100,92 @@ def cpu_baseline(m, n, k, budget_s=20.0):
                 threads = int(info.get("num_threads", threads))
     except Exception:
         pass
-    return {
-        "value": rate_sample * ms / float(m),
-        "unit": "iter/s",
-        "cores": threads,
-        "kind": "port",
-        "value_all_fp32": (it32 / dt32) * ms / float(m),
-        "sample": "oracle NMF (reference op order, float64 W/H, float32 V) on the first %d of %d rows, "
-                  "n=%d k=%d: %d iterations in %.2f s = %.3f iter/s on the sample, scaled by %d/%d "
-                  "(cost is linear in rows); all-float32 variant: %d iterations in %.2f s; numpy %s, "
-                  "host cpu_count=%d" %
-                  (ms, m, n, k, it, dt, rate_sample, ms, m, it32, dt32, np.__version__, os.cpu_count() or 1),
-    }
+    return threads
+
+
+def _time_loop(step, budget_s, min_iters=3, max_iters=50):
+    step()                                    # warm-up iteration
+    t0 = time.time()
+    it = 0
+    while True:
+        step()
+        it += 1
+        dt = time.time() - t0
+        if (it >= min_iters and dt > budget_s * 0.5) or dt > budget_s or it >= max_iters:
+            return it, dt
+
+
+def cpu_baseline(cfg, m, n, k, budget_s=24.0):
+    """The oracle (NumPy restatement of the reference, its op order) on this host's cores.
+    cfg4 / cfg2: FULL size, reference-default operands (float64 W/H, float32 V) = `value`, the all-float32
+    variant alongside.  cfg3 / cfg5: a bounded row sample, scaled -- stated in `sample`."""
+    import oracle
+    algo = CONFIGS[cfg][0]
+    out = {"unit": "iter/s", "cores": _blas_threads(), "kind": "port"}
+    host = "numpy %s, host cpu_count=%d" % (np.__version__, os.cpu_count() or 1)
+    if algo == "NMF":
+        V = gen_rows(np.random.RandomState(1234), m, n, 0, m)
+        np.random.seed(42)
+        W = np.random.random((m, k))
+        H = np.random.random((k, n))
+        W32, H32 = W.astype(np.float32), H.astype(np.float32)
+
+        def step64():
+            oracle.nmf_update_w(V, W, H)
+            oracle.nmf_update_h(V, W, H)
+
+        def step32():
+            oracle.nmf_update_w(V, W32, H32)
+            oracle.nmf_update_h(V, W32, H32)
+        it, dt = _time_loop(step64, budget_s * 0.7)
+        it32, dt32 = _time_loop(step32, budget_s * 0.3)
+        out.update(value=it / dt, value_all_fp32=it32 / dt32,
+                   sample="oracle NMF (reference op order, float64 W/H, float32 V) at FULL size %dx%d k=%d: "
+                          "1 warm-up + %d iterations in %.2f s; all-float32 variant: %d iterations in %.2f s; %s"
+                          % (m, n, k, it, dt, it32, dt32, host))
+    elif algo == "NMFALS":
+        ms = min(m, 256)                          # rows of the W half step in the sample
+        V = gen_rows(np.random.RandomState(1234), m, n, 0, ms)
+        np.random.seed(42)
+        W = np.random.random((m, k))[:ms]
+        H = np.random.random((k, n))
+        o = oracle.NMFALSOracle(V, num_bases=k)
+        o.W, o.H = W.copy(), H.copy()
+        t0 = time.time()
+        o.update_w()
+        tw = time.time() - t0                     # ms QPs of the W half step
+        ns = min(n, 256)
+        o2 = oracle.NMFALSOracle(V[:, :ns], num_bases=k)
+        o2.W, o2.H = o.W.copy(), H[:, :ns].copy()
+        t0 = time.time()
+        o2.update_h()
+        th = time.time() - t0                     # ns QPs of the H half step (Hessian of the sample's W)
+        per_iter = tw * m / ms + th * n / ns
+        out.update(value=1.0 / per_iter,
+                   sample="oracle NMFALS (exact active-set QP per row / column, float64, one Python-level solve per "
+                          "sub-problem like the reference's cvxopt calls): %d of %d W rows in %.2f s, %d of %d H columns "
+                          "in %.2f s, scaled to %d + %d QPs of dimension %d per iteration; %s"
+                          % (ms, m, tw, ns, n, th, m, n, k, host))
+    else:                                         # SNMF on the densified sample (the reference cannot take CSR)
+        ms = min(m, 131072)
+        ip, ix, vv = gen_csr(m, n, 0.01, 0, ms, fast=True)
+        import scipy.sparse as sp
+        Vd = np.asarray(sp.csr_matrix((vv, ix, ip), shape=(ms, n)).toarray(), dtype=np.float32)
+        np.random.seed(42)
+        W = np.random.random((ms, k))
+        H = np.random.random((k, n))
+        o = oracle.SNMFOracle(Vd, num_bases=k)
+        o.W, o.H = W, H
+
+        def step():
+            o.update_w()
+            o.update_h()
+        it, dt = _time_loop(step, budget_s)
+        out.update(value=(it / dt) * ms / float(m),
+                   sample="oracle SNMF (snmf.py:67-91) on V.toarray() of the first %d of %d rows (the reference has no "
+                          "sparse path), n=%d k=%d: %d iterations in %.2f s, scaled by %d/%d (cost is linear in rows); %s"
+                          % (ms, m, n, k, it, dt, ms, m, host))
+    return out
 
 
 def main():
@@ -116,19 +193,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", dest="m", type=int, default=M_FULL)
-    ap.add_argument("--cols", dest="n", type=int, default=N_FULL)
-    ap.add_argument("--bases", dest="k", type=int, default=K_FULL)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg4",
+                    help="BASELINE.json workload (default cfg4 = the headline metric)")
+    ap.add_argument("--rows", dest="m", type=int, default=0)
+    ap.add_argument("--cols", dest="n", type=int, default=0)
+    ap.add_argument("--bases", dest="k", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preroll-ms", type=float, default=PREROLL_MS_DEFAULT,
                     help="disclosed device pre-conditioning: untimed iterations of the same loop for about this "
                          "many ms of device time BEFORE the W counted warm-up steps (the chip's clock/power "
                          "state needs more than 5 launches to settle on a fresh box); 0 disables")
-    ap.add_argument("--fill", choices=["numpy", "device"], default="numpy",
-                    help="numpy: BASELINE.md protocol; device: counter-based fill (fast start-up)")
+    ap.add_argument("--fill", choices=["numpy", "device", "fast"], default="numpy",
+                    help="numpy: BASELINE.md protocol; device: counter-based fill of dense inputs (fast start-up); "
+                         "fast: cfg5 only, a Poisson/uniform CSR stand-in of the same density (seconds, not a minute)")
+    ap.add_argument("--snmf-gram", type=int, default=-1, choices=[-1, 0, 1],
+                    help="SNMF: -1 library default (Gram-space loop), 0 one pass over V per iteration")
     ap.add_argument("--debug-share-gpu", action="store_true",
                     help="plumbing check on a 1-GPU box: every rank uses device 0 and its own 1-rank RCCL "
-                         "communicator (rows still sharded, gloo barriers still used); NOT a measurement")
+                         "communicator (rows still sharded, barriers still used); NOT a measurement")
     args = ap.parse_args()
 
     from pymf_amd import _lib, dist
@@ -136,26 +218,40 @@ def main():
     if w.size != args.gpus and w.rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, w.size),
               file=sys.stderr)
-    m, n, k = args.m, args.n, args.k
+    algo_name, m, n, k, cfg_index, cfg_desc = CONFIGS[args.config]
+    m, n, k = args.m or m, args.n or n, args.k or k
+    algo = getattr(_lib, "ALGO_" + algo_name)
     lo, hi = w.row_range(m)
     if args.debug_share_gpu:
-        ctx = _lib.Context(_lib.ALGO_NMF, hi - lo, n, k, device=0, rank=0, nranks=1,
-                           nccl_id=_lib.nccl_unique_id())
+        ctx = _lib.Context(algo, hi - lo, n, k, device=0, rank=0, nranks=1, nccl_id=_lib.nccl_unique_id())
     else:
-        ctx = _lib.Context(_lib.ALGO_NMF, hi - lo, n, k, device=w.local_rank, rank=w.rank,
+        ctx = _lib.Context(algo, hi - lo, n, k, device=w.local_rank, rank=w.rank,
                            nranks=w.size, nccl_id=w.nccl_id)
-    if args.fill == "numpy":
+    data = "synthetic"
+    nnz_local = 0
+    if args.config == "cfg5":
+        ip, ix, vv = gen_csr(m, n, 0.01, lo, hi, fast=(args.fill != "numpy"))
+        nnz_local = int(vv.shape[0])
+        ctx.set_v_csr(ip, ix, vv)
+        del ip, ix, vv
+        if args.fill != "numpy":
+            data = "synthetic (Poisson/uniform CSR stand-in of the BASELINE density)"
+        if args.snmf_gram >= 0:
+            ctx.set_option("snmf_gram", args.snmf_gram)
+    elif args.fill == "device":
+        ctx.fill_v_uniform(1234, lo)
+    else:
         V = gen_rows(np.random.RandomState(1234), m, n, lo, hi)
         ctx.set_v_dense(V)
         del V
+    if args.fill == "device" and args.config != "cfg5":
+        ctx.fill_w_uniform(42, lo)
+        ctx.fill_h_uniform(43)
+    else:
         np.random.seed(42)
         rs = np.random.mtrand._rand            # the global legacy stream, as np.random.random uses
         ctx.set_w(gen_rows(rs, m, k, lo, hi))
         ctx.set_h(np.random.random((k, n)))
-    else:
-        ctx.fill_v_uniform(1234, lo)
-        ctx.fill_w_uniform(42, lo)
-        ctx.fill_h_uniform(43)
 
     # ---- disclosed pre-conditioning (untimed, reported as "preroll_ms" / "preroll_iters") ----
     preroll_iters, preroll_ms = 0, 0.0
@@ -168,8 +264,9 @@ def main():
         preroll_iters += 2
 
     # ---- warm-up (untimed) ----
-    _, done, _ = ctx.factorize(args.warmup, compute_err=False)
-    assert done == args.warmup
+    if args.warmup > 0:
+        _, done, _ = ctx.factorize(args.warmup, compute_err=False)
+        assert done == args.warmup
 
     # ---- timed region: exactly K steps, barrier + device sync on both sides ----
     ctx.profile_enable(True)
@@ -183,31 +280,45 @@ def main():
     assert done == args.steps and conv < 0, "timed run was shortened (%d of %d)" % (done, args.steps)
     dt = dist.allreduce_max(dt)
     stats = ctx.kernel_stats()
-    launch_ms = np.sort(ctx.kernel_launch_ms())
-    first_ms = [round(float(x), 4) for x in ctx.kernel_launch_ms()[:5]]
+    all_ms = ctx.kernel_launch_ms()
+    launch_ms = np.sort(all_ms)
+    first_ms = [round(float(x), 4) for x in all_ms[:5]]
     ctx.profile_enable(False)
 
-    # secondary: the API-default compute_err=True rate (not the headline value)
-    ne = max(2, min(args.steps, 20))
-    ctx.synchronize()
-    dist.barrier()
-    t1 = time.perf_counter()
-    _, done_e, conv_e = ctx.factorize(ne, compute_err=True)
-    ctx.synchronize()
-    dist.barrier()
-    dte = dist.allreduce_max(time.perf_counter() - t1)
+    # secondary: the API-default compute_err=True rate (not the headline value; the reference has no
+    # error on sparse data, nmf.py:109-112)
+    rate_err = None
+    if args.config != "cfg5":
+        ne = max(2, min(args.steps, 20))
+        ctx.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        _, done_e, conv_e = ctx.factorize(ne, compute_err=True)
+        ctx.synchronize()
+        dist.barrier()
+        rate_err = done_e / dist.allreduce_max(time.perf_counter() - t1)
 
     if w.rank == 0:
-        ach = (stats["flops_per_launch"] / (stats["mean_ms"] * 1e-3)) / 1e12 if stats["mean_ms"] > 0 else 0.0
+        mean_s = stats["mean_ms"] * 1e-3
+        fl, ex, by = stats["flops_per_launch"], stats["executed_flops_per_launch"], stats["bytes_per_launch"]
+        mfma_bound = by > 0 and fl / by > RIDGE_FLOP_PER_BYTE
+        if mean_s > 0 and mfma_bound:
+            ach, peak, unit, bound = fl / mean_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
+        elif mean_s > 0:
+            ach, peak, unit, bound = by / mean_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        else:
+            ach, peak, unit, bound = 0.0, PEAK_HBM_GBS, "GB/s", "hbm"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                key = "%s@%dx%dx%d/%d" % (stats["name"], m, n, k, w.size)
-                traffic = tj.get(key)
+                traffic = json.load(open(tpath)).get("%s@%dx%dx%d/%d" % (stats["name"], m, n, k, w.size))
             except Exception:
                 traffic = None
+        if algo_name == "SNMF":
+            collective = "ncclAllReduce(V^T V), once per factorize()" if w.size > 1 else "none"
+        else:
+            collective = "ncclAllReduce(W^T V | W^T W), %d B/iter" % (4 * k * (n + k)) if w.size > 1 else "none"
         out = {
             "metric": "factorize_iters_per_sec",
             "value": args.steps / dt,
@@ -221,29 +332,34 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "cfg4: pymf.NMF multiplicative update, dense fp32 V %dx%d, k=%d, rows "
-                                   "sharded over %d GPU(s), compute_err=False" % (m, n, k, w.size),
-                       "m": m, "n": n, "k": k, "algo": "NMF", "path": ctx.path_name,
-                       "collective": "ncclAllReduce(W^T V | W^T W), %d B/iter" % (4 * k * (n + k))
-                       if w.size > 1 else "none",
-                       "compute_err_true_iters_per_sec": done_e / dte},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": stats["name"], "launches": stats["launches"],
+            "dtype": "f64" if algo_name == "NMFALS" else "f32",
+            "data": data,
+            "config": {"workload": "%s (BASELINE.json configs[%d]): %s %dx%d, k=%d, rows sharded over %d GPU(s), "
+                                   "compute_err=False" % (args.config, cfg_index, cfg_desc, m, n, k, w.size),
+                       "m": m, "n": n, "k": k, "algo": algo_name, "path": ctx.path_name,
+                       "collective": collective,
+                       "compute_err_true_iters_per_sec": rate_err},
+            "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "traffic": traffic, "kernel": stats["name"], "launches": stats["launches"],
                          "mean_kernel_ms": stats["mean_ms"],
                          "min_kernel_ms": float(launch_ms[0]) if len(launch_ms) else None,
                          "median_kernel_ms": float(np.median(launch_ms)) if len(launch_ms) else None,
                          "max_kernel_ms": float(launch_ms[-1]) if len(launch_ms) else None,
                          "first_launches_ms": first_ms,
-                         "flops_per_launch": stats["flops_per_launch"],
-                         "algorithmic_bytes_per_launch": stats["bytes_per_launch"],
-                         "achieved_hbm_GBs": stats["bytes_per_launch"] / (stats["mean_ms"] * 1e-3) / 1e9
-                         if stats["mean_ms"] > 0 else 0.0},
+                         "flops_per_launch": fl,
+                         "executed_flops_per_launch": ex,
+                         "executed_TFLOPs": ex / mean_s / 1e12 if mean_s > 0 else 0.0,
+                         "algorithmic_bytes_per_launch": by,
+                         "achieved_hbm_GBs": by / mean_s / 1e9 if mean_s > 0 else 0.0,
+                         "kernel_share_of_timed_region": stats["launches"] * mean_s / dt if dt > 0 else 0.0},
         }
+        if args.config == "cfg5":
+            out["config"]["nnz_local"] = nnz_local
+            out["config"]["loop"] = ("Gram space: one k x n sized iteration per step, W = V M materialised once "
+                                     "inside the timed region" if stats["name"].startswith("k_csr_w")
+                                     else "one pass over the CSR rows per iteration")
         if w.size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m, n, k)
+            out["cpu_baseline"] = cpu_baseline(args.config, m, n, k)
         print(json.dumps(out), flush=True)
     ctx.close()
     dist.shutdown()

@@ -188,6 +188,10 @@ int pmf_set_host_allreduce(pmf_ctx* ctx, pmf_host_allreduce_fn fn, void* user);
  * rebound or edited between calls. */
 int pmf_invalidate_v(pmf_ctx* ctx);
 
+/* The flops one launch of that kernel really executes (pmf_kernel_stats reports SURVEY's algorithmic
+ * count): W^T W is symmetric (upper triangle only) and SNMF's W step is reassociated. */
+int pmf_kernel_exec_flops(pmf_ctx* ctx, double* executed_flops_per_launch);
+
 /* The individual launch durations behind pmf_kernel_stats' mean, in launch order: out_ms[0..min(cap,*count))
  * (ms, HIP events on the library's stream); *count = launches recorded since the last pmf_profile_enable. */
 int pmf_kernel_launch_ms(pmf_ctx* ctx, double* out_ms, int64_t cap, int64_t* count);

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("pmf_set_option", _c.c_int, [_ctx, _c.c_char_p, _c.c_int64]),
     ("pmf_set_host_allreduce", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p]),
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
+    ("pmf_kernel_exec_flops", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
     ("pmf_path_name", _c.c_char_p, [_ctx]),
@@ -293,8 +294,11 @@ class Context(object):
         by = ctypes.c_double(0.0)
         self._chk(self._lib.pmf_kernel_stats(self._h, ctypes.byref(name), ctypes.byref(n),
                                              ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        ex = ctypes.c_double(0.0)
+        self._chk(self._lib.pmf_kernel_exec_flops(self._h, ctypes.byref(ex)))
         return dict(name=(name.value or b"").decode(), launches=int(n.value), mean_ms=float(ms.value),
-                    flops_per_launch=float(fl.value), bytes_per_launch=float(by.value))
+                    flops_per_launch=float(fl.value), bytes_per_launch=float(by.value),
+                    executed_flops_per_launch=float(ex.value))
 
     def set_option(self, name, value):
         self._chk(self._lib.pmf_set_option(self._h, name.encode(), int(value)))

@@ -36,9 +36,14 @@ constexpr int PMF_HGRAM_MAX_WGS = 64;   // workgroups of k_nmf_h_gram (one or mo
 
 std::string g_create_error;
 
+// Launch sites that can be bracketed by HIP events (pmf_profile_enable): ONE of them, the dominant
+// m-sized kernel of the path the context takes, is recorded at a time (choose_stat_site).
+enum { SITE_NONE = 0, SITE_FUSED, SITE_ROWGEMM_W, SITE_NNQP_W, SITE_MATERIALIZE, SITE_CSR_PASS };
+
 struct KernelStat {
   std::string name = "none";
-  double flops = 0.0, bytes = 0.0;
+  int site = SITE_NONE;
+  double flops = 0.0, bytes = 0.0, exec_flops = 0.0;
   std::vector<hipEvent_t> ev;   // pairs
   size_t used = 0;              // events recorded since reset
 };
@@ -166,8 +171,8 @@ int ensure_dv(pmf_ctx* c) {
 }
 
 // ---- profiling of the dominant kernel -------------------------------------------------
-void stat_begin(pmf_ctx* c) {
-  if (!c->profile) return;
+void stat_begin(pmf_ctx* c, int site) {
+  if (!c->profile || c->stat.site != site) return;
   KernelStat& s = c->stat;
   if (s.used + 2 > s.ev.size()) {
     for (int q = 0; q < 2; ++q) {
@@ -178,8 +183,8 @@ void stat_begin(pmf_ctx* c) {
   }
   hipEventRecord(s.ev[s.used], c->stream);
 }
-void stat_end(pmf_ctx* c) {
-  if (!c->profile) return;
+void stat_end(pmf_ctx* c, int site) {
+  if (!c->profile || c->stat.site != site) return;
   KernelStat& s = c->stat;
   if (s.used + 2 > s.ev.size()) return;
   hipEventRecord(s.ev[s.used + 1], c->stream);
@@ -547,7 +552,10 @@ int nmf_update_w(pmf_ctx* c) {
     c->num_valid = true;
     return PMF_OK;
   }
-  return rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
+  stat_begin(c, SITE_ROWGEMM_W);
+  const int wrc = rowgemm<EPI_NMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
+  stat_end(c, SITE_ROWGEMM_W);
+  return wrc;
 }
 
 template <int NT, bool BNMF>
@@ -681,13 +689,13 @@ int nmf_fused_pass(pmf_ctx* c) {
   int ngp = 0;
   if (c->g_valid && c->g_parts > 0) { Gsrc = c->dGpart; ngp = c->g_parts; }   // partial sums, added by the kernel
   else PMFCHK(ensure_gram(c, 0.0));
-  stat_begin(c);
+  stat_begin(c, SITE_FUSED);
   const bool rn = c->algo == PMF_ALGO_RNMF;     // rnmf.py:100-115: both contractions run on D = S - data
   if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
   const int lrc = launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
                                c->np, rn ? c->dD : c->dV, c->dW, c->dH, Gsrc, c->mp, c->fused_wgs, (float)c->lamb_w,
                                c->dSlab, c->stop_arg, ngp);
-  stat_end(c);
+  stat_end(c, SITE_FUSED);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
   {
@@ -745,10 +753,10 @@ int snmf_fused_pass(pmf_ctx* c) {
   c->ps_valid = false;
   c->trace_ready = false;
   PMFCHK(snmf_inverse(c));
-  stat_begin(c);
+  stat_begin(c, SITE_FUSED);
   const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dMT, nullptr, c->mp,
                                c->fused_wgs, 0.f, c->dSlab, c->stop_arg);
-  stat_end(c);
+  stat_end(c, SITE_FUSED);
   if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
   HIPCHK(c, hipGetLastError());
   {
@@ -847,13 +855,17 @@ int snmf_gram_iteration(pmf_ctx* c) {
 int materialize_w(pmf_ctx* c) {
   if (!c->w_implicit) return PMF_OK;
   c->w_implicit = false;
+  stat_begin(c, SITE_MATERIALIZE);
+  int rc = PMF_OK;
   if (c->v_csr) {
     const bool keep_ps = c->ps_valid;
-    PMFCHK(csr_w(c));
+    rc = csr_w(c);
     c->ps_valid = keep_ps;
-    return PMF_OK;
+  } else {
+    rc = rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dMT, c->np, nullptr, nullptr, c->dW);
   }
-  return rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dMT, c->np, nullptr, nullptr, c->dW);
+  stat_end(c, SITE_MATERIALIZE);
+  return rc;
 }
 
 // CSR SNMF: update_w and the (P | S) partials of update_h in one pass over the CSR rows.
@@ -919,10 +931,10 @@ int snmf_csr_fused_iteration(pmf_ctx* c) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   int wgs = (int)std::min<int64_t>((c->mp / 16 + 3) / 4, cus);
   wgs = std::min(wgs, c->nchunks > 0 ? std::max(c->nchunks, 1) : wgs);   // slab capacity
-  stat_begin(c);
+  stat_begin(c, SITE_CSR_PASS);
   int mrc = PMF_OK;
   if (csr_mfma(c, wgs, &mrc)) {
-    stat_end(c);
+    stat_end(c, SITE_CSR_PASS);
     PMFCHK(mrc);
     PMFCHK(reduce_slabs(c, wgs));
     PMFCHK(allreduce_ps(c));
@@ -936,7 +948,7 @@ int snmf_csr_fused_iteration(pmf_ctx* c) {
     case 8: PMFCHK(launch_csr_fused<8>(c, wgs)); break;
     default: return fail(c, PMF_EINVAL, "bad NT");
   }
-  stat_end(c);
+  stat_end(c, SITE_CSR_PASS);
   PMFCHK(reduce_slabs(c, wgs));
   PMFCHK(allreduce_ps(c));
   c->ps_valid = true;
@@ -961,9 +973,9 @@ int als_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
   PMFCHK(nnqp_warm_flag(c));
-  stat_begin(c);
+  stat_begin(c, SITE_NNQP_W);
   int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, c->dWarm);
-  stat_end(c);
+  stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (W) failed");
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
@@ -1130,26 +1142,61 @@ int download_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64
   return PMF_OK;
 }
 
-void set_stat_model(pmf_ctx* c) {
-  // Algorithmic flops / bytes of ONE launch of the dominant kernel on THIS rank's rows
-  // (SURVEY.md section 8(d)): the fused kernel does the four m-sized contractions of an
-  // iteration in one pass over V: F = 4 m n k + 4 m k^2, B = 4 (m n + 2 m k).
-  const double m = (double)c->m, n = (double)c->n, k = (double)c->k;
-  if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->fused_wgs > 0) {
-    c->stat.name = fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF);
-    c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;
-    c->stat.bytes = 4.0 * (m * n + 2.0 * m * k);
-  } else if (c->algo == PMF_ALGO_SNMF && c->fused_wgs > 0) {
-    c->stat.name = fused_kernel_name(c->NT, c->np, FUSED_SNMF);
-    // SURVEY 8(d) counts V H^T, (.) inv, W^T V, W^T W; the kernel EXECUTES V M^T (2mnk), W^T V (2mnk) and
-    // the upper triangle of W^T W (m k (k + 16)): 4mnk + m k^2 + 16 m k
-    c->stat.flops = 4.0 * m * n * k + 4.0 * m * k * k;
-    c->stat.bytes = 4.0 * (m * n + m * k);               // V read once, W written once
+// Which launch site pmf_profile_enable times, with the ALGORITHMIC flops / bytes of ONE launch on THIS
+// rank's rows and the flops the kernel really executes (symmetry of W^T W,
+// reassociations) next to them.
+void choose_stat_site(pmf_ctx* c, bool gram) {
+  const double m = (double)c->m, n = (double)c->n, k = (double)c->k, nnz = (double)c->nnz;
+  KernelStat& st = c->stat;
+  const int old_site = st.site;
+  st.site = SITE_NONE; st.name = "none"; st.flops = st.bytes = st.exec_flops = 0.0;
+  char buf[96];
+  if (c->algo == PMF_ALGO_SNMF && gram) {
+    st.site = SITE_MATERIALIZE;                   // the only m-sized kernel of a Gram-space loop: W = V M, once
+    if (c->v_csr) {
+      st.name = "k_csr_w(W = V M)";
+      st.flops = st.exec_flops = 2.0 * nnz * k;
+      st.bytes = 4.0 * m * k + 8.0 * nnz + 8.0 * (m + 1.0);      // W written once; CSR arrays read once
+    } else {
+      snprintf(buf, sizeof(buf), "k_rowgemm<%d,store>(W = V M^T)", c->NT);
+      st.name = buf;
+      st.flops = st.exec_flops = 2.0 * m * n * k;
+      st.bytes = 4.0 * (m * n + m * k);
+    }
+  } else if (c->algo == PMF_ALGO_SNMF && c->v_csr) {
+    st.site = SITE_CSR_PASS;
+    st.name = "k_snmf_csr_mfma (one pass per iteration)";
+    st.flops = 4.0 * nnz * k + 4.0 * m * k * k;                  // SURVEY: SpMM, (.) inv, W^T V, W^T W
+    st.exec_flops = 4.0 * nnz * k + m * k * (k + 16.0);          // V M, W^T V, upper triangle of W^T W
+    st.bytes = 4.0 * m * k + 8.0 * nnz + 8.0 * (m + 1.0);
+  } else if (c->fused_wgs > 0 && c->algo != PMF_ALGO_NMFALS) {
+    st.site = SITE_FUSED;
+    st.name = fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_SNMF   ? FUSED_SNMF
+                                              : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF
+                                              : c->algo == PMF_ALGO_RNMF ? FUSED_RNMF
+                                                                         : FUSED_NMF);
+    // one pass over V does the four m-sized contractions of an iteration: F = 4 m n k + 4 m k^2
+    st.flops = 4.0 * m * n * k + 4.0 * m * k * k;
+    if (c->algo == PMF_ALGO_SNMF) {               // executes V M^T, W^T V and the upper triangle of W^T W
+      st.exec_flops = 4.0 * m * n * k + m * k * (k + 16.0);
+      st.bytes = 4.0 * (m * n + m * k);           // V read once, W written once
+    } else {                                      // V H^T, W G, W^T V and the upper triangle of W^T W
+      st.exec_flops = 4.0 * m * n * k + 2.0 * m * k * k + m * k * (k + 16.0);
+      st.bytes = 4.0 * (m * n + 2.0 * m * k);     // V read once, W read and written once
+    }
   } else if (c->algo == PMF_ALGO_NMFALS) {
-    c->stat.name = "k_nnqp(update_w)";
-    c->stat.flops = 0.0;
-    c->stat.bytes = 4.0 * (2.0 * m * k);
+    st.site = SITE_NNQP_W;
+    snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
+    st.name = buf;
+    st.bytes = 4.0 * (3.0 * m * k);               // right-hand sides read, warm start read, solution written
+  } else if ((c->algo == PMF_ALGO_NMF) && c->nb == 1) {
+    st.site = SITE_ROWGEMM_W;
+    snprintf(buf, sizeof(buf), "k_rowgemm<%d,nmf_w>", c->NT);
+    st.name = buf;
+    st.flops = st.exec_flops = 2.0 * m * n * k + 2.0 * m * k * k;
+    st.bytes = 4.0 * (m * n + 2.0 * m * k);
   }
+  if (st.site != old_site) st.used = 0;
 }
 
 }  // namespace
@@ -1265,7 +1312,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
                                                                            : algo == PMF_ALGO_RNMF ? FUSED_RNMF
                                                                                                    : FUSED_NMF))
                                : std::string("tiled");
-  set_stat_model(c);
+  choose_stat_site(c, false);
   *out = c;
   return PMF_OK;
 }
@@ -1446,6 +1493,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   // SNMF with both updates on: the loop runs in Gram space (snmf_gram_iteration), W materialised at the end
   const bool gram = cw && ch && snmf_gram_ok(c, niter);
   if (gram) PMFCHK(ensure_vgram(c));
+  choose_stat_site(c, gram);
   const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !c->v_csr)) && ce) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
@@ -1899,6 +1947,12 @@ int pmf_invalidate_v(pmf_ctx* c) {
   if (!c) return PMF_EINVAL;
   c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
   c->c_valid = false;
+  return PMF_OK;
+}
+
+int pmf_kernel_exec_flops(pmf_ctx* c, double* executed_flops_per_launch) {
+  if (!c || !executed_flops_per_launch) return PMF_EINVAL;
+  *executed_flops_per_launch = c->stat.exec_flops;
   return PMF_OK;
 }
 

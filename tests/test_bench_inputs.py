@@ -25,6 +25,25 @@ def test_gen_rows_matches_unsharded_stream():
 
 
 def test_cpu_baseline_shape():
-    out = bench.cpu_baseline(4096, 64, 8, budget_s=0.5)
-    assert out["kind"] == "port" and out["unit"] == "iter/s" and out["value"] > 0 and out["cores"] >= 1
-    assert "sample" in out
+    for cfg, (m, n, k) in (("cfg4", (4096, 64, 8)), ("cfg3", (64, 48, 6)), ("cfg5", (2048, 64, 16))):
+        out = bench.cpu_baseline(cfg, m, n, k, budget_s=0.5)
+        assert out["kind"] == "port" and out["unit"] == "iter/s" and out["value"] > 0 and out["cores"] >= 1
+        assert "sample" in out
+
+
+def test_gen_csr_row_blocks_partition_the_matrix():
+    """The per-rank CSR generator (fast stand-in): row blocks of any partition concatenate to the whole."""
+    m, n = 5000, 32
+    ip, ix, vv = bench.gen_csr(m, n, 0.05, 0, m, True)
+    assert ip[0] == 0 and ip[-1] == len(vv) == len(ix) and len(ip) == m + 1
+    for size in (2, 3):
+        cols, vals, rows = [], [], 0
+        for rank in range(size):
+            lo, hi = shard_rows(m, rank, size)
+            a, b, c = bench.gen_csr(m, n, 0.05, lo, hi, True)
+            assert a[0] == 0 and len(a) == hi - lo + 1
+            np.testing.assert_array_equal(np.diff(a), np.diff(ip[lo:hi + 1]))
+            cols.append(b); vals.append(c); rows += hi - lo
+        np.testing.assert_array_equal(np.concatenate(cols), ix)
+        np.testing.assert_array_equal(np.concatenate(vals), vv)
+        assert rows == m
