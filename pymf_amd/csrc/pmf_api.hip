@@ -276,16 +276,38 @@ bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != n
 int allreduce_ps(pmf_ctx* c) { return allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false); }
 
 // ---- CSR (SNMF) ----------------------------------------------------------------------------
-int csr_w(pmf_ctx* c) {   // W = V M, M = H^T inv(H H^T) (np x KP) in dW1 (snmf_inverse formed it)
-  const unsigned blocks = (unsigned)std::min<int64_t>((c->mp + 3) / 4, 256 * 16);
-  if (c->KP <= 64)
-    hipLaunchKernelGGL((k_csr_w<1>), dim3(blocks), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,
-                       c->dVals, c->mp, c->KP, c->dW1, c->dW);
-  else
-    hipLaunchKernelGGL((k_csr_w<2>), dim3(blocks), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,
-                       c->dVals, c->mp, c->KP, c->dW1, c->dW);
+template <int NT>
+int launch_csr_w_blocks(pmf_ctx* c) {
+  const size_t mbytes = (size_t)c->np * c->KP * sizeof(float);
+  const int in_lds = mbytes <= 128 * 1024;
+  const size_t smem = in_lds ? mbytes : 0;
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[pmf_current_device()];
+  if (!attr_done) {
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_w_blocks<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  const int64_t nblk = c->mp / 16;
+  const int per_cu = smem <= 80 * 1024 ? 2 : 1;     // workgroups of 16 waves per CU
+  const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nblk + 15) / 16, (int64_t)cus * per_cu));
+  hipLaunchKernelGGL((k_csr_w_blocks<NT>), dim3(wgs), dim3(1024), smem, c->stream, c->dIndptr, c->dIndices, c->dVals,
+                     nblk, c->np, c->dW1, c->dW, in_lds);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
+}
+
+int csr_w(pmf_ctx* c) {   // W = V M, M = H^T inv(H H^T) (np x KP) in dW1 (snmf_inverse formed it)
+  switch (c->NT) {
+    case 1: return launch_csr_w_blocks<1>(c);
+    case 2: return launch_csr_w_blocks<2>(c);
+    case 4: return launch_csr_w_blocks<4>(c);
+    case 8: return launch_csr_w_blocks<8>(c);
+  }
+  return fail(c, PMF_EINVAL, "bad NT");
 }
 
 int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by the CSR scatter
@@ -1154,7 +1176,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
   if (c->algo == PMF_ALGO_SNMF && gram) {
     st.site = SITE_MATERIALIZE;                   // the only m-sized kernel of a Gram-space loop: W = V M, once
     if (c->v_csr) {
-      st.name = "k_csr_w(W = V M)";
+      st.name = "k_csr_w_blocks(W = V M)";
       st.flops = st.exec_flops = 2.0 * nnz * k;
       st.bytes = 4.0 * m * k + 8.0 * nnz + 8.0 * (m + 1.0);      // W written once; CSR arrays read once
     } else {

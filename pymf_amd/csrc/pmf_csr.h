@@ -8,32 +8,63 @@
 #pragma once
 #include "pmf_dev.h"
 
-// W[row][:] = sum over the row's non-zeros of val * M[col][:]; one wave per row, lanes <-> bases.
-template <int VPL>   // bases per lane: KP = 64 * VPL or less
-__global__ __launch_bounds__(256) void k_csr_w(const int64_t* __restrict__ indptr,
-                                               const int32_t* __restrict__ indices,
-                                               const float* __restrict__ vals, int64_t rows, int KP,
-                                               const float* __restrict__ M, float* __restrict__ W) {
-  const int lane = threadIdx.x & 63;
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (int64_t row = w0; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int64_t a = indptr[row], b = indptr[row + 1];
-    float acc[VPL];
+// W = V M for CSR V, the write-bound form (the Gram-space SNMF loop materialises W with it, once per
+// factorize()).  A wave takes 16-row blocks: ONE load brings the block's 17 row pointers, one (or more)
+// its column/value run; then 64 / (KP / 4) rows are formed at a time, KP / 4 lanes per row with four
+// bases each, so every store is a 16-byte-per-lane, 1-KiB-per-instruction contiguous piece of W.  M
+// (np x KP) sits in LDS when it fits (64 KiB at n = k = 128: conflict-free float4 row reads) and is read
+// through L2 otherwise.  1024-thread workgroups: 16 waves share one M image, 256 rows in flight per CU.
+template <int NT>
+__global__ __launch_bounds__(1024) void k_csr_w_blocks(const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ vals, int64_t nblk, int np,
+                                                       const float* __restrict__ M, float* __restrict__ W,
+                                                       int m_in_lds) {
+  constexpr int KP = 16 * NT, LPR = KP / 4, RPI = 64 / LPR;     // lanes per row, rows per store instruction
+  extern __shared__ __attribute__((aligned(16))) float sMw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (m_in_lds) {
+    for (int q = tid; q < np * KP / 4; q += 1024) reinterpret_cast<f32x4*>(sMw)[q] = reinterpret_cast<const f32x4*>(M)[q];
+    __syncthreads();
+  }
+  const float* Msrc = m_in_lds ? sMw : M;
+  const int sub = lane / LPR, c4 = 4 * (lane % LPR);
+  const int64_t nwaves = (int64_t)gridDim.x * 16;
+  for (int64_t blk = (int64_t)blockIdx.x * 16 + wv; blk < nblk; blk += nwaves) {
+    const int64_t r0 = blk * 16;
+    const long long ipv = (long long)indptr[r0 + (lane < 17 ? lane : 16)];
+    const unsigned alo = (unsigned)__builtin_amdgcn_readlane((int)(ipv & 0xffffffffll), 0);
+    const unsigned ahi = (unsigned)__builtin_amdgcn_readlane((int)(ipv >> 32), 0);
+    const long long a = (long long)(((unsigned long long)ahi << 32) | alo);
+    const int rel = (int)(ipv - a);                               // lane r < 17: first entry of row r, block-relative
+    const int nzb = __builtin_amdgcn_readlane(rel, 16);
+    int colv = 0;
+    float valv = 0.f;
+    if (lane < nzb) { colv = indices[a + lane]; valv = vals[a + lane]; }
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) acc[v] = 0.f;
-    for (int64_t e = a; e < b; ++e) {
-      const int col = indices[e];
-      const float val = vals[e];
+    for (int g = 0; g < 16 / RPI; ++g) {
+      const int row = g * RPI + sub;
+      const int ea = __shfl(rel, row, 64), eb = __shfl(rel, row + 1, 64);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int cnt = eb - ea;
+      int cmax = cnt;                                             // wave-uniform trip count: longest row of the group
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int kk = lane + 64 * v;
-        if (kk < KP) acc[v] = fmaf(val, M[(int64_t)col * KP + kk], acc[v]);
+      for (int o = 32; o >= LPR; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+      for (int it = 0; it < cmax; ++it) {
+        const int e = ea + it;
+        int col = __shfl(colv, e & 63, 64);
+        float val = __shfl(valv, e & 63, 64);
+        if (it < cnt && e >= 64) { col = indices[a + e]; val = vals[a + e]; }
+        if (it >= cnt) { col = 0; val = 0.f; }
+        const f32x4 mrow = *reinterpret_cast<const f32x4*>(Msrc + (size_t)col * KP + c4);
+        acc += val * mrow;                                        // duplicates add up, as in V.toarray()
       }
-    }
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const int kk = lane + 64 * v;
-      if (kk < KP) W[row * KP + kk] = acc[v];
+#ifdef PMF_CSRW_PLAIN
+      *reinterpret_cast<f32x4*>(W + (size_t)(r0 + row) * KP + c4) = acc;
+#else
+      __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(W + (size_t)(r0 + row) * KP + c4));   // W is written once, never re-read here
+#endif
     }
   }
 }
