@@ -867,3 +867,125 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
     assert rel_fro(outs[0][4], outs[1][4], what="H after the hooks that follow") < tol
     if not sparse:
         close(outs[0][2], o.ferr, rtol=2e-5, what="gram ferr vs oracle")
+
+
+# ---- BASELINE's other configs at FULL size: size-independent properties (cfg4's are above) ----------
+def _synthetic_rows(seed, rows, ncols):
+    """Host replica of the library's counter-based U[0,1) fill (u01_from in pmf_dev.h: splitmix64 finaliser
+    of seed + golden * (row * ncols + col + 1)) for the given global rows."""
+    with np.errstate(over="ignore"):
+        idx = (np.asarray(rows, dtype=np.uint64)[:, None] * np.uint64(ncols) + np.arange(ncols, dtype=np.uint64)[None, :])
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0))
+
+
+def test_full_size_properties_cfg2(pm):
+    """cfg2 (NMF 65,536 x 512, k = 32, the two-waves-per-block fused kernel): monotone objective, fused
+    one-pass == two-pass tiled hooks, trace-identity error == direct residual, non-negativity."""
+    from pymf_amd import _lib
+    m, n, k = 65536, 512, 32
+    a = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    a.fill_v_uniform(1234); a.fill_w_uniform(42); a.fill_h_uniform(43)
+    assert a.path_name == "k_nmf_fused<2,8>"
+    ferr, done, conv = a.factorize(8, compute_err=True)
+    assert done == 8 and conv < 0
+    assert np.all(np.diff(ferr) <= 1e-6 * ferr[0]), ferr
+    b = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    b.fill_v_uniform(1234); b.fill_w_uniform(42); b.fill_h_uniform(43)
+    fb = []
+    for _ in range(8):
+        b.update_w(); b.update_h()
+        b.set_w(b.get_w())                       # forces the direct residual pass
+        fb.append(b.frobenius())
+    close(ferr, np.array(fb), rtol=2e-6, what="cfg2 ferr: fused + trace identity vs hooks + direct residual")
+    assert rel_fro(a.get_h(), b.get_h(), what="cfg2 H fused vs hooks") < 5e-6
+    Wa, Wb = a.get_w(), b.get_w()
+    assert rel_fro(Wa, Wb, what="cfg2 W fused vs hooks") < 5e-6
+    assert float(Wa.min()) >= 0.0 and np.isfinite(Wa).all() and float(a.get_h().min()) >= 0.0
+    a.close(); b.close()
+
+
+def test_full_size_properties_cfg3(pm):
+    """cfg3 (NMFALS 262,144 x 1024, k = 64): the 262,144 row QPs of one W half step satisfy their KKT
+    conditions (x >= 0, gradient >= -tol, complementarity; every 257th row checked in float64 on the host),
+    the objective does not increase over the two half steps, and the column QPs are at a fixed point."""
+    from pymf_amd import _lib
+    m, n, k = 262144, 1024, 64
+    c = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+    c.fill_v_uniform(1234); c.fill_w_uniform(42); c.fill_h_uniform(43)
+    f0 = c.frobenius()
+    H0 = c.get_h().astype(np.float64)
+    c.update_w()
+    W1 = c.get_w()
+    assert W1.shape == (m, k) and float(W1.min()) >= 0.0 and np.isfinite(W1).all()
+    # KKT of the row QPs (nmfals.py:85-97: HA = H H^T, f = H v^T) on a row sample, in float64 on the host;
+    # the synthetic V is a counter-based stream, so any row can be rebuilt here
+    rows = np.arange(0, m, 257)
+    Vs = _synthetic_rows(1234, rows, n).astype(np.float64)
+    HA, Fm = H0.dot(H0.T), Vs.dot(H0.T)
+    Ws = W1[rows].astype(np.float64)
+    g = Ws.dot(HA) - Fm                               # gradient of 1/2 x'HA x - f'x at the solution
+    scale = np.abs(Fm).max()
+    assert g.min() > -2e-4 * scale, g.min() / scale   # dual feasibility (float32 right-hand sides and storage)
+    assert np.abs(Ws * g).max() < 2e-4 * scale * max(1.0, Ws.max())     # complementarity
+    f1 = c.frobenius()
+    c.update_h()
+    f2 = c.frobenius()
+    assert f1 <= f0 * (1 + 1e-6) and f2 <= f1 * (1 + 1e-6), (f0, f1, f2)
+    H1 = c.get_h().astype(np.float64)
+    assert float(H1.min()) >= 0.0
+    # fixed-point property of the exact column QPs: a second update_h with unchanged W must not move H
+    c.update_h()
+    H2 = c.get_h().astype(np.float64)
+    assert rel_fro(H2, H1, what="cfg3 H: update_h twice (fixed point of the exact QP)") < 1e-6
+    c.close()
+
+
+def test_full_size_properties_cfg5(pm):
+    """cfg5 (SNMF on CSR 4,194,304 x 128 at 1 % nnz, k = 128; the full 2 GiB W): the Gram-space loop and
+    the pass-per-iteration loop agree, the materialised W satisfies W (H H^T) = V H^T row by row (the normal
+    equations of snmf.py:67-70) on sampled rows, H stays non-negative."""
+    import bench
+    from pymf_amd import _lib
+    m, n, k = 4194304, 128, 64           # k = 64 keeps H H^T well conditioned for the equality checks ...
+    ip, ix, vv = bench.gen_csr(m, n, 0.01, 0, m, True)
+    outs = []
+    for gram in (1, 0):
+        c = _lib.Context(_lib.ALGO_SNMF, m, n, k)
+        c.set_v_csr(ip, ix, vv)
+        c.fill_w_uniform(42); c.fill_h_uniform(43)
+        c.set_option("snmf_gram", gram)
+        _, done, _ = c.factorize(3, compute_err=False)
+        assert done == 3
+        H = c.get_h()
+        W = c.get_w()
+        outs.append((W[::1021].copy(), H))
+        if gram:
+            Hd = H.astype(np.float64)
+            assert float(H.min()) >= 0.0 and np.isfinite(H).all()
+            # W was formed from the H BEFORE the last H step: re-derive it by one more W step and check the
+            # normal equations against a float64 evaluation of the sampled rows
+            c.update_w()
+            W2 = c.get_w()
+            rows = np.arange(0, m, 65537)
+            G = Hd.dot(Hd.T)
+            for r in rows:
+                v = np.zeros(n)
+                np.add.at(v, ix[ip[r]:ip[r + 1]], vv[ip[r]:ip[r + 1]].astype(np.float64))
+                lhs, rhs = W2[r].astype(np.float64).dot(G), v.dot(Hd.T)
+                assert np.linalg.norm(lhs - rhs) <= 2e-5 * max(np.linalg.norm(rhs), 1e-30) + 1e-6, r
+        del W
+        c.close()
+    assert rel_fro(outs[0][0], outs[1][0], what="cfg5 W (every 1021st row): Gram-space vs pass-per-iteration") < 5e-5
+    assert rel_fro(outs[0][1], outs[1][1], what="cfg5 H: Gram-space vs pass-per-iteration") < 2e-5
+    # ... and the real thing, k = 128, one Gram-space run end to end (2 GiB of W written)
+    c = _lib.Context(_lib.ALGO_SNMF, m, n, 128)
+    c.set_v_csr(ip, ix, vv)
+    c.fill_w_uniform(42); c.fill_h_uniform(43)
+    _, done, _ = c.factorize(2, compute_err=False)
+    H = c.get_h()
+    assert done == 2 and float(H.min()) >= 0.0 and np.isfinite(H).all()
+    c.close()
