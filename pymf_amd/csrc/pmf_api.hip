@@ -26,6 +26,7 @@
 #include "pmf_small.h"
 #include "pmf_tiled.h"
 #include "pmf_fused.h"
+#include "pmf_fused8.h"
 #include "pmf_nnls.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
@@ -88,6 +89,7 @@ struct pmf_ctx {
   bool v_csr = false;
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
+  bool fused8 = false;          // ... and it is the cooperative 64 < k <= 128 form (pmf_fused8.h)
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
   int g_parts = 0;              // > 0 (with g_valid): G = sum of that many partials in dGpart, dG is stale
   int trace_parts = 0;          // > 0 (with trace_ready): the trace terms are that many pairs in dT1part
@@ -709,11 +711,27 @@ int nmf_fused_pass(pmf_ctx* c) {
   c->trace_ready = false;       // <P,H>, <S,G> belong to the old W
   const float* Gsrc = c->dG;
   int ngp = 0;
-  if (c->g_valid && c->g_parts > 0) { Gsrc = c->dGpart; ngp = c->g_parts; }   // partial sums, added by the kernel
+  if (c->g_valid && c->g_parts > 0 && !c->fused8) { Gsrc = c->dGpart; ngp = c->g_parts; }   // partial sums, added by the kernel
   else PMFCHK(ensure_gram(c, 0.0));
-  stat_begin(c, SITE_FUSED);
   const bool rn = c->algo == PMF_ALGO_RNMF;     // rnmf.py:100-115: both contractions run on D = S - data
   if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+  if (c->fused8) {               // 64 < num_bases <= 128: the cooperative form (pmf_fused8.h)
+    stat_begin(c, SITE_FUSED);
+    const int lrc8 = launch_fused8(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->np,
+                                   rn ? c->dD : c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab,
+                                   c->stop_arg);
+    stat_end(c, SITE_FUSED);
+    if (lrc8 != PMF_OK) return fail(c, lrc8, "fused (k <= 128) kernel launch failed");
+    HIPCHK(c, hipGetLastError());
+    const int NTP8 = c->np / 16;
+    hipLaunchKernelGGL(k_reduce_slabs_tiles8, dim3((unsigned)(8 * NTP8 + 64)), dim3(1024), 0, c->stream, c->dSlab, c->fused_wgs,
+                       NTP8, c->np, c->dPS, c->stop_arg);
+    HIPCHK(c, hipGetLastError());
+    PMFCHK(allreduce_ps(c));
+    c->ps_valid = true;
+    return PMF_OK;
+  }
+  stat_begin(c, SITE_FUSED);
   const int lrc = launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
                                c->np, rn ? c->dD : c->dV, c->dW, c->dH, Gsrc, c->mp, c->fused_wgs, (float)c->lamb_w,
                                c->dSlab, c->stop_arg, ngp);
@@ -1193,15 +1211,19 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
     st.bytes = 4.0 * m * k + 8.0 * nnz + 8.0 * (m + 1.0);
   } else if (c->fused_wgs > 0 && c->algo != PMF_ALGO_NMFALS) {
     st.site = SITE_FUSED;
-    st.name = fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_SNMF   ? FUSED_SNMF
-                                              : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF
-                                              : c->algo == PMF_ALGO_RNMF ? FUSED_RNMF
-                                                                         : FUSED_NMF);
+    st.name = c->fused8 ? c->path.c_str()
+                        : fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_SNMF   ? FUSED_SNMF
+                                                          : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF
+                                                          : c->algo == PMF_ALGO_RNMF ? FUSED_RNMF
+                                                                                     : FUSED_NMF);
     // one pass over V does the four m-sized contractions of an iteration: F = 4 m n k + 4 m k^2
     st.flops = 4.0 * m * n * k + 4.0 * m * k * k;
     if (c->algo == PMF_ALGO_SNMF) {               // executes V M^T, W^T V and the upper triangle of W^T W
       st.exec_flops = 4.0 * m * n * k + m * k * (k + 16.0);
       st.bytes = 4.0 * (m * n + m * k);           // V read once, W written once
+    } else if (c->fused8) {                       // V H^T, W G, W^T V and ALL of W^T W (base split: no symmetry to use)
+      st.exec_flops = 4.0 * m * n * k + 4.0 * m * k * k;
+      st.bytes = 4.0 * (m * n + 2.0 * m * k);
     } else {                                      // V H^T, W G, W^T V and the upper triangle of W^T W
       st.exec_flops = 4.0 * m * n * k + 2.0 * m * k * k + m * k * (k + 16.0);
       st.bytes = 4.0 * (m * n + 2.0 * m * k);     // V read once, W read and written once
@@ -1289,6 +1311,11 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
     c->fused_wgs = (c->nb == 1 && (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF))
                        ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
+    if (c->fused_wgs == 0 && c->nb == 1 && fused8_shape_ok(c->NT, c->np) &&
+        (algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF)) {
+      c->fused8 = true;
+      c->fused_wgs = fused8_grid_for(c->mp);
+    }
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     // dV [mp][np] is allocated by the first pmf_set_v_dense_f32 / pmf_fill_v_uniform: CSR and
     // streamed (pmf_stream_*) contexts never hold a dense V
@@ -1329,6 +1356,11 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     pmf_ctx_destroy(c);
     return rc;
   }
+  if (c->fused8) {
+    char nb_[64];
+    snprintf(nb_, sizeof(nb_), "k_nmf_fused8<%d%s>", c->np / 64, algo == PMF_ALGO_BNMF ? ",bnmf" : algo == PMF_ALGO_RNMF ? ",rnmf" : "");
+    c->path = nb_;
+  } else
   c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF   ? FUSED_SNMF
                                                                            : algo == PMF_ALGO_BNMF ? FUSED_BNMF
                                                                            : algo == PMF_ALGO_RNMF ? FUSED_RNMF
@@ -1526,7 +1558,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       const double lamb_w0 = c->lamb_w, lamb_h0 = c->lamb_h;   // BNMF: every H step scales them (bnmf.py:84-85)
       int lrc = PMF_OK;
       for (int j = 0; j < chunk && lrc == PMF_OK; ++j) {
-        c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + j + 1 < niter;
+        c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + j + 1 < niter && !c->fused8;
         if (h_only) {
           lrc = ensure_ps(c);                               // current since the first iteration (W is fixed)
           if (lrc == PMF_OK) lrc = h_step_from_ps(c);
@@ -1571,7 +1603,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       if (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) {
         // the launches behind the stop were no-ops, but the host-side picture of where G lives was
         // advanced by them: put it back to what iteration s_it's H step (the last that ran) left
-        const bool part = s_it + 1 < niter;
+        const bool part = s_it + 1 < niter && !c->fused8;
         c->g_parts = part ? std::min(c->np / 64, PMF_HGRAM_MAX_WGS) : 0;
       }
       c->trace_ready = false;
@@ -1591,7 +1623,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       } else if (cw && ch && c->algo == PMF_ALGO_SNMF && csr_fused_ok(c)) {
         PMFCHK(snmf_csr_fused_iteration(c));                // CSR: one pass over the rows
       } else if (fused) {                                   // update_w + update_h, one pass over V
-        c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + 1 < niter;
+        c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + 1 < niter && !c->fused8;
         PMFCHK(c->algo == PMF_ALGO_SNMF ? snmf_fused_iteration(c) : nmf_fused_iteration(c));
       } else {
         if (cw) PMFCHK(do_update_w(c));                     // nmf.py:183-184

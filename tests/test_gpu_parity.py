@@ -562,7 +562,7 @@ def test_results_are_reproducible_bit_for_bit(pm, shape, k):
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
 
 
-@pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 300), 128), ("NMF", (2000, 700), 40), ("BNMF", (2500, 200), 100),
+@pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 300), 128), ("NMF", (2000, 700), 40), ("BNMF", (2500, 300), 100),
                                               ("SNMF", (3000, 400), 100), ("NMF", (1500, 1100), 20)])
 def test_tiled_kernels_vs_oracle(pm, cls_name, shape, k):
     """Shapes the one-pass kernel does not take (k > 64, or wider than its LDS budget) run on the
@@ -989,3 +989,69 @@ def test_full_size_properties_cfg5(pm):
     H = c.get_h()
     assert done == 2 and float(H.min()) >= 0.0 and np.isfinite(H).all()
     c.close()
+
+
+
+# ---- 64 < num_bases <= 128: the cooperative one-pass kernel (pmf_fused8.h) ---------------------------
+@pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 256), 128), ("NMF", (777, 200), 100), ("NMF", (64, 64), 65),
+                                              ("BNMF", (5000, 128), 128), ("NMF", (130, 256), 70), ("NMF", (1, 190), 128),
+                                              ("BNMF", (2500, 200), 100), ("NMF", (20000, 256), 96)])
+def test_fused8_vs_oracle(pm, cls_name, shape, k):
+    import oracle
+    rs = np.random.RandomState(shape[0] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    if cls_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    mdl = getattr(pm, cls_name)(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=5)
+    assert mdl._ctx.path_name.startswith("k_nmf_fused8<")
+    o = getattr(oracle, cls_name + "Oracle")(V, num_bases=k)
+    o.W, o.H = W0.copy(), H0.copy()
+    o.factorize(niter=5)
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, o.H, what="mdl.H") < TOL_X
+    close(mdl.ferr, o.ferr, rtol=TOL_F, what="mdl.ferr")
+    # single hooks on the same shape: one-pass update_w + cached (P | S) for update_h
+    mdl.update_w(); o.update_w()
+    mdl.update_h(); o.update_h()
+    assert rel_fro(mdl.W, o.W, what="hooks W") < TOL_X and rel_fro(mdl.H, o.H, what="hooks H") < TOL_X
+
+
+def test_fused8_rnmf_free_run_and_reproducibility(pm):
+    """RNMF on the k <= 128 kernel; the free-running loop equals the stepwise loop bit for bit; two runs
+    give identical bits (per-wave fixed order, float64 slab sums)."""
+    from pymf_amd import _lib
+    from pymf_amd.rnmf import RNMF
+    from oracle import RNMFOracle
+    rs = np.random.RandomState(8)
+    V = rs.random_sample((1200, 256)).astype(np.float32)
+    V.flat[rs.randint(0, V.size, size=V.size // 300)] += 5.0
+    np.random.seed(5)
+    mdl = RNMF(V, num_bases=96, lamb=1.0)
+    mdl.factorize(niter=3)
+    assert mdl._ctx.path_name == "k_nmf_fused8<4,rnmf>"
+    np.random.seed(5)
+    o = RNMFOracle(V, num_bases=96, lamb=1.0)
+    o.factorize(niter=3)
+    close(mdl.ferr, o.ferr, rtol=2e-4, what="mdl.ferr")
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-3 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-3
+    m, n, k = 9000, 192, 128
+    Vd = rs.random_sample((m, n)).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    outs = []
+    for mode in ("free", "free", "step"):
+        c = _lib.Context(_lib.ALGO_NMF, m, n, k)
+        c.set_v_dense(Vd); c.set_w(W0); c.set_h(H0)
+        if mode == "free":
+            f, done, conv = c.factorize(21)
+            f = list(f)
+        else:
+            f = [c.factorize(1, conv_eps=0.0)[0][0] for _ in range(21)]
+        outs.append((c.get_w(), c.get_h(), np.array(f)))
+        c.close()
+    for a, b_ in ((outs[0], outs[1]), (outs[0], outs[2])):
+        np.testing.assert_array_equal(a[0], b_[0])
+        np.testing.assert_array_equal(a[1], b_[1])
+        np.testing.assert_allclose(a[2], b_[2], rtol=1e-12)
