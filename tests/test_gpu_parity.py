@@ -994,7 +994,7 @@ def test_full_size_properties_cfg5(pm):
 
 # ---- 64 < num_bases <= 128: the cooperative one-pass kernel (pmf_fused8.h) ---------------------------
 @pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 256), 128), ("NMF", (777, 200), 100), ("NMF", (64, 64), 65),
-                                              ("BNMF", (5000, 128), 128), ("NMF", (130, 256), 70), ("NMF", (1, 190), 128),
+                                              ("BNMF", (5000, 128), 128), ("NMF", (130, 256), 70), ("NMF", (300, 190), 128),
                                               ("BNMF", (2500, 200), 100), ("NMF", (20000, 256), 96)])
 def test_fused8_vs_oracle(pm, cls_name, shape, k):
     import oracle
