@@ -33,7 +33,11 @@
 
 namespace {
 
-constexpr int PMF_HGRAM_MAX_WGS = 64;   // workgroups of k_nmf_h_gram (one or more 64-column panels each)
+constexpr int PMF_HGRAM_MAX_WGS = 64;
+#ifndef PMF_INV8_TG
+#define PMF_INV8_TG 32          // the 128 x 128 inverse: 32 x 32 threads with 4 x 4 entries each (4 waves per SIMD)
+#endif
+constexpr int PMF_INV8_B = 128 / PMF_INV8_TG;   // workgroups of k_nmf_h_gram (one or more 64-column panels each)
 
 std::string g_create_error;
 
@@ -768,7 +772,7 @@ int snmf_inverse(pmf_ctx* c) {
   if (c->KP <= 64)
     hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
   else
-    hipLaunchKernelGGL((k_inverse_spd<8>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
+    hipLaunchKernelGGL((k_inverse_spd<PMF_INV8_B, PMF_INV8_TG>), dim3(1), dim3(PMF_INV8_TG * PMF_INV8_TG), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
                      (int64_t)c->np, c->np, c->KP, c->dGinvD, c->v_csr ? (float*)nullptr : c->dMT,
@@ -873,7 +877,7 @@ int snmf_gram_iteration(pmf_ctx* c) {
   if (KP <= 64)
     hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
   else
-    hipLaunchKernelGGL((k_inverse_spd<8>), dim3(1), dim3(256), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
+    hipLaunchKernelGGL((k_inverse_spd<PMF_INV8_B, PMF_INV8_TG>), dim3(1), dim3(PMF_INV8_TG * PMF_INV8_TG), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dH, (int64_t)np, np, KP,
                      c->dGinvD, c->v_csr ? (float*)nullptr : c->dMT, c->v_csr ? c->dW1 : (float*)nullptr, c->dMTd, c->stop_arg);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
                                               float* __restrict__ X, int64_t x_sk, int64_t x_sp,
                                               int64_t nprob, const int* __restrict__ warm_flag) {
   const bool warm = warm_flag != nullptr && *warm_flag != 0;
-  extern __shared__ __attribute__((aligned(16))) double sH[];   // [KR][KR], + 1 double: tol
+  extern __shared__ __attribute__((aligned(16))) double sH[];   // [KR][KR]
   const int tid = threadIdx.x, t = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int q = tid; q < KR * KR; q += 256) {
@@ -126,25 +126,27 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
       // slots above the highest passive index hold zeros: the loops stop there (blocks of 8, one
       // uniform branch each) -- the warm start borders in ascending order, so its early steps are short
       const int hi = 63 - __builtin_clzll(pm | (1ull << j));
+      // row j of HA as SCALAR loads (j is wave-uniform; Hd carries the same identity padding as sH): the
+      // operands of this loop arrive in SGPRs through the scalar memory pipe instead of two v_readlane
+      // per slot -- one VALU instruction per slot instead of three
+      const double* __restrict__ hrow = Hd + (size_t)__builtin_amdgcn_readfirstlane(j) * KP;
       double u = 0.0;
 #pragma unroll
       for (int cb = 0; cb < KR; cb += 8) {
         if (cb > hi) break;
 #pragma unroll
-        for (int c = cb; c < cb + 8; c += 4) {          // 4 broadcasts, then 4 fmas: no hazard nops
-          const double b0 = readlane_f64(h, c), b1 = readlane_f64(h, c + 1), b2 = readlane_f64(h, c + 2),
-                       b3 = readlane_f64(h, c + 3);
-          u = fma(A[c], b0, u); u = fma(A[c + 1], b1, u); u = fma(A[c + 2], b2, u); u = fma(A[c + 3], b3, u);
-        }
+        for (int c = cb; c < cb + 8; ++c) u = fma(A[c], hrow[c], u);
       }
-      const double hjj = readlane_f64(h, j);
+      const double hjj = hrow[__builtin_amdgcn_readfirstlane(j)];
       const double sig = hjj - wave_sum_f64(h * u);                     // u is zero off the passive set
       if (!(sig > rel_min * hjj)) { ban |= 1ull << j; return false; }   // numerically dependent column
       // bordered inverse [A + u u'/sig, -u/sig; -u'/sig, 1/sig] = A + v v'/sig with v = (u; -1):
       // row j and column j of A are zero beforehand, so ONE rank-one update writes all four parts
-      const double inv = 1.0 / sig;
+      const double inv = pmf_rcp_f64(sig);     // within an ulp or two of 1 / sig: the size of the update's own rounding
       const double v = (t == j) ? -1.0 : u;                             // u is zero off the passive set
       const double vi = v * inv;
+      // (v through LDS -- one broadcast read per slot instead of two v_readlane -- was measured twice
+      // and is slower: 11.9 vs 6.9 ms per W step at cfg3; the LDS pipe is shared by the CU's 32 waves)
 #pragma unroll
       for (int cb = 0; cb < KR; cb += 8) {
         if (cb > hi) break;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
           for (int c = 0; c < KR; ++c)
             if (c == r) colr = A[c];
           const double arr = readlane_f64(colr, r);
-          const double scale = colr / arr;                // zero on lanes off the passive set
+          const double scale = colr * pmf_rcp_f64(arr);   // zero on lanes off the passive set
           const bool isr = (t == r);
 #pragma unroll
           for (int c = 0; c < KR; ++c) {

@@ -347,46 +347,46 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
 // pivot row" is a compile-time fact.  Writes float32 inv(G)^T into GinvT[ld][ld] (identity on the
 // padding) so that a B[n][k] MFMA operand reads inv[k][n].
 // 128 x 128: 153 us as 1024 threads x 16 entries with per-entry case selects -> see DESIGN 3.3.
-template <int B>
-__global__ __launch_bounds__(256) void k_inverse_spd(const double* __restrict__ Gd, int ld, int k,
-                                                     float* __restrict__ GinvT,
-                                                     double* __restrict__ Ginv64 = nullptr) {
-  constexpr int KP = 16 * B;
+template <int B, int TG = 16>   // TG x TG threads, each B x B entries: matrix order TG * B
+__global__ __launch_bounds__(TG * TG) void k_inverse_spd(const double* __restrict__ Gd, int ld, int k,
+                                                         float* __restrict__ GinvT,
+                                                         double* __restrict__ Ginv64 = nullptr) {
+  constexpr int KP = TG * B;
   __shared__ double prow[2][KP];
   __shared__ double pcol[2][KP];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x, tx = tid % TG, ty = tid / TG;
   double a[B][B];
 #pragma unroll
   for (int u = 0; u < B; ++u)
 #pragma unroll
     for (int v = 0; v < B; ++v) {
-      const int r = ty + 16 * u, c = tx + 16 * v;
+      const int r = ty + TG * u, c = tx + TG * v;
       a[u][v] = (r < k && c < k) ? Gd[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
     }
   int step = 0;
 #pragma unroll
   for (int pu = 0; pu < B; ++pu) {
-    for (int pl = 0; pl < 16; ++pl) {
-      const int p = pl + 16 * pu;
+    for (int pl = 0; pl < TG; ++pl) {
+      const int p = pl + TG * pu;
       if (p >= k) break;                                // identity padding: nothing to eliminate
       const int buf = step & 1;
       ++step;
       if (ty == pl) {                                   // owners of row p
 #pragma unroll
-        for (int v = 0; v < B; ++v) prow[buf][tx + 16 * v] = a[pu][v];
+        for (int v = 0; v < B; ++v) prow[buf][tx + TG * v] = a[pu][v];
       }
       if (tx == pl) {                                   // owners of column p
 #pragma unroll
-        for (int u = 0; u < B; ++u) pcol[buf][ty + 16 * u] = a[u][pu];
+        for (int u = 0; u < B; ++u) pcol[buf][ty + TG * u] = a[u][pu];
       }
       __syncthreads();
       const double app = prow[buf][p];
       const double d = pmf_rcp_f64(app);
       double pr[B], pc[B];
 #pragma unroll
-      for (int v = 0; v < B; ++v) pr[v] = (tx + 16 * v == p) ? 1.0 + d : prow[buf][tx + 16 * v] * d;
+      for (int v = 0; v < B; ++v) pr[v] = (tx + TG * v == p) ? 1.0 + d : prow[buf][tx + TG * v] * d;
 #pragma unroll
-      for (int u = 0; u < B; ++u) pc[u] = (ty + 16 * u == p) ? app - 1.0 : pcol[buf][ty + 16 * u];
+      for (int u = 0; u < B; ++u) pc[u] = (ty + TG * u == p) ? app - 1.0 : pcol[buf][ty + TG * u];
 #pragma unroll
       for (int u = 0; u < B; ++u)
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_inverse_spd(const double* __restrict__ 
   for (int u = 0; u < B; ++u)
 #pragma unroll
     for (int v = 0; v < B; ++v) {
-      const int r = ty + 16 * u, c = tx + 16 * v;     // GinvT[c][r] = inv[r][c]
+      const int r = ty + TG * u, c = tx + TG * v;     // GinvT[c][r] = inv[r][c]
       if (r < ld && c < ld) {
         if (GinvT) GinvT[(int64_t)c * ld + r] = (r < k && c < k) ? (float)a[u][v] : (r == c ? 1.f : 0.f);
         if (Ginv64) Ginv64[(int64_t)r * ld + c] = (r < k && c < k) ? a[u][v] : (r == c ? 1.0 : 0.0);
