@@ -257,7 +257,8 @@ def main():
     preroll_iters, preroll_ms = 0, 0.0
     if args.preroll_ms > 0:
         ctx.factorize(2, compute_err=False)
-        per = max(ctx.last_loop_ms() / 2.0, 1e-3)
+        # every iteration carries a collective: ALL ranks must run the same count (the slowest rank's estimate)
+        per = dist.allreduce_max(max(ctx.last_loop_ms() / 2.0, 1e-3))
         preroll_iters = int(min(max(args.preroll_ms / per, 1), 20000))
         ctx.factorize(preroll_iters, compute_err=False)
         preroll_ms = ctx.last_loop_ms()
