@@ -1721,7 +1721,8 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
 // stream into two device tiles, so the copy of tile t+1 overlaps the kernels of tile t.
 int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
   if (!c) return PMF_EINVAL;
-  if (c->algo != PMF_ALGO_NMF || c->nb > 1) return fail(c, PMF_EINVAL, "pmf_stream_*: NMF contexts with num_bases <= 128 only");
+  if ((c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) || c->nb > 1)
+    return fail(c, PMF_EINVAL, "pmf_stream_*: NMF and BNMF contexts with num_bases <= 128 only");
   if (!c->have_w || !c->have_h) return fail(c, PMF_EINVAL, "pmf_stream_begin: W and H must be set");
   if (max_tile_rows < 1) return fail(c, PMF_EINVAL, "pmf_stream_begin: max_tile_rows must be >= 1");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1791,7 +1792,10 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       HIPCHK(c, hipGetLastError());
     }
     if (c->st_flags & PMF_COMPUTE_W) {
-      PMFCHK(rowgemm<EPI_NMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
+      if (c->algo == PMF_ALGO_BNMF)   // bnmf.py:87-90: the penalised W rule, same contractions
+        PMFCHK(rowgemm<EPI_BNMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
+      else
+        PMFCHK(rowgemm<EPI_NMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
       c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
     }
     if ((c->st_flags & (PMF_COMPUTE_H | PMF_COMPUTE_ERR)) && !((c->st_flags & PMF_COMPUTE_W) == 0 && c->ps_valid)) {

@@ -139,3 +139,23 @@ def test_stream_c_abi_contract(pm):
     with pytest.raises(PmfError):
         snmf.stream_begin()                              # NMF contexts only
     ctx.close(); snmf.close()
+
+
+@pytest.mark.parametrize("name,rows", [("bnmf_96x64_k8", 64), ("bnmf_1024x256_k64", 256)])
+def test_streamed_bnmf_vs_reference_golden(pm, name, rows):
+    """BNMF streams too (bnmf.py:79-90 reads data[:, :] like NMF): same tiles, the penalised epilogue, the
+    reference's lambda schedule (both weights grow by 1.1 per update_h)."""
+    g = load_golden(name)
+    src = SliceOnly(g["V"], rows)
+    mdl = pm.BNMF(src, num_bases=int(g["k"]))
+    mdl.stream_rows = rows
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert src.reads >= int(g["niter"]) * ((g["V"].shape[0] + rows - 1) // rows)
+    assert len(mdl.ferr) == len(g["ferr"])
+    close(mdl.ferr, g["ferr"], rtol=2e-5, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-5 and rel_fro(mdl.H, g["H"], what="mdl.H") < 5e-5
+    res = pm.BNMF(g["V"], num_bases=int(g["k"]))
+    res.W, res.H = g["W0"].copy(), g["H0"].copy()
+    res.factorize(niter=int(g["niter"]))
+    assert (mdl._lamb_W, mdl._lamb_H) == (res._lamb_W, res._lamb_H)
