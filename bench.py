@@ -354,6 +354,11 @@ def main():
                          "achieved_hbm_GBs": by / mean_s / 1e9 if mean_s > 0 else 0.0,
                          "kernel_share_of_timed_region": stats["launches"] * mean_s / dt if dt > 0 else 0.0},
         }
+        if algo_name == "NMFALS":
+            out["roofline"]["note"] = ("k_nnqp is bound by VALU issue, not by HBM or MFMA: float64 active-set updates with lane = "
+                                       "variable cost ~17 k wave instructions per QP at ~3.9 cycles each (rocprofv3 SQ_INSTS_VALU, "
+                                       "profiles/r02_pmc_summary.csv; model in DESIGN.md 3.4) -- the hbm fraction above only says that "
+                                       "memory is not the limit")
         if args.config == "cfg5":
             out["config"]["nnz_local"] = nnz_local
             out["config"]["loop"] = ("Gram space: one k x n sized iteration per step, W = V M materialised once "
