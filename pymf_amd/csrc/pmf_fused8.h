@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused8(const float* __restrict__
     }
     PMF_STAMP(ts2);
 
-    // ---------------- epilogue: W <- (W * Num) / (Den + eps) for 64 rows x own 32 bases ----------------
+    // ---------------- epilogue + P part, row block by row block ----------------
+    // W <- (W * Num) / (Den + eps) for 64 rows x own 32 bases
     // row block by row block (8 elements per lane each); the division in stages as in pmf_fused.h
     f32x4 wn[4][2];
 #pragma unroll
@@ -245,26 +246,25 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused8(const float* __restrict__
         *reinterpret_cast<f32x2*>(wdst + j * KP) = pr;
         *reinterpret_cast<f32x2*>(ldst + vtile_off(4 * kq + j, 8 * (wv & 1) + (i >> 1)) + 2 * (i & 1)) = pr;
       }
+      // ---- phase B, P part of this row block: P += W_new^T V.  The new rows are still in registers
+      // (register j of lane group q IS row 4 q + j of the A operand); its 128 MFMAs run beside the VALU
+      // of the NEXT row block's epilogue ----
+      {
+        const float* sVr = sVall + rb * (NPANEL * 1024);
+#pragma unroll
+        for (int p = 0; p < NPANEL; ++p)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 bf = vtile_read4(sVr + p * 1024, 4 * kq + j, i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              P[0][4 * p + e] = mfma16(wn[rb][0][j], bf[e], P[0][4 * p + e]);
+              P[1][4 * p + e] = mfma16(wn[rb][1][j], bf[e], P[1][4 * p + e]);
+            }
+          }
+      }
     }
     PMF_STAMP(ts3);
-
-    // ---------------- phase B, P part: P += W_new^T V (the new rows are still in registers:
-    // register j of lane group q IS row 4 q + j of the A operand) ----------------
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const float* sVr = sVall + rb * (NPANEL * 1024);
-#pragma unroll
-      for (int p = 0; p < NPANEL; ++p)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 bf = vtile_read4(sVr + p * 1024, 4 * kq + j, i);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            P[0][4 * p + e] = mfma16(wn[rb][0][j], bf[e], P[0][4 * p + e]);
-            P[1][4 * p + e] = mfma16(wn[rb][1][j], bf[e], P[1][4 * p + e]);
-          }
-        }
-    }
     PMF_STAMP(ts4);
     __syncthreads();                  // new-W tile complete; every wave is done with the V and old-W images
     PMF_STAMP(ts5);
