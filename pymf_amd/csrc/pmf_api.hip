@@ -1721,8 +1721,8 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
 // stream into two device tiles, so the copy of tile t+1 overlaps the kernels of tile t.
 int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
   if (!c) return PMF_EINVAL;
-  if ((c->algo != PMF_ALGO_NMF && c->algo != PMF_ALGO_BNMF) || c->nb > 1)
-    return fail(c, PMF_EINVAL, "pmf_stream_*: NMF and BNMF contexts with num_bases <= 128 only");
+  if (c->algo == PMF_ALGO_RNMF || c->nb > 1)
+    return fail(c, PMF_EINVAL, "pmf_stream_*: NMF, BNMF, SNMF and NMFALS contexts with num_bases <= 128");
   if (!c->have_w || !c->have_h) return fail(c, PMF_EINVAL, "pmf_stream_begin: W and H must be set");
   if (max_tile_rows < 1) return fail(c, PMF_EINVAL, "pmf_stream_begin: max_tile_rows must be >= 1");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1751,7 +1751,13 @@ int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
   c->st_tiles = 0;
   c->st_active = true;
   c->st_vnorm_pending = !(flags & PMF_STREAM_RESID) && !c->vnorm_valid;
-  if ((flags & PMF_COMPUTE_W) && !(flags & PMF_STREAM_RESID)) PMFCHK(ensure_gram(c, 0.0));
+  if ((flags & PMF_COMPUTE_W) && !(flags & PMF_STREAM_RESID)) {
+    // what the W step of every tile needs from H: G = H H^T (NMF, BNMF); M^T = inv(H H^T) H (SNMF, snmf.py:67-70);
+    // the Hessian H H^T in float64 + the warm-start verdict (NMFALS, nmfals.py:85-97)
+    if (c->algo == PMF_ALGO_SNMF) PMFCHK(snmf_inverse(c));
+    else if (c->algo == PMF_ALGO_NMFALS) { PMFCHK(ensure_gram(c, 1.0)); PMFCHK(nnqp_warm_flag(c)); }
+    else PMFCHK(ensure_gram(c, 0.0));
+  }
   return PMF_OK;
 }
 
@@ -1792,10 +1798,19 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       HIPCHK(c, hipGetLastError());
     }
     if (c->st_flags & PMF_COMPUTE_W) {
-      if (c->algo == PMF_ALGO_BNMF)   // bnmf.py:87-90: the penalised W rule, same contractions
+      if (c->algo == PMF_ALGO_BNMF) {   // bnmf.py:87-90: the penalised W rule, same contractions
         PMFCHK(rowgemm<EPI_BNMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
-      else
+      } else if (c->algo == PMF_ALGO_SNMF) {   // snmf.py:67-70: the tile's rows of W = V M^T
+        PMFCHK(rowgemm<EPI_STORE>(c, T, c->np, c->np, c->dMT, c->np, nullptr, nullptr, Wt, rows_p, rows));
+      } else if (c->algo == PMF_ALGO_NMFALS) {  // nmfals.py:85-97: right-hand sides V H^T of the tile's rows, one QP per row
+        float* Ft = c->dW1 + row0 * c->KP;
+        PMFCHK(rowgemm<EPI_STORE>(c, T, c->np, c->np, c->dH, c->np, nullptr, nullptr, Ft, rows_p, rows));
+        const int qrc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm);
+        if (qrc != PMF_OK) return fail(c, qrc, "nnqp launch (streamed W tile) failed");
+        HIPCHK(c, hipGetLastError());
+      } else {
         PMFCHK(rowgemm<EPI_NMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
+      }
       c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
     }
     if ((c->st_flags & (PMF_COMPUTE_H | PMF_COMPUTE_ERR)) && !((c->st_flags & PMF_COMPUTE_W) == 0 && c->ps_valid)) {
@@ -1857,7 +1872,7 @@ int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
   }
   if (c->st_flags & PMF_COMPUTE_H) {
     c->want_trace = (c->st_flags & PMF_COMPUTE_ERR) != 0;
-    const int rc = h_step_from_ps(c);
+    const int rc = c->algo == PMF_ALGO_NMFALS ? als_update_h(c) : h_step_from_ps(c);   // nmfals.py:70-82: QPs over the summed (P | S)
     c->want_trace = false;
     PMFCHK(rc);
   }

@@ -134,11 +134,11 @@ def test_stream_c_abi_contract(pm):
         ctx.stream_end()                                 # rows missing
     with pytest.raises(PmfError):
         ctx.update_w()                                   # V was never made resident
-    snmf = _lib.Context(_lib.ALGO_SNMF, 300, 40, 5)
-    snmf.set_w(np.ones((300, 5))); snmf.set_h(np.ones((5, 40)))
+    rn = _lib.Context(_lib.ALGO_RNMF, 300, 40, 5)
+    rn.set_w(np.ones((300, 5))); rn.set_h(np.ones((5, 40)))
     with pytest.raises(PmfError):
-        snmf.stream_begin()                              # NMF contexts only
-    ctx.close(); snmf.close()
+        rn.stream_begin()                                # RNMF keeps an m x n state (S): not streamed
+    ctx.close(); rn.close()
 
 
 @pytest.mark.parametrize("name,rows", [("bnmf_96x64_k8", 64), ("bnmf_1024x256_k64", 256)])
@@ -159,3 +159,30 @@ def test_streamed_bnmf_vs_reference_golden(pm, name, rows):
     res.W, res.H = g["W0"].copy(), g["H0"].copy()
     res.factorize(niter=int(g["niter"]))
     assert (mdl._lamb_W, mdl._lamb_H) == (res._lamb_W, res._lamb_H)
+
+
+@pytest.mark.parametrize("cls_name,name,rows", [("SNMF", "snmf_cfg4s", 512), ("SNMF", "snmf_512x128_k16", 128),
+                                                ("SNMF", "snmf_37x29_k5", 64), ("NMFALS", "nmfals_130x90_k33", 64),
+                                                ("NMFALS", "nmfals_cfg3s", 512), ("NMFNNLS", "nnls_24x18_k4", 64)])
+def test_streamed_snmf_and_nmfals_vs_reference_golden(pm, cls_name, name, rows):
+    """The `data[:, :]` idiom is in every class of the reference (snmf.py:68,79; nmfals.py:73,88): SNMF and
+    NMFALS stream row tiles like NMF -- per tile the class's W step (W = V M^T resp. one QP per row), then
+    the partials of W^T V | W^T W; the H step once per pass."""
+    g = load_golden(name)
+    src = SliceOnly(g["V"], rows)
+    mdl = getattr(pm, cls_name)(src, num_bases=int(g["k"]))
+    mdl.stream_rows = rows
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert src.reads >= int(g["niter"]) * ((g["V"].shape[0] + rows - 1) // rows)
+    assert len(mdl.ferr) == len(g["ferr"])
+    tol = 5e-5 if cls_name == "SNMF" else 2e-4
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < tol and rel_fro(mdl.H, g["H"], what="mdl.H") < tol
+    close(mdl.ferr, g["ferr"], rtol=1e-4, what="mdl.ferr")
+    # and the streamed object equals the resident one on the same inputs
+    res = getattr(pm, cls_name)(g["V"], num_bases=int(g["k"]))
+    res.W, res.H = g["W0"].copy(), g["H0"].copy()
+    res.factorize(niter=int(g["niter"]))
+    assert rel_fro(mdl.W, res.W, what="streamed vs resident W") < tol
+    assert rel_fro(mdl.H, res.H, what="streamed vs resident H") < tol
+    assert abs(mdl.frobenius_norm() - res.frobenius_norm()) <= 1e-4 * res.frobenius_norm()

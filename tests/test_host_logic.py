@@ -70,7 +70,7 @@ def test_fingerprint_follows_in_place_edits():
 
 def test_stream_switches():
     V = np.ones((200, 5), dtype=np.float32)
-    for cls, ok in ((pymf_amd.NMF, True), (pymf_amd.BNMF, True), (pymf_amd.SNMF, False), (pymf_amd.NMFALS, False)):
+    for cls, ok in ((pymf_amd.NMF, True), (pymf_amd.BNMF, True), (pymf_amd.SNMF, True), (pymf_amd.NMFALS, True), (RNMF, False)):
         m = cls(V, num_bases=2)
         assert m._stream_rows() == 0
         m.stream_rows = 100
