@@ -384,13 +384,16 @@ __global__ __launch_bounds__(TG * TG) void k_inverse_spd(const double* __restric
       const double d = pmf_rcp_f64(app);
       double pr[B], pc[B];
 #pragma unroll
-      for (int v = 0; v < B; ++v) pr[v] = (tx + TG * v == p) ? 1.0 + d : prow[buf][tx + TG * v] * d;
+      for (int v = 0; v < B; ++v) pr[v] = prow[buf][tx + TG * v] * d;
 #pragma unroll
-      for (int u = 0; u < B; ++u) pc[u] = (ty + TG * u == p) ? app - 1.0 : pcol[buf][ty + TG * u];
+      for (int u = 0; u < B; ++u) pc[u] = -pcol[buf][ty + TG * u];
+      // the pivot's own row / column entry: p = pl + TG pu, so only register pu of the owners can be it
+      if (tx == pl) pr[pu] = 1.0 + d;
+      if (ty == pl) pc[pu] = 1.0 - app;
 #pragma unroll
       for (int u = 0; u < B; ++u)
 #pragma unroll
-        for (int v = 0; v < B; ++v) a[u][v] = fma(-pc[u], pr[v], a[u][v]);
+        for (int v = 0; v < B; ++v) a[u][v] = fma(pc[u], pr[v], a[u][v]);
     }
   }
 #pragma unroll
