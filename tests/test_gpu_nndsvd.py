@@ -29,8 +29,8 @@ def test_nndsvd_vs_reference_golden(pm, name):
     assert mdl.W.shape == g["W"].shape and mdl.H.shape == g["H"].shape
     assert mdl.W.dtype == np.float64 and mdl.H.dtype == np.float64      # np.zeros init (nndsvd.py:70,73)
     assert (mdl.W >= 0).all() and (mdl.H >= 0).all()
-    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-4, rel_fro(mdl.W, g["W"], what="mdl.W")
-    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 5e-4, rel_fro(mdl.H, g["H"], what="mdl.H")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 3e-4, rel_fro(mdl.W, g["W"], what="mdl.W")
+    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 3e-4, rel_fro(mdl.H, g["H"], what="mdl.H")
     assert len(mdl.ferr) == 1
     close(mdl.ferr, g["ferr"], rtol=1e-4, atol=1e-5, what="mdl.ferr")
 
@@ -44,8 +44,8 @@ def test_nndsvd_then_nmf_matches_reference(pm):
     mdl.W = nd.W
     mdl.H = nd.H
     mdl.factorize(niter=10)
-    close(mdl.ferr, g["ferr_nmf10"], rtol=1e-4, what="mdl.ferr")
-    assert rel_fro(mdl.W, g["W_nmf10"], what="mdl.W") < 2e-3 and rel_fro(mdl.H, g["H_nmf10"], what="mdl.H") < 2e-3
+    close(mdl.ferr, g["ferr_nmf10"], rtol=8e-7, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W_nmf10"], what="mdl.W") < 6e-5 and rel_fro(mdl.H, g["H_nmf10"], what="mdl.H") < 6e-5
     # the head start the initialiser exists for: the first NMF error is below a random start's
     rnd = pm.NMF(g["V"], num_bases=int(g["k"]))
     np.random.seed(0)
@@ -63,8 +63,8 @@ def test_nndsvd_vs_float64_oracle(pm, shape, k):
     W, H = nndsvd_closed_form(V, k)
     # trailing singular directions of a random matrix are nearly degenerate: compare the product
     # basis by basis only where the gap allows, and the factors overall
-    assert rel_fro(mdl.W, W, what="mdl.W") < 2e-3, rel_fro(mdl.W, W, what="mdl.W")
-    assert rel_fro(mdl.H, H, what="mdl.H") < 2e-3, rel_fro(mdl.H, H, what="mdl.H")
+    assert rel_fro(mdl.W, W, what="mdl.W") < 2e-5, rel_fro(mdl.W, W, what="mdl.W")
+    assert rel_fro(mdl.H, H, what="mdl.H") < 2e-5, rel_fro(mdl.H, H, what="mdl.H")
     ref_err = np.linalg.norm(V.astype(np.float64) - W @ H)
     assert abs(mdl.ferr[0] - ref_err) <= 1e-4 * max(ref_err, 1e-3)
 
@@ -87,12 +87,12 @@ def test_nndsvd_init_through_the_c_abi(pm):
     assert ctx.nndsvd_init() == 24
     W0, H0 = ctx.get_w(), ctx.get_h()
     Wr, Hr = nndsvd_closed_form(V, 24)
-    assert rel_fro(W0, Wr, what="W0") < 1e-3 and rel_fro(H0, Hr, what="H0") < 1e-3
+    assert rel_fro(W0, Wr, what="W0") < 6e-6 and rel_fro(H0, Hr, what="H0") < 6e-6
     ferr, done, _ = ctx.factorize(5, True, True, True)
     o = NMFOracle(V, num_bases=24)
     o.W, o.H = W0.astype(np.float64), H0.astype(np.float64)
     o.factorize(niter=5)
-    close(ferr[:done], o.ferr, rtol=1e-5, what="ferr[:done]")
+    close(ferr[:done], o.ferr, rtol=3e-7, what="ferr[:done]")
     ctx.close()
 
 

@@ -60,7 +60,7 @@ def test_snmf_vs_reference_golden(pm, name):
     # W crosses zero: Frobenius-relative only
     assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-5
     assert rel_fro(mdl.H, g["H"], what="mdl.H") < TOL_X
-    close(mdl.ferr, g["ferr"], rtol=2e-5, what="mdl.ferr")
+    close(mdl.ferr, g["ferr"], rtol=5e-6, what="mdl.ferr")
 
 
 @pytest.mark.parametrize("name,sparse", [("snmf_cfg5s_dense_f64", False), ("snmf_csr_k128_f64", False),
@@ -77,11 +77,11 @@ def test_snmf_cfg5_shape_class_vs_reference_golden(pm, name, sparse):
     mdl = pm.SNMF(V, num_bases=int(g["k"]))
     mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
     mdl.factorize(niter=int(g["niter"]), compute_err=not sparse)
-    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-5
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 3e-5
     assert rel_fro(mdl.H, g["H"], what="mdl.H") < TOL_X
     # on record next to them: what the reference's own float32 arithmetic achieves on the same inputs
-    assert rel_fro(g["W32"], g["W"], what="reference float32 path W (not the device)") < 1.0
-    assert rel_fro(g["H32"], g["H"], what="reference float32 path H (not the device)") < 1.0
+    assert rel_fro(g["W32"], g["W"], what="reference float32 path W (not the device)") < 4e-1
+    assert rel_fro(g["H32"], g["H"], what="reference float32 path H (not the device)") < 9e-5
     assert rel_fro(mdl.W, g["W"]) < 1e-2 * rel_fro(g["W32"], g["W"])
     if not sparse:
         assert len(mdl.ferr) == len(g["ferr"])
@@ -117,10 +117,10 @@ def test_single_hooks_match_oracle(pm):
     assert abs(mdl.frobenius_norm() - frobenius_norm(V, W, H)) / frobenius_norm(V, W, H) < TOL_F
     mdl.update_w()
     nmf_update_w(V, W, H)
-    assert rel_fro(mdl.W, W, what="mdl.W") < 2e-6
+    assert rel_fro(mdl.W, W, what="mdl.W") < 7e-7
     mdl.update_h()
     nmf_update_h(V, W, H)
-    assert rel_fro(mdl.H, H, what="mdl.H") < 2e-6
+    assert rel_fro(mdl.H, H, what="mdl.H") < 2e-7
     assert abs(mdl.frobenius_norm() - frobenius_norm(V, W, H)) / frobenius_norm(V, W, H) < TOL_F
 
 
@@ -198,7 +198,7 @@ def test_linearity_property_large(pm):
     b = pm.NMF(V, num_bases=k)
     b.W, b.H = W0.copy(), (2.0 * H0)
     b.update_w()
-    assert rel_fro(2.0 * b.W, a.W, what="2.0 * b.W") < 1e-6
+    assert rel_fro(2.0 * b.W, a.W, what="2.0 * b.W") < 1e-9
 
 
 def test_rccl_path_single_rank_communicator(pm):
@@ -241,8 +241,8 @@ def test_fused_and_tiled_paths_agree(pm):
     for _ in range(3):                               # hooks -> tiled kernels
         b.update_w()
         b.update_h()
-    assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < 2e-6
-    assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < 2e-6
+    assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < 1e-9
+    assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < 1e-9
 
 
 def test_full_size_properties_cfg4(pm):
@@ -267,15 +267,15 @@ def test_full_size_properties_cfg4(pm):
         b.update_h()
         b.set_w(b.get_w())                                        # "new" W invalidates (W^T V | W^T W): forces the direct pass
         fb.append(b.frobenius())
-    close(ferr, np.array(fb), rtol=2e-6, what="ferr")     # (2) + (3)
+    close(ferr, np.array(fb), rtol=8e-9, what="ferr")     # (2) + (3)
     Ha, Hb = a.get_h(), b.get_h()                                 # H depends on every row of W
-    assert rel_fro(Ha, Hb, what="Ha") < 5e-6
+    assert rel_fro(Ha, Hb, what="Ha") < 1e-9
     assert np.isfinite(Ha).all() and Ha.min() >= 0                # (4)
     Wa = a.get_w()
     assert float(Wa.min()) >= 0.0 and np.isfinite(float(Wa.sum(dtype=np.float64)))
     Wb = b.get_w()
     sl = slice(0, m, 4097)
-    assert rel_fro(Wa[sl], Wb[sl], what="Wa[sl]") < 5e-6
+    assert rel_fro(Wa[sl], Wb[sl], what="Wa[sl]") < 1e-9
     a.close(); b.close()
 
 
@@ -292,7 +292,7 @@ def test_ragged_and_tiny_shapes(pm, m, n, k):
     ref.W, ref.H = W0.copy(), H0.copy()
     ref.factorize(niter=4)
     assert mdl.W.shape == (m, k) and mdl.H.shape == (k, n)
-    assert rel_fro(mdl.W, ref.W, what="mdl.W") < 5e-5 and rel_fro(mdl.H, ref.H, what="mdl.H") < 5e-5
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < 2e-6 and rel_fro(mdl.H, ref.H, what="mdl.H") < 8e-7
     if ref.ferr[-1] > 1e-5 * np.linalg.norm(V):
         close(mdl.ferr, ref.ferr, rtol=2e-4, atol=1e-6, what="mdl.ferr")
     else:
@@ -334,8 +334,8 @@ def test_snmf_fused_and_tiled_paths_agree(pm):
     for _ in range(3):
         b.update_w()
         b.update_h()
-    assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < 1e-5
-    assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < 1e-5
+    assert rel_fro(a.get_w(), b.get_w(), what="a.get_w()") < 2e-6
+    assert rel_fro(a.get_h(), b.get_h(), what="a.get_h()") < 4e-7
 
 
 def test_bitwise_reproducible(pm):
@@ -582,7 +582,7 @@ def test_tiled_kernels_vs_oracle(pm, cls_name, shape, k):
     o.factorize(niter=4)
     tol = 5e-4 if cls_name == "SNMF" else 5e-5
     assert rel_fro(mdl.W, o.W, what="mdl.W") < tol and rel_fro(mdl.H, o.H, what="mdl.H") < tol
-    close(mdl.ferr, o.ferr, rtol=2e-5, what="mdl.ferr")
+    close(mdl.ferr, o.ferr, rtol=2e-8, what="mdl.ferr")
 
 
 @pytest.mark.parametrize("shape,k", [((2000, 300), 200), ((1500, 500), 129), ((700, 900), 300), ((3000, 64), 256)])
@@ -599,7 +599,7 @@ def test_nmf_more_than_128_bases(pm, shape, k):
     o.W, o.H = W0.copy(), H0.copy()
     o.factorize(niter=4)
     assert rel_fro(mdl.W, o.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, o.H, what="mdl.H") < TOL_X
-    close(mdl.ferr, o.ferr, rtol=5e-5, what="mdl.ferr")       # trace identity only at this width
+    close(mdl.ferr, o.ferr, rtol=7e-9, what="mdl.ferr")       # trace identity only at this width
     mdl.update_w(); o.update_w()
     mdl.update_h(); o.update_h()
     assert rel_fro(mdl.W, o.W, what="mdl.W") < TOL_X and rel_fro(mdl.H, o.H, what="mdl.H") < TOL_X
@@ -623,7 +623,7 @@ def test_error_after_a_w_only_step_is_not_stale(pm, cls_name):
     a.factorize(niter=7, compute_h=False); o.factorize(niter=7, compute_h=False)
     # SNMF's W step with H fixed is a closed form: the error repeats and the loop stops at i == 2
     assert len(a.ferr) == len(o.ferr) == (2 if cls_name == "SNMF" else 7)
-    close(a.ferr, o.ferr, rtol=2e-5, what="a.ferr")
+    close(a.ferr, o.ferr, rtol=3e-8, what="a.ferr")
     tol = 5e-4 if cls_name == "SNMF" else 5e-5
     assert rel_fro(a.W, o.W, what="a.W") < tol
     a.update_w(); o.update_w()
@@ -717,7 +717,7 @@ def test_overridden_hooks_are_called_like_the_reference(pm, cls_name):
     assert len(a.ferr) == len(o.ferr) == 4                   # the user's converged() fired at i == 4
     tol = 5e-5 if cls_name == "SNMF" else TOL_X
     assert rel_fro(a.W, o.W, what="a.W") < tol and rel_fro(a.H, o.H, what="a.H") < tol
-    close(a.ferr, o.ferr, rtol=2e-5, what="a.ferr")
+    close(a.ferr, o.ferr, rtol=2e-8, what="a.ferr")
 
 
 def test_hook_loop_equals_one_call_loop(pm):
@@ -744,7 +744,7 @@ def test_hook_loop_equals_one_call_loop(pm):
     np.testing.assert_array_equal(a.H, b.H)
     # the error: same (P | S), H and ||V||^2, but the trace terms are summed by k_trace_terms in the hook
     # loop and inside k_nmf_h_gram in the one-call loop -- float64 sums in a different order
-    close(a.ferr, b.ferr, rtol=1e-8, what="a.ferr")
+    close(a.ferr, b.ferr, rtol=3e-9, what="a.ferr")
 
 
 def test_instance_level_hook_and_show_progress(pm, caplog):
@@ -813,7 +813,7 @@ def test_data_edited_in_place_is_noticed(pm, cls_name):
     a.factorize(niter=3); o.factorize(niter=3)
     tol = 5e-5 if cls_name == "SNMF" else TOL_X
     assert rel_fro(a.W, o.W, what="a.W") < tol and rel_fro(a.H, o.H, what="a.H") < tol
-    close(a.ferr, o.ferr, rtol=2e-5, what="a.ferr")
+    close(a.ferr, o.ferr, rtol=4e-8, what="a.ferr")
     # check_data = False: the upload happens once per object until invalidate_data() is called
     a.check_data = False
     Va[:, 3] = 0.0; Vo[:, 3] = 0.0
@@ -866,7 +866,7 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
     assert rel_fro(outs[0][3], outs[1][3], what="W after the hooks that follow") < (tol if ill else 5e-5)
     assert rel_fro(outs[0][4], outs[1][4], what="H after the hooks that follow") < tol
     if not sparse:
-        close(outs[0][2], o.ferr, rtol=2e-5, what="gram ferr vs oracle")
+        close(outs[0][2], o.ferr, rtol=2e-8, what="gram ferr vs oracle")
 
 
 # ---- BASELINE's other configs at FULL size: size-independent properties (cfg4's are above) ----------
@@ -900,10 +900,10 @@ def test_full_size_properties_cfg2(pm):
         b.update_w(); b.update_h()
         b.set_w(b.get_w())                       # forces the direct residual pass
         fb.append(b.frobenius())
-    close(ferr, np.array(fb), rtol=2e-6, what="cfg2 ferr: fused + trace identity vs hooks + direct residual")
-    assert rel_fro(a.get_h(), b.get_h(), what="cfg2 H fused vs hooks") < 5e-6
+    close(ferr, np.array(fb), rtol=2e-8, what="cfg2 ferr: fused + trace identity vs hooks + direct residual")
+    assert rel_fro(a.get_h(), b.get_h(), what="cfg2 H fused vs hooks") < 1e-9
     Wa, Wb = a.get_w(), b.get_w()
-    assert rel_fro(Wa, Wb, what="cfg2 W fused vs hooks") < 5e-6
+    assert rel_fro(Wa, Wb, what="cfg2 W fused vs hooks") < 1e-9
     assert float(Wa.min()) >= 0.0 and np.isfinite(Wa).all() and float(a.get_h().min()) >= 0.0
     a.close(); b.close()
 
@@ -940,7 +940,7 @@ def test_full_size_properties_cfg3(pm):
     # fixed-point property of the exact column QPs: a second update_h with unchanged W must not move H
     c.update_h()
     H2 = c.get_h().astype(np.float64)
-    assert rel_fro(H2, H1, what="cfg3 H: update_h twice (fixed point of the exact QP)") < 1e-6
+    assert rel_fro(H2, H1, what="cfg3 H: update_h twice (fixed point of the exact QP)") < 1e-9
     c.close()
 
 
@@ -979,8 +979,8 @@ def test_full_size_properties_cfg5(pm):
                 assert np.linalg.norm(lhs - rhs) <= 2e-5 * max(np.linalg.norm(rhs), 1e-30) + 1e-6, r
         del W
         c.close()
-    assert rel_fro(outs[0][0], outs[1][0], what="cfg5 W (every 1021st row): Gram-space vs pass-per-iteration") < 5e-5
-    assert rel_fro(outs[0][1], outs[1][1], what="cfg5 H: Gram-space vs pass-per-iteration") < 2e-5
+    assert rel_fro(outs[0][0], outs[1][0], what="cfg5 W (every 1021st row): Gram-space vs pass-per-iteration") < 1e-6
+    assert rel_fro(outs[0][1], outs[1][1], what="cfg5 H: Gram-space vs pass-per-iteration") < 5e-7
     # ... and the real thing, k = 128, one Gram-space run end to end (2 GiB of W written)
     c = _lib.Context(_lib.ALGO_SNMF, m, n, 128)
     c.set_v_csr(ip, ix, vv)
@@ -1034,8 +1034,8 @@ def test_fused8_rnmf_free_run_and_reproducibility(pm):
     np.random.seed(5)
     o = RNMFOracle(V, num_bases=96, lamb=1.0)
     o.factorize(niter=3)
-    close(mdl.ferr, o.ferr, rtol=2e-4, what="mdl.ferr")
-    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-3 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-3
+    close(mdl.ferr, o.ferr, rtol=1e-7, what="mdl.ferr")
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 8e-7
     m, n, k = 9000, 192, 128
     Vd = rs.random_sample((m, n)).astype(np.float32)
     W0 = rs.random_sample((m, k)).astype(np.float32)

@@ -27,14 +27,14 @@ def test_rnmf_vs_reference_golden(pm, name):
     mdl = RNMF(g["V"], num_bases=int(g["k"]), lamb=float(g["lamb"]))
     mdl.factorize(niter=int(g["niter"]))                 # lazy init_w / init_h / update_s as in the reference
     assert len(mdl.ferr) == len(g["ferr"])
-    close(mdl.ferr, g["ferr"], rtol=2e-4, what="mdl.ferr")
-    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 1e-3
-    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 1e-3
+    close(mdl.ferr, g["ferr"], rtol=3e-6, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-5
+    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-6
     S = mdl.S
     assert S.shape == g["S"].shape
     mism = np.count_nonzero((S != 0) != (g["S"] != 0))
     assert mism <= max(2, g["S"].size // 2000)           # threshold flips at float32 rounding only
-    assert rel_fro(S, g["S"], what="S") < 2e-2
+    assert rel_fro(S, g["S"], what="S") < 5e-7
 
 
 def test_rnmf_hooks_and_missing_s(pm):
@@ -55,8 +55,8 @@ def test_rnmf_hooks_and_missing_s(pm):
     mdl.update_s(); ref.update_s()
     mdl.update_w(); ref.update_w()
     mdl.update_h(); ref.update_h()
-    assert rel_fro(mdl.W, ref.W, what="mdl.W") < 1e-4 and rel_fro(mdl.H, ref.H, what="mdl.H") < 1e-4
-    assert rel_fro(mdl.S, ref.S, what="mdl.S") < 1e-2
+    assert rel_fro(mdl.W, ref.W, what="mdl.W") < 5e-7 and rel_fro(mdl.H, ref.H, what="mdl.H") < 3e-7
+    assert rel_fro(mdl.S, ref.S, what="mdl.S") < 8e-7
     assert abs(mdl.frobenius_norm() - ref.frobenius_norm()) / ref.frobenius_norm() < 1e-4
 
 
@@ -75,5 +75,5 @@ def test_rnmf_fused_shapes_vs_oracle(pm, shape, k):
     np.random.seed(5)
     o = RNMFOracle(V, num_bases=k, lamb=1.0)
     o.factorize(niter=3)
-    close(mdl.ferr, o.ferr, rtol=2e-4, what="mdl.ferr")
-    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-3 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-3
+    close(mdl.ferr, o.ferr, rtol=1e-7, what="mdl.ferr")
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 8e-7

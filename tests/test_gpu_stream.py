@@ -44,8 +44,8 @@ def test_streamed_nmf_vs_reference_golden(pm, name, rows):
     mdl.factorize(niter=int(g["niter"]))
     assert src.reads >= int(g["niter"]) * ((g["V"].shape[0] + rows - 1) // rows)
     assert len(mdl.ferr) == len(g["ferr"])
-    close(mdl.ferr, g["ferr"], rtol=1e-5, what="mdl.ferr")
-    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-5 and rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-5
+    close(mdl.ferr, g["ferr"], rtol=5e-7, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 4e-6 and rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-6
 
 
 @pytest.mark.parametrize("shape,k,rows", [((5000, 200), 20, 1024), ((1000, 70), 7, 384), ((4096, 256), 64, 4096),
@@ -64,8 +64,8 @@ def test_streamed_equals_resident(pm, shape, k, rows, tmp_path):
     st.stream_rows = rows
     st.W, st.H = W0.copy(), H0.copy()
     st.factorize(niter=6)
-    close(st.ferr, res.ferr, rtol=2e-6, what="st.ferr")
-    assert rel_fro(st.W, res.W, what="st.W") < 5e-6 and rel_fro(st.H, res.H, what="st.H") < 5e-6
+    close(st.ferr, res.ferr, rtol=1e-7, what="st.ferr")
+    assert rel_fro(st.W, res.W, what="st.W") < 6e-7 and rel_fro(st.H, res.H, what="st.H") < 5e-7
     assert abs(st.frobenius_norm() - res.frobenius_norm()) <= 2e-6 * res.frobenius_norm()
 
 
@@ -82,9 +82,9 @@ def test_streamed_flags_and_hooks(pm):
         m.stream_rows = 256
         m.W, m.H = W0.copy(), H0.copy()
         m.factorize(niter=4, **flags)
-        assert rel_fro(m.W, o.W, what="m.W") < 2e-5 and rel_fro(m.H, o.H, what="m.H") < 2e-5, flags
+        assert rel_fro(m.W, o.W, what="m.W") < 2e-6 and rel_fro(m.H, o.H, what="m.H") < 4e-7, flags
         if flags.get("compute_err", True):
-            close(m.ferr, o.ferr, rtol=1e-5, what="m.ferr")
+            close(m.ferr, o.ferr, rtol=6e-8, what="m.ferr")
         else:
             assert not hasattr(m, "ferr")
     o = NMFOracle(V, num_bases=9)
@@ -95,7 +95,7 @@ def test_streamed_flags_and_hooks(pm):
     for _ in range(2):
         m.update_w(); o.update_w()
         m.update_h(); o.update_h()
-    assert rel_fro(m.W, o.W, what="m.W") < 2e-5 and rel_fro(m.H, o.H, what="m.H") < 2e-5
+    assert rel_fro(m.W, o.W, what="m.W") < 7e-7 and rel_fro(m.H, o.H, what="m.H") < 3e-7
     assert abs(m.frobenius_norm() - o.frobenius_norm()) <= 1e-5 * o.frobenius_norm()
 
 
@@ -108,7 +108,7 @@ def test_streamed_early_exit_on_exact_data(pm):
     mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
     mdl.factorize(niter=int(g["niter"]), compute_w=False)
     assert len(mdl.ferr) == len(g["ferr"]) == 2
-    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-5
+    assert rel_fro(mdl.H, g["H"], what="mdl.H") < 3e-9
 
 
 def test_stream_c_abi_contract(pm):
@@ -153,8 +153,8 @@ def test_streamed_bnmf_vs_reference_golden(pm, name, rows):
     mdl.factorize(niter=int(g["niter"]))
     assert src.reads >= int(g["niter"]) * ((g["V"].shape[0] + rows - 1) // rows)
     assert len(mdl.ferr) == len(g["ferr"])
-    close(mdl.ferr, g["ferr"], rtol=2e-5, what="mdl.ferr")
-    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-5 and rel_fro(mdl.H, g["H"], what="mdl.H") < 5e-5
+    close(mdl.ferr, g["ferr"], rtol=3e-7, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-6 and rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-6
     res = pm.BNMF(g["V"], num_bases=int(g["k"]))
     res.W, res.H = g["W0"].copy(), g["H0"].copy()
     res.factorize(niter=int(g["niter"]))
@@ -178,7 +178,7 @@ def test_streamed_snmf_and_nmfals_vs_reference_golden(pm, cls_name, name, rows):
     assert len(mdl.ferr) == len(g["ferr"])
     tol = 5e-5 if cls_name == "SNMF" else 2e-4
     assert rel_fro(mdl.W, g["W"], what="mdl.W") < tol and rel_fro(mdl.H, g["H"], what="mdl.H") < tol
-    close(mdl.ferr, g["ferr"], rtol=1e-4, what="mdl.ferr")
+    close(mdl.ferr, g["ferr"], rtol=5e-7, what="mdl.ferr")
     # and the streamed object equals the resident one on the same inputs
     res = getattr(pm, cls_name)(g["V"], num_bases=int(g["k"]))
     res.W, res.H = g["W0"].copy(), g["H0"].copy()
