@@ -172,7 +172,8 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *   "snmf_gram"  SNMF loops with both updates on iterate in Gram space -- P = M^T (V^T V), S = P M on
  *                k x n sized data, W materialised once after the last iteration -- instead of one pass
  *                over V per iteration: -1 automatic (default: CSR data always, dense data from about
- *                n / 2k iterations on), 0 never, 1 whenever the shape allows (n <= 1024). */
+ *                n / 2k iterations on), 0 never, 1 whenever the shape allows (n <= 1024), 2 as 1 but W = V M is
+ *                written in EVERY iteration (what the reference's update_w does; same results). */
 int pmf_set_option(pmf_ctx* ctx, const char* name, int64_t value);
 
 /* Host transport for the cross-rank sums, for set-ups in which the ranks cannot form an RCCL communicator

@@ -74,7 +74,7 @@ struct pmf_ctx {
   double *dC = nullptr, *dMTd = nullptr, *dPd = nullptr;
   std::vector<double> hC;       // CSR data: this rank's V^T V, formed on the host by pmf_set_v_csr_f32
   bool c_valid = false;         // dC holds the all-rank V^T V of the current V
-  int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible
+  int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible, 2 = 1 + W written in every iteration
   bool w_implicit = false;      // the loop ran in Gram space: dW is stale, W = V M with the M at hand (materialize_w)
   float* dD = nullptr;          // RNMF: D = S - V (rnmf.py:102,111), [mp][np]
   bool s_valid = false;         // RNMF: D has been formed (update_s ran)
@@ -865,7 +865,7 @@ bool snmf_gram_ok(const pmf_ctx* c, int niter) {
   if (c->algo != PMF_ALGO_SNMF || c->nb > 1 || c->np > PMF_GRAM_MAX_NP) return false;
   if (c->opt_snmf_gram == 0) return false;
   if (c->v_csr) return c->hC.size() == (size_t)c->np * c->np;
-  return c->opt_snmf_gram == 1 || c->c_valid || (int64_t)2 * c->k * niter >= c->n;
+  return c->opt_snmf_gram >= 1 || c->c_valid || (int64_t)2 * c->k * niter >= c->n;
 }
 
 int snmf_gram_iteration(pmf_ctx* c) {
@@ -892,6 +892,8 @@ int snmf_gram_iteration(pmf_ctx* c) {
   HIPCHK(c, hipGetLastError());
   c->w_implicit = true;       // dW is stale from here on: W = V M with the M just formed
   c->ps_valid = true;         // (P | S) of that W, all ranks (C is all-reduced)
+  if (c->opt_snmf_gram == 2) PMFCHK(materialize_w(c));   // W rewritten in every iteration, as the reference's update_w does
+  c->ps_valid = true;
   return h_step_from_ps(c);
 }
 
@@ -2004,7 +2006,7 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2) {
 int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return PMF_EINVAL;
   if (std::strcmp(name, "snmf_gram") == 0) {
-    if (value < -1 || value > 1) return fail(c, PMF_EINVAL, "snmf_gram: -1 (auto), 0 (off) or 1 (on)");
+    if (value < -1 || value > 2) return fail(c, PMF_EINVAL, "snmf_gram: -1 (auto), 0 (off), 1 (on) or 2 (on, W written every iteration)");
     c->opt_snmf_gram = (int)value;
     return PMF_OK;
   }

@@ -840,7 +840,7 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
     W0 = rs.random_sample((shape[0], k)).astype(np.float32)
     H0 = (rs.random_sample((k, shape[1])) + 0.1).astype(np.float32)
     outs = []
-    for gram in (1, 0):
+    for gram in (1, 0, 2):             # Gram space / one pass over V per iteration / Gram space + W written every iteration
         c = _lib.Context(_lib.ALGO_SNMF, shape[0], shape[1], k)
         if sparse:
             c.set_v_csr(Vs.indptr, Vs.indices, Vs.data)
@@ -865,6 +865,8 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
     assert rel_fro(outs[0][1], outs[1][1], what="gram H vs pass-per-iteration H") < tol
     assert rel_fro(outs[0][3], outs[1][3], what="W after the hooks that follow") < (tol if ill else 5e-5)
     assert rel_fro(outs[0][4], outs[1][4], what="H after the hooks that follow") < tol
+    np.testing.assert_array_equal(outs[0][0], outs[2][0])        # option 2 only writes W more often: same bits
+    np.testing.assert_array_equal(outs[0][1], outs[2][1])
     if not sparse:
         close(outs[0][2], o.ferr, rtol=2e-8, what="gram ferr vs oracle")
 
