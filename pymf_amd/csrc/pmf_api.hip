@@ -26,7 +26,7 @@
 #include "pmf_small.h"
 #include "pmf_tiled.h"
 #include "pmf_fused.h"
-#include "pmf_fused8.h"
+#include "pmf_coop.h"
 #include "pmf_nnls.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
@@ -93,7 +93,8 @@ struct pmf_ctx {
   bool v_csr = false;
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
-  bool fused8 = false;          // ... and it is the cooperative 64 < k <= 128 form (pmf_fused8.h)
+  bool fused8 = false;          // ... and it is the cooperative form (pmf_coop.h: 64 < k <= 128, or k <= 64 with n > 256)
+  int coop_bt = 0, coop_rb = 0; // its base tiles per wave / row blocks per tile
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
   int g_parts = 0;              // > 0 (with g_valid): G = sum of that many partials in dGpart, dG is stale
   int trace_parts = 0;          // > 0 (with trace_ready): the trace terms are that many pairs in dT1part
@@ -719,17 +720,17 @@ int nmf_fused_pass(pmf_ctx* c) {
   else PMFCHK(ensure_gram(c, 0.0));
   const bool rn = c->algo == PMF_ALGO_RNMF;     // rnmf.py:100-115: both contractions run on D = S - data
   if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
-  if (c->fused8) {               // 64 < num_bases <= 128: the cooperative form (pmf_fused8.h)
+  if (c->fused8) {               // the cooperative form (pmf_coop.h)
     stat_begin(c, SITE_FUSED);
-    const int lrc8 = launch_fused8(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->np,
-                                   rn ? c->dD : c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab,
-                                   c->stop_arg);
+    const int lrc8 = launch_coop(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT, c->np,
+                                 rn ? c->dD : c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab,
+                                 c->stop_arg);
     stat_end(c, SITE_FUSED);
-    if (lrc8 != PMF_OK) return fail(c, lrc8, "fused (k <= 128) kernel launch failed");
+    if (lrc8 != PMF_OK) return fail(c, lrc8, "cooperative one-pass kernel launch failed");
     HIPCHK(c, hipGetLastError());
-    const int NTP8 = c->np / 16;
-    hipLaunchKernelGGL(k_reduce_slabs_tiles8, dim3((unsigned)(8 * NTP8 + 64)), dim3(1024), 0, c->stream, c->dSlab, c->fused_wgs,
-                       NTP8, c->np, c->dPS, c->stop_arg);
+    const int NTP8 = c->np / 16, KT8 = c->KP / 16;
+    hipLaunchKernelGGL(k_reduce_slabs_coop, dim3((unsigned)(4 * c->coop_bt * (NTP8 + KT8))), dim3(1024), 0, c->stream, c->dSlab,
+                       c->fused_wgs, c->coop_bt, NTP8, c->np, c->dPS, c->stop_arg);
     HIPCHK(c, hipGetLastError());
     PMFCHK(allreduce_ps(c));
     c->ps_valid = true;
@@ -1298,6 +1299,11 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   }
   // 448 columns are not a panel count the wide (two waves per block) fused kernel takes: pad to 512
   if ((algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF) && c->NT <= 2 && c->np == 448) c->np = 512;
+  // ... and the cooperative kernel (pmf_coop.h) takes 6, 8, 12 or 16 column panels beyond 4
+  if ((algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF) && c->nb == 1 && k <= 128) {
+    const int padded = coop_pad_np(c->NT, c->np);
+    if (padded > 0) c->np = padded;
+  }
   int rc = [&]() -> int {
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1317,10 +1323,14 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
     c->fused_wgs = (c->nb == 1 && (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF))
                        ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
-    if (c->fused_wgs == 0 && c->nb == 1 && fused8_shape_ok(c->NT, c->np) &&
-        (algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF)) {
-      c->fused8 = true;
-      c->fused_wgs = fused8_grid_for(c->mp);
+    {
+      int bt = 0, rb = 0, pn = 0;
+      if (c->fused_wgs == 0 && c->nb == 1 && coop_shape(c->NT, c->np, &bt, &rb, &pn) &&
+          (algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF || (algo == PMF_ALGO_RNMF && bt == 2 && rb == 4))) {
+        c->fused8 = true;
+        c->coop_bt = bt; c->coop_rb = rb;
+        c->fused_wgs = coop_grid_for(c->mp, rb);
+      }
     }
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
     // dV [mp][np] is allocated by the first pmf_set_v_dense_f32 / pmf_fill_v_uniform: CSR and
@@ -1364,7 +1374,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   }
   if (c->fused8) {
     char nb_[64];
-    snprintf(nb_, sizeof(nb_), "k_nmf_fused8<%d%s>", c->np / 64, algo == PMF_ALGO_BNMF ? ",bnmf" : algo == PMF_ALGO_RNMF ? ",rnmf" : "");
+    snprintf(nb_, sizeof(nb_), "k_nmf_coop<%d,%d,%d%s>", c->coop_bt, c->coop_rb, c->np / 64,
+             algo == PMF_ALGO_BNMF ? ",bnmf" : algo == PMF_ALGO_RNMF ? ",rnmf" : "");
     c->path = nb_;
   } else
   c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF   ? FUSED_SNMF

@@ -562,7 +562,7 @@ def test_results_are_reproducible_bit_for_bit(pm, shape, k):
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
 
 
-@pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 300), 128), ("NMF", (2000, 700), 40), ("BNMF", (2500, 300), 100),
+@pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 400), 128), ("NMF", (2000, 700), 40), ("BNMF", (2500, 450), 100),
                                               ("SNMF", (3000, 400), 100), ("NMF", (1500, 1100), 20)])
 def test_tiled_kernels_vs_oracle(pm, cls_name, shape, k):
     """Shapes the one-pass kernel does not take (k > 64, or wider than its LDS budget) run on the
@@ -994,10 +994,12 @@ def test_full_size_properties_cfg5(pm):
 
 
 
-# ---- 64 < num_bases <= 128: the cooperative one-pass kernel (pmf_fused8.h) ---------------------------
+# ---- the cooperative one-pass kernel (pmf_coop.h): 64 < num_bases <= 128 with n <= 384, num_bases <= 64 with 256 < n <= 512 ----
 @pytest.mark.parametrize("cls_name,shape,k", [("NMF", (3000, 256), 128), ("NMF", (777, 200), 100), ("NMF", (64, 64), 65),
                                               ("BNMF", (5000, 128), 128), ("NMF", (130, 256), 70), ("NMF", (300, 190), 128),
-                                              ("BNMF", (2500, 200), 100), ("NMF", (20000, 256), 96)])
+                                              ("BNMF", (2500, 200), 100), ("NMF", (20000, 256), 96),
+                                              ("NMF", (1000, 330), 100), ("BNMF", (900, 384), 128), ("NMF", (1500, 384), 64),
+                                              ("NMF", (800, 500), 33), ("BNMF", (4000, 512), 64), ("NMF", (70, 300), 50)])
 def test_fused8_vs_oracle(pm, cls_name, shape, k):
     import oracle
     rs = np.random.RandomState(shape[0] + k)
@@ -1008,7 +1010,7 @@ def test_fused8_vs_oracle(pm, cls_name, shape, k):
     mdl = getattr(pm, cls_name)(V, num_bases=k)
     mdl.W, mdl.H = W0.copy(), H0.copy()
     mdl.factorize(niter=5)
-    assert mdl._ctx.path_name.startswith("k_nmf_fused8<")
+    assert mdl._ctx.path_name.startswith("k_nmf_coop<")
     o = getattr(oracle, cls_name + "Oracle")(V, num_bases=k)
     o.W, o.H = W0.copy(), H0.copy()
     o.factorize(niter=5)
@@ -1032,7 +1034,7 @@ def test_fused8_rnmf_free_run_and_reproducibility(pm):
     np.random.seed(5)
     mdl = RNMF(V, num_bases=96, lamb=1.0)
     mdl.factorize(niter=3)
-    assert mdl._ctx.path_name == "k_nmf_fused8<4,rnmf>"
+    assert mdl._ctx.path_name == "k_nmf_coop<2,4,4,rnmf>"
     np.random.seed(5)
     o = RNMFOracle(V, num_bases=96, lamb=1.0)
     o.factorize(niter=3)

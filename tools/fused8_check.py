@@ -5,7 +5,7 @@ import pymf_amd
 from pymf_amd import _lib
 from oracle import NMFOracle, BNMFOracle
 def rel(a,b): return np.linalg.norm(np.asarray(a,np.float64)-b)/np.linalg.norm(b)
-for (m,n,k) in ((3000,256,128),(777,200,100),(64,64,65),(5000,128,128),(130,256,70)):
+for (m,n,k) in ((3000,256,128),(777,200,100),(64,64,65),(5000,128,128),(130,256,70),(1000,330,100),(1500,384,64),(800,500,33),(4000,512,64),(70,300,50)):
     rs=np.random.RandomState(m+k); V=rs.random_sample((m,n)).astype(np.float32)
     W0,H0=rs.random_sample((m,k)),rs.random_sample((k,n))
     a=pymf_amd.NMF(V,num_bases=k); a.W,a.H=W0.copy(),H0.copy(); a.factorize(niter=4)

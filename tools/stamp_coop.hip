@@ -2,7 +2,7 @@
 #define PMF_STAMPS
 #define PMF_FUSED_KERNEL_ONLY
 #include <algorithm>
-#include "/root/repo/pymf_amd/csrc/pmf_fused8.h"
+#include "/root/repo/pymf_amd/csrc/pmf_coop.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -15,13 +15,13 @@ int main(int argc, char** argv){
   CK(hipMalloc(&slab,(size_t)wgs*KP*(NP+KP)*4)); CK(hipMalloc(&dbg,wgs*4*9*8));
   fillk<<<(mp*NP+255)/256,256>>>(V,mp*NP,1); fillk<<<(mp*KP+255)/256,256>>>(W,mp*KP,2);
   fillk<<<(KP*NP+255)/256,256>>>(H,KP*NP,3); fillk<<<(KP*KP+255)/256,256>>>(G,KP*KP,4);
-  size_t smem=fused8_smem_bytes<4>();
-  CK(hipFuncSetAttribute((const void*)&k_nmf_fused8<4,0>, hipFuncAttributeMaxDynamicSharedMemorySize,(int)smem));
+  size_t smem=coop_smem_bytes<2,4,4>();
+  CK(hipFuncSetAttribute((const void*)&k_nmf_coop<2,4,4,0>, hipFuncAttributeMaxDynamicSharedMemorySize,(int)smem));
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int ntiles=(int)(mp/64);
   for(int it=0; it<4; ++it){
     hipEventRecord(e0);
-    k_nmf_fused8<4,0><<<wgs,256,smem>>>(V,W,H,G,ntiles/wgs,ntiles%wgs,0.f,slab,nullptr,dbg);
+    k_nmf_coop<2,4,4,0><<<wgs,256,smem>>>(V,W,H,G,ntiles/wgs,ntiles%wgs,0.f,slab,nullptr,dbg);
     hipEventRecord(e1); CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms,e0,e1);
     std::vector<unsigned long long> h(wgs*4*9); CK(hipMemcpy(h.data(),dbg,h.size()*8,hipMemcpyDeviceToHost));
