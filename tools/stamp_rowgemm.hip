@@ -19,7 +19,7 @@ int main(){
   for (int it=0; it<3; ++it){
     unsigned long long z[4]={0,0,0,0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_rg_acc), z, sizeof(z)));
     hipEventRecord(e0);
-    k_rowgemm<NT,EPI_NMF_W><<<(unsigned)(mp/64/8),256,smem>>>(V,(int64_t)NP,NP,H,(int64_t)NP,W,G,nullptr,0.f,mp,KP,(int)(mp/64),8);
+    k_rowgemm<NT,EPI_NMF_W><<<(unsigned)(mp/64/8),256,smem>>>(V,(int64_t)NP,NP,H,(int64_t)NP,W,G,nullptr,(int64_t)KP,0.f,mp,KP,(int)(mp/64),8);
     hipEventRecord(e1); CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms,e0,e1);
     CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rg_acc), sizeof(z)));
