@@ -72,7 +72,6 @@ struct pmf_ctx {
   double* dGinvD = nullptr;     // SNMF: inv(H H^T) in float64, [KP][KP]
   // Gram-space SNMF loop (snmf_gram_iteration): C = V^T V over all ranks' rows, and the float64 M^T, P
   double *dC = nullptr, *dMTd = nullptr, *dPd = nullptr;
-  std::vector<double> hC;       // CSR data: this rank's V^T V, formed on the host by pmf_set_v_csr_f32
   bool c_valid = false;         // dC holds the all-rank V^T V of the current V
   int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible, 2 = 1 + W written in every iteration
   bool w_implicit = false;      // the loop ran in Gram space: dW is stale, W = V M with the M at hand (materialize_w)
@@ -831,18 +830,33 @@ int snmf_fused_iteration(pmf_ctx* c) {
 // trace identity (same P, S).  W is materialised once, after the last iteration (W = V M with the M of
 // that iteration: exactly the W the reference holds then).  No per-iteration pass over V or W, no
 // per-iteration collective; results agree with the pass-per-iteration form to rounding (P, S now come
-// out of float64 arithmetic).  CSR data: C is formed on the host while the arrays are uploaded.
+// out of float64 arithmetic).  CSR data: C by k_csr_gram (pmf_csr.h), dense data: gram_vtv.
 int ensure_vgram(pmf_ctx* c) {
   if (c->c_valid) return PMF_OK;
   const int np = c->np;
   if (!c->dC) PMFCHK(dalloc(c, &c->dC, (size_t)np * np));
   if (!c->dMTd) PMFCHK(dalloc(c, &c->dMTd, (size_t)c->KP * np));
   if (!c->dPd) PMFCHK(dalloc(c, &c->dPd, (size_t)c->KP * np));
-  if (c->v_csr) {
-    if (c->hC.size() != (size_t)np * np) return fail(c, PMF_EINVAL, "CSR Gram matrix missing");
-    HIPCHK(c, hipMemcpyAsync(c->dC, c->hC.data(), c->hC.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    PMFCHK(allreduce_sum(c, c->dC, (size_t)np * np, true));
+  if (c->v_csr) {                 // k_csr_gram: per-workgroup images of C, added up in fixed order
+    DevTemps tmp;
+    const size_t E = (size_t)np * np;
+    const int use_lds = E * sizeof(double) <= 128 * 1024;
+    const int wgs = use_lds ? 256 : 32;            // global images are E doubles each: fewer of them
+    double* slabs = nullptr;
+    PMFCHK(talloc(c, tmp, &slabs, (size_t)wgs * E));   // zeroed
+    static bool attr_done_dev[PMF_MAX_DEVICES] = {};
+    bool& attr_done = attr_done_dev[pmf_current_device()];
+    if (!attr_done) {
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_gram), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_csr_gram, dim3((unsigned)wgs), dim3(256), use_lds ? E * sizeof(double) : 0, c->stream, c->dIndptr,
+                       c->dIndices, c->dVals, c->m, np, slabs, use_lds);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, slabs, wgs, (int64_t)E, c->dC);
+    HIPCHK(c, hipGetLastError());
+    PMFCHK(allreduce_sum(c, c->dC, E, true));
+    HIPCHK(c, hipStreamSynchronize(c->stream));    // the scratch is freed on return
   } else {
     DevTemps tmp;
     const int64_t blocks16 = c->mp / 16;
@@ -865,7 +879,7 @@ constexpr int PMF_GRAM_MAX_NP = 1024;   // C is np x np float64 (8 MiB at the li
 bool snmf_gram_ok(const pmf_ctx* c, int niter) {
   if (c->algo != PMF_ALGO_SNMF || c->nb > 1 || c->np > PMF_GRAM_MAX_NP) return false;
   if (c->opt_snmf_gram == 0) return false;
-  if (c->v_csr) return c->hC.size() == (size_t)c->np * c->np;
+  if (c->v_csr) return true;
   return c->opt_snmf_gram >= 1 || c->c_valid || (int64_t)2 * c->k * niter >= c->n;
 }
 
@@ -1445,20 +1459,7 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false;
-  // this rank's V^T V for the Gram-space loop, float64 on the host (sum over a row's pairs of entries,
-  // duplicates included: (a + b)^2 = aa + ab + ba + bb, the semantics of V.toarray())
-  c->c_valid = false;
-  c->hC.clear();
-  if (c->np <= PMF_GRAM_MAX_NP) {
-    const size_t np = (size_t)c->np;
-    c->hC.assign(np * np, 0.0);
-    for (int64_t r = 0; r < c->m; ++r)
-      for (int64_t e1 = indptr[r]; e1 < indptr[r + 1]; ++e1) {
-        double* crow = c->hC.data() + (size_t)indices[e1] * np;
-        const double v1 = (double)vals[e1];
-        for (int64_t e2 = indptr[r]; e2 < indptr[r + 1]; ++e2) crow[indices[e2]] += v1 * (double)vals[e2];
-      }
-  }
+  c->c_valid = false;            // V^T V for the Gram-space loop is formed on first use (k_csr_gram)
   return PMF_OK;
 }
 

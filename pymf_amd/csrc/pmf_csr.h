@@ -8,6 +8,52 @@
 #pragma once
 #include "pmf_dev.h"
 
+// C = V^T V (np x np, float64) of CSR data, for the Gram-space SNMF loop: a row with c entries adds its
+// c^2 products v_a v_b to C[col_a][col_b] (duplicates included: (a + b)^2 = aa + ab + ba + bb, the semantics
+// of V.toarray()).  One wave per row at a time, lanes <-> pairs of entries; every workgroup accumulates its
+// rows into a private image of C -- in LDS when it fits (np <= 128: float64 LDS atomics), else directly into
+// its slab in global memory (float64 global atomics) -- and k_csr_gram_sum adds the slabs in fixed order.
+// float32 products are exact in float64, so the only run-to-run freedom is the order of float64 additions
+// inside a workgroup (1e-16 relative).
+__global__ __launch_bounds__(256) void k_csr_gram(const int64_t* __restrict__ indptr,
+                                                  const int32_t* __restrict__ indices,
+                                                  const float* __restrict__ vals, int64_t rows, int np,
+                                                  double* __restrict__ slabs, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) double sC[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* img = use_lds ? sC : slabs + (size_t)blockIdx.x * np * np;
+  if (use_lds) {
+    for (int q = tid; q < np * np; q += 256) sC[q] = 0.0;
+    __syncthreads();
+  }
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  for (int64_t row = r0 + wv; row < r1; row += 4) {
+    const int64_t a = indptr[row], b = indptr[row + 1];
+    const int cnt = (int)(b - a);
+    for (int pq = lane; pq < cnt * cnt; pq += 64) {
+      const int e1 = pq / cnt, e2 = pq % cnt;
+      const double v = (double)vals[a + e1] * (double)vals[a + e2];
+      atomicAdd(&img[(size_t)indices[a + e1] * np + indices[a + e2]], v);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    double* out = slabs + (size_t)blockIdx.x * np * np;
+    for (int q = tid; q < np * np; q += 256) out[q] = sC[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_csr_gram_sum(const double* __restrict__ slabs, int nslabs, int64_t E,
+                                                      double* __restrict__ C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  double s = 0.0;
+  for (int q = 0; q < nslabs; ++q) s += slabs[(size_t)q * E + e];
+  C[e] = s;
+}
+
 // W = V M for CSR V, the write-bound form (the Gram-space SNMF loop materialises W with it, once per
 // factorize()).  A wave takes 16-row blocks: ONE load brings the block's 17 row pointers, one (or more)
 // its column/value run; then 64 / (KP / 4) rows are formed at a time, KP / 4 lanes per row with four
