@@ -1717,13 +1717,14 @@ int pmf_rnmf_update_s(pmf_ctx* c) {
 int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
   PMFCHK(need(c, true, false, false));
   if (c->algo != PMF_ALGO_RNMF || !c->s_valid || !S) return fail(c, PMF_EINVAL, "pmf_rnmf_get_s_f32: no S");
-  // S = D + V, formed row block by row block on the host from the two device images
-  std::vector<float> d((size_t)c->n), v((size_t)c->n);
-  std::vector<float> Dh((size_t)c->m * c->n), Vh((size_t)c->m * c->n);
-  PMFCHK(download_padded(c, Dh.data(), c->n, c->dD, c->np, c->m, c->n));
-  PMFCHK(download_padded(c, Vh.data(), c->n, c->dV, c->np, c->m, c->n));
-  for (size_t q = 0; q < Dh.size(); ++q) S[q] = Dh[q] + Vh[q];
-  return PMF_OK;
+  // S = D + V on the device (the state kept is D = S - data, rnmf.py:102,111), then one download
+  DevTemps tmp;
+  float* dS = nullptr;
+  PMFCHK(talloc(c, tmp, &dS, (size_t)c->mp * c->np));
+  const int64_t E = c->mp * c->np;
+  hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((E / 4 + 255) / 256)), dim3(256), 0, c->stream, c->dD, c->dV, E, dS);
+  HIPCHK(c, hipGetLastError());
+  return download_padded(c, S, c->n, dS, c->np, c->m, c->n);
 }
 
 // ---- streamed V: one pass = one reference iteration over row tiles handed in by the caller ------

@@ -473,6 +473,14 @@ __global__ __launch_bounds__(256) void k_dgemm_small(const double* __restrict__ 
   if (Cf) Cf[(int64_t)(r0 + ty) * ldcf + c0 + tx] = (float)s;
 }
 
+// out = a + b over count floats (count a multiple of 4): RNMF's S = D + V for pmf_rnmf_get_s_f32.
+__global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ a, const float* __restrict__ b, int64_t count,
+                                                 float* __restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (4 * q < count)
+    reinterpret_cast<f32x4*>(out)[q] = reinterpret_cast<const f32x4*>(a)[q] + reinterpret_cast<const f32x4*>(b)[q];
+}
+
 // Per-block float64 partials of sum(X^2) over a padded [rows][ld] buffer (padding is zero).
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ X, int64_t count,
                                                double* __restrict__ part) {
