@@ -401,7 +401,9 @@ int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
 int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: dense V only");
   if (c->nb > 1) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases <= 128");
-  if (c->n > 1024) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= 1024 (the Gram matrix is n x n; pass the transposed problem for wide data)");
+  if (c->n > PMF_NNDSVD_MAX_N)
+    return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= " + std::to_string(PMF_NNDSVD_MAX_N) +
+                " (the Gram matrix is n x n and its eigen-decomposition O(n^3); pass the transposed problem for wide data)");
   if (c->k > c->n) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases exceeds the number of columns");
   const int n = (int)c->n, np = c->np, KP = c->KP, ld = np;
   const int nj = n + (n & 1);
@@ -434,13 +436,18 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   // 2./3. eigen-decomposition, top-k selection
   {
     const int64_t items = (int64_t)(nj / 2) * (nj / 2) + (int64_t)(nj / 2) * nj;
-    const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, items / 4096));
+    // one 1024-thread workgroup per CU at most (cooperative launch: all must be co-resident)
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const int64_t max_wgs = nj > 1024 ? cus : 64;
+    const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(max_wgs, items / 4096));
     double *a_ = Ad, *b_ = Ad2, *q_ = QT, *e_ = evals;
     int ld_ = ld, nj_ = nj, sweeps_ = 40;
     int* done_ = info + 1;
     void* args[] = {&a_, &b_, &q_, &ld_, &nj_, &sweeps_, &e_, &done_};
-    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_jacobi_eigh), dim3(wgs), dim3(1024), args, 0,
-                                         c->stream));
+    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_jacobi_eigh), dim3(wgs), dim3(1024), args,
+                                         (unsigned)jacobi_smem_bytes(nj), c->stream));
   }
   hipLaunchKernelGGL(k_nndsvd_select, dim3(1), dim3(1024), 0, c->stream, evals, QT, ld, nj, n, c->k, KP, np, B, sv,
                      order, info);

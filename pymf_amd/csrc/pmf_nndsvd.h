@@ -28,16 +28,20 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ s
   Ad[(int64_t)(c0 + r) * ld + c] = s;
 }
 
-// Symmetric eigen-decomposition of the nj x nj (nj even, <= 1024) matrix A (leading dimension ld):
+// Symmetric eigen-decomposition of the nj x nj (nj even, <= PMF_NNDSVD_MAX_N) matrix A (leading dimension ld):
 // cyclic two-sided Jacobi in the round-robin parallel order, float64.  Every step rotates nj/2
 // disjoint (p, q) pairs at once: A <- J^T A J decomposes into independent 2 x 2 blocks
 // A[{p,q}][{p',q'}] <- J_pq^T (.) J_p'q', one block per thread (the upper triangle of blocks is
 // computed, the mirror image written, so A stays exactly symmetric), and QT <- J^T QT row pairs.
 // Cooperative launch: the blocks are spread over the whole grid, ONE grid barrier per step; every
-// workgroup derives the step's rotations redundantly into its LDS, so all take the same exit.
+// workgroup derives the step's rotations redundantly into its LDS (24 bytes per pair, dynamic:
+// jacobi_smem_bytes(nj)), so all take the same exit.
 // A ping-pongs between two buffers (step t reads A0/A1, writes the other), so a workgroup still
 // deriving its rotations never sees a block another workgroup has already rotated.
 // On return evals[j] holds the eigenvalues and row j of QT the eigenvector of evals[j].
+#define PMF_NNDSVD_MAX_N 4096
+static inline size_t jacobi_smem_bytes(int nj) { return (size_t)(nj / 2) * 24; }
+
 __global__ __launch_bounds__(1024) void k_jacobi_eigh(double* A0, double* A1, double* QT,
                                                       int ld, int nj, int max_sweeps,
                                                       double* __restrict__ evals,
@@ -45,13 +49,16 @@ __global__ __launch_bounds__(1024) void k_jacobi_eigh(double* A0, double* A1, do
   double* A = A0;       // current
   double* An = A1;      // next
   cooperative_groups::grid_group grid = cooperative_groups::this_grid();
-  __shared__ double sc[512], ss[512];
-  __shared__ int sp[512], sq[512];
+  extern __shared__ double jac_lds[];
   __shared__ int s_rot;
   __shared__ double s_trace;
   const int tid = threadIdx.x;
   const int gtid = blockIdx.x * 1024 + tid, gsize = gridDim.x * 1024;
   const int half = nj >> 1;
+  double* sc = jac_lds;
+  double* ss = sc + half;
+  int* sp = reinterpret_cast<int*>(ss + half);
+  int* sq = sp + half;
   for (int idx = gtid; idx < nj * nj; idx += gsize) {
     const int r = idx / nj, c = idx % nj;
     if (r < c) {
@@ -74,10 +81,10 @@ __global__ __launch_bounds__(1024) void k_jacobi_eigh(double* A0, double* A1, do
     if (tid == 0) s_rot = 0;
     __syncthreads();
     for (int t = 0; t < nj - 1; ++t) {
-      if (tid < half) {
+      for (int pr = tid; pr < half; pr += 1024) {
         int p, q;
-        if (tid == 0) { p = nj - 1; q = t; }
-        else { p = (t + tid) % (nj - 1); q = (t + nj - 1 - tid) % (nj - 1); }
+        if (pr == 0) { p = nj - 1; q = t; }
+        else { p = (t + pr) % (nj - 1); q = (t + nj - 1 - pr) % (nj - 1); }
         if (p > q) { const int x = p; p = q; q = x; }
         const double app = A[(int64_t)p * ld + p], aqq = A[(int64_t)q * ld + q], apq = A[(int64_t)p * ld + q];
         double c = 1.0, s = 0.0;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_eigh(double* A0, double* A1, do
           s = tt * c;
           if (fabs(apq) > conv) s_rot = 1;
         }
-        sc[tid] = c; ss[tid] = s; sp[tid] = p; sq[tid] = q;
+        sc[pr] = c; ss[pr] = s; sp[pr] = p; sq[pr] = q;
       }
       __syncthreads();
       for (int idx = gtid; idx < half * half; idx += gsize) {       // 2 x 2 blocks, pr <= pc
@@ -146,12 +153,24 @@ __global__ __launch_bounds__(1024) void k_nndsvd_select(const double* __restrict
   __shared__ double ssv[128];
   __shared__ int sord[128];
   const int tid = threadIdx.x;
-  const double mine = tid < nj ? evals[tid] : -1.0e300;
-  bool taken = tid >= nj;
+  constexpr int PER = PMF_NNDSVD_MAX_N / 1024;      // eigenvalues tid, tid + 1024, ... per thread
+  double mine[PER];
+  unsigned taken = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = tid + j * 1024;
+    mine[j] = e < nj ? evals[e] : -1.0e300;
+    if (e >= nj) taken |= 1u << j;
+  }
   int nfound = 0;
   for (int i = 0; i < k; ++i) {
-    sval[tid] = taken ? -1.0e300 : mine;
-    sidx[tid] = tid;
+    double best = -1.0e300;
+    int bidx = tid;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)                     // ascending index: ties keep the lowest
+      if (!((taken >> j) & 1u) && mine[j] > best) { best = mine[j]; bidx = tid + j * 1024; }
+    sval[tid] = best;
+    sidx[tid] = bidx;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
       if (tid < o) {
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(1024) void k_nndsvd_select(const double* __restrict
     }
     const int win = sidx[0];
     const double val = sval[0];
-    if (tid == win) taken = true;
+    if ((win & 1023) == tid) taken |= 1u << (win >> 10);
     const bool ok = val > 1e-8;
     if (ok) ++nfound;
     if (tid == 0) { sord[i] = win; ssv[i] = ok ? sqrt(val) : 0.0; }
@@ -239,34 +258,42 @@ __global__ __launch_bounds__(1024) void k_nndsvd_finalize(const double* __restri
   const int tid = threadIdx.x;
   for (int i = 0; i < KP; ++i) {
     if (i >= k) {
-      if (tid < np) H[(int64_t)i * np + tid] = 0.f;
+      for (int c = tid; c < np; c += 1024) H[(int64_t)i * np + c] = 0.f;
       if (tid == 0) { wscale[i] = 0.f; wmode[i] = 0; }
       continue;
     }
-    const double v = tid < n ? QT[(int64_t)order[i] * ld + tid] : 0.0;
-    double vp2 = v > 0.0 ? v * v : 0.0, vn2 = v < 0.0 ? v * v : 0.0;
+    const double* qrow = QT + (int64_t)order[i] * ld;
+    double vp2 = 0.0, vn2 = 0.0;
+    for (int c = tid; c < n; c += 1024) {
+      const double v = qrow[c];
+      if (v > 0.0) vp2 += v * v; else vn2 += v * v;
+    }
     block_sum2(vp2, vn2, sh);
     const double s = sv[i];
-    double h = 0.0, ws = 0.0;
+    double hp = 0.0, hn = 0.0, ws = 0.0;             // h = hp * max(v,0) + hn * max(-v,0)
     int mode = 0;
     if (i == 0) {
       ws = sqrt(s);
-      h = ws * fabs(v);
+      hp = hn = ws;                                  // sqrt(s_0) |v_0|
     } else {
       const double up = sqrt(norms[i]), un = sqrt(norms[KP + i]);
       const double vp = sqrt(vp2), vn = sqrt(vn2);
       const double a = up * vp, b = un * vn;
       if (a >= b) {
         mode = 1;
-        if (a > 0.0) { const double rs = sqrt(s * a); ws = rs / up; h = rs / vp * (v > 0.0 ? v : 0.0); }
+        if (a > 0.0) { const double rs = sqrt(s * a); ws = rs / up; hp = rs / vp; }
       } else {
         mode = -1;
         const double rs = sqrt(s * b);
         ws = rs / un;
-        h = rs / vn * (v < 0.0 ? -v : 0.0);
+        hn = rs / vn;
       }
     }
-    if (tid < np) H[(int64_t)i * np + tid] = tid < n ? (float)h : 0.f;
+    for (int c = tid; c < np; c += 1024) {
+      double h = 0.0;
+      if (c < n) { const double v = qrow[c]; h = v > 0.0 ? hp * v : hn * -v; }
+      H[(int64_t)i * np + c] = (float)h;
+    }
     if (tid == 0) { wscale[i] = (float)ws; wmode[i] = mode; }
   }
 }

@@ -9,7 +9,7 @@ the reference's per-basis second SVD; pymf_amd/csrc/pmf_nndsvd.h).
 The reference's SVD works on data^T data when rows > cols and on data data^T otherwise
 (svd.py:237-246).  The device routine takes the first form, so a wide matrix is passed transposed
 (W and H swap roles and are transposed back) -- the same switch, made on the host.  Limit of this
-build: min(rows, cols) <= 1024.
+build: min(rows, cols) <= 4096.
 """
 import logging
 

@@ -54,7 +54,10 @@ def test_nndsvd_then_nmf_matches_reference(pm):
 
 
 @pytest.mark.parametrize("shape,k", [((4096, 256), 64), ((700, 130), 17), ((129, 1000), 9), ((200, 64), 64), ((64, 64), 16),
-                                     ((5000, 3), 3), ((2, 2), 1)])
+                                     ((5000, 3), 3), ((2, 2), 1),
+                                     # min(m, n) > 1024 (svd.py:125-148 has no size limit): 750 and 1250 rotation
+                                     # pairs per Jacobi step, more than one per thread of a workgroup
+                                     ((3000, 1500), 12), ((1100, 2500), 8)])
 def test_nndsvd_vs_float64_oracle(pm, shape, k):
     from oracle import nndsvd_closed_form
     V = np.random.RandomState(sum(shape) + k).random_sample(shape).astype(np.float32)
