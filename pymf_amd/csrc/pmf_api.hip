@@ -90,6 +90,8 @@ struct pmf_ctx {
   // CSR V (SNMF sparse path)
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
   bool v_csr = false;
+  bool csr_dense = false;       // CSR data with num_bases > 128: a dense image in dV serves the data paths (no CSR kernel at that width)
+  double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
   bool fused8 = false;          // ... and it is the cooperative form (pmf_coop.h: 64 < k <= 128, or k <= 64 with n > 256)
@@ -171,6 +173,9 @@ int dalloc(pmf_ctx* c, T** p, size_t count) {
   return PMF_OK;
 }
 
+// CSR kernels serve the data paths (SNMF, num_bases <= 128); wider contexts keep a dense image of the CSR rows
+static inline bool use_csr(const pmf_ctx* c) { return c->v_csr && !c->csr_dense; }
+
 int ensure_dv(pmf_ctx* c) {
   if (c->dV) return PMF_OK;
   return dalloc(c, &c->dV, (size_t)c->mp * c->np);
@@ -223,6 +228,13 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
 template <int EPI>
 int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
             float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
+  if (c->nb > 1) {            // num_bases > 128: the plain product in blocks of 128 bases, C is [.][KP]
+    if (EPI != EPI_STORE) return fail(c, PMF_EINVAL, "rowgemm: only the plain product runs in base blocks");
+    for (int b = 0; b < c->nb; ++b)
+      PMFCHK((launch_rowgemm<8, EPI_STORE>(c, A, lda, kdimA, B + (size_t)b * 128 * ldb, ldb, nullptr, nullptr, C + b * 128,
+                                           rows_p, mvalid, c->KP)));
+    return PMF_OK;
+  }
   switch (c->NT) {
     case 1: return launch_rowgemm<1, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
     case 2: return launch_rowgemm<2, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
@@ -568,7 +580,7 @@ int nmf_update_w(pmf_ctx* c) {
   // price of the second half of the pass, (W^T V | W^T W) of the new W is already there when
   // update_h() follows (it then costs one k x n sized kernel) -- 0.65 ms for the pair at cfg4
   // instead of 1.12 ms as two tiled passes.
-  if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->fused_wgs > 0 && !c->fixed_h_loop && !c->v_csr)
+  if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->fused_wgs > 0 && !c->fixed_h_loop && !use_csr(c))
     return nmf_fused_pass(c);
   PMFCHK(ensure_gram(c, 0.0));
   if (c->algo == PMF_ALGO_RNMF) {
@@ -646,6 +658,11 @@ int launch_snmf_h(pmf_ctx* c) {
 }
 
 int snmf_h_step(pmf_ctx* c) {   // snmf.py:72-91 on MFMA, one workgroup per 64-column panel
+  if (c->nb > 1) {                // num_bases > 128: the generic column-block kernel
+    hipLaunchKernelGGL(k_nmf_h, dim3((unsigned)(c->np / 16)), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream, c->dH,
+                       (int64_t)c->np, c->np, c->KP, c->dPS, 3, 0.f, c->k, (int)c->n);
+    return PMF_OK;
+  }
   switch (c->NT) {
     case 1: return launch_snmf_h<1>(c);
     case 2: return launch_snmf_h<2>(c);
@@ -688,7 +705,7 @@ int h_step_from_ps(pmf_ctx* c) {
 
 int ps_tiled(pmf_ctx* c) {   // dPS = (W^T V | W^T W) over this rank's rows
   if (c->nb > 1) return bigk_ps(c);
-  if (c->v_csr) return csr_ps(c);
+  if (use_csr(c)) return csr_ps(c);
   PMFCHK(colgemm(c));
   return reduce_slabs(c, c->nchunks);
 }
@@ -774,16 +791,37 @@ int nmf_fused_iteration(pmf_ctx* c) {
 // ---- SNMF -----------------------------------------------------------------------------------
 // inv(H H^T) in float64 (Gauss-Jordan in registers, identity on the padding), then M^T = inv(H H^T) H in
 // float64, rounded once: dMT [KP][np] for the dense kernels, dW1 = M [np][KP] for the CSR kernels.
+int launch_inverse(pmf_ctx* c) {   // dGinvD = inv(dGd), float64
+  if (c->KP <= 64) {
+    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
+  } else if (c->KP <= 128) {
+    hipLaunchKernelGGL((k_inverse_spd<PMF_INV8_B, PMF_INV8_TG>), dim3(1), dim3(PMF_INV8_TG * PMF_INV8_TG), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
+  } else {                         // num_bases > 128: the matrix in L2, a cooperative grid (k_inverse_spd_big)
+    const size_t E = (size_t)c->KP * c->KP;
+    if (!c->dInvA) { PMFCHK(dalloc(c, &c->dInvA, E)); PMFCHK(dalloc(c, &c->dInvB, E)); }
+    // dGd stays intact (g_valid covers it): the elimination runs on a copy; a stopped free-running loop keeps dGinvD
+    HIPCHK(c, hipMemcpyAsync(c->dInvA, c->dGd, E * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, (int64_t)E / 4096));
+    double *a_ = c->dInvA, *b_ = c->dInvB, *o_ = c->dGinvD;
+    int kp_ = c->KP, k_ = c->k;
+    const int* stop_ = c->stop_arg;
+    void* args[] = {&a_, &b_, &kp_, &k_, &o_, &stop_};
+    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_inverse_spd_big), dim3(wgs), dim3(1024), args, 0,
+                                         c->stream));
+  }
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
 int snmf_inverse(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
-  if (c->KP <= 64)
-    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
-  else
-    hipLaunchKernelGGL((k_inverse_spd<PMF_INV8_B, PMF_INV8_TG>), dim3(1), dim3(PMF_INV8_TG * PMF_INV8_TG), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
-  HIPCHK(c, hipGetLastError());
+  PMFCHK(launch_inverse(c));
   hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
-                     (int64_t)c->np, c->np, c->KP, c->dGinvD, c->v_csr ? (float*)nullptr : c->dMT,
-                     c->v_csr ? c->dW1 : (float*)nullptr);
+                     (int64_t)c->np, c->np, c->KP, c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT,
+                     use_csr(c) ? c->dW1 : (float*)nullptr);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -791,9 +829,9 @@ int snmf_inverse(pmf_ctx* c) {
 int snmf_fused_pass(pmf_ctx* c);
 
 int snmf_update_w(pmf_ctx* c) {
-  if (c->fused_wgs > 0 && !c->v_csr) return snmf_fused_pass(c);   // as nmf_update_w: one pass, (P | S) kept for update_h
+  if (c->fused_wgs > 0 && !use_csr(c)) return snmf_fused_pass(c);   // as nmf_update_w: one pass, (P | S) kept for update_h
   PMFCHK(snmf_inverse(c));
-  if (c->v_csr) return csr_w(c);
+  if (use_csr(c)) return csr_w(c);
   return rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dMT, c->np, nullptr, nullptr, c->dW);   // W = V M^T
 }
 
@@ -844,7 +882,7 @@ int ensure_vgram(pmf_ctx* c) {
   if (!c->dC) PMFCHK(dalloc(c, &c->dC, (size_t)np * np));
   if (!c->dMTd) PMFCHK(dalloc(c, &c->dMTd, (size_t)c->KP * np));
   if (!c->dPd) PMFCHK(dalloc(c, &c->dPd, (size_t)c->KP * np));
-  if (c->v_csr) {                 // k_csr_gram: per-workgroup images of C, added up in fixed order
+  if (use_csr(c)) {                 // k_csr_gram: per-workgroup images of C, added up in fixed order
     DevTemps tmp;
     const size_t E = (size_t)np * np;
     const int use_lds = E * sizeof(double) <= 128 * 1024;
@@ -884,9 +922,9 @@ constexpr int PMF_GRAM_MAX_NP = 1024;   // C is np x np float64 (8 MiB at the li
 // Worth it?  CSR data: always (C costs a few ms on the host).  Dense data: forming C is 2 m n^2 flop, a
 // pass-per-iteration step 4 m n k: from about n / 2k iterations on (or when C is already there).
 bool snmf_gram_ok(const pmf_ctx* c, int niter) {
-  if (c->algo != PMF_ALGO_SNMF || c->nb > 1 || c->np > PMF_GRAM_MAX_NP) return false;
+  if (c->algo != PMF_ALGO_SNMF || c->np > PMF_GRAM_MAX_NP) return false;
   if (c->opt_snmf_gram == 0) return false;
-  if (c->v_csr) return true;
+  if (use_csr(c)) return true;
   return c->opt_snmf_gram >= 1 || c->c_valid || (int64_t)2 * c->k * niter >= c->n;
 }
 
@@ -896,13 +934,9 @@ int snmf_gram_iteration(pmf_ctx* c) {
   c->ps_valid = false;
   c->trace_ready = false;
   PMFCHK(ensure_gram(c, 1.0));
-  if (KP <= 64)
-    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
-  else
-    hipLaunchKernelGGL((k_inverse_spd<PMF_INV8_B, PMF_INV8_TG>), dim3(1), dim3(PMF_INV8_TG * PMF_INV8_TG), 0, c->stream, c->dGd, KP, c->k, (float*)nullptr, c->dGinvD);
-  HIPCHK(c, hipGetLastError());
+  PMFCHK(launch_inverse(c));
   hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dH, (int64_t)np, np, KP,
-                     c->dGinvD, c->v_csr ? (float*)nullptr : c->dMT, c->v_csr ? c->dW1 : (float*)nullptr, c->dMTd, c->stop_arg);
+                     c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? c->dW1 : (float*)nullptr, c->dMTd, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   // P = M^T C  (KP x np), float64 kept for S, float32 into (P | S)
   hipLaunchKernelGGL((k_dgemm_small<false>), dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dMTd,
@@ -925,7 +959,7 @@ int materialize_w(pmf_ctx* c) {
   c->w_implicit = false;
   stat_begin(c, SITE_MATERIALIZE);
   int rc = PMF_OK;
-  if (c->v_csr) {
+  if (use_csr(c)) {
     const bool keep_ps = c->ps_valid;
     rc = csr_w(c);
     c->ps_valid = keep_ps;
@@ -988,7 +1022,7 @@ bool csr_mfma(pmf_ctx* c, int wgs, int* rc) {
 
 bool csr_fused_ok(const pmf_ctx* c) {
   const size_t smem = ((size_t)2 * c->np * c->KP + 4 * 16 * c->KP) * sizeof(float);
-  return c->v_csr && smem <= 160 * 1024;
+  return use_csr(c) && smem <= 160 * 1024;
 }
 
 int snmf_csr_fused_iteration(pmf_ctx* c) {
@@ -1162,12 +1196,14 @@ int ensure_ps(pmf_ctx* c);
 
 int do_frobenius(pmf_ctx* c, double* out) {
   if (c->nb > 1) {            // num_bases > 128: the residual through the trace identity (no MFMA residual kernel at that width)
+    if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
     PMFCHK(ensure_ps(c));
     PMFCHK(ensure_vnorm(c));
     double e2 = 0.0;
     PMFCHK(trace_e2(c, &e2));
     if (e2 > 1e-3 * c->vnorm2) { *out = std::sqrt(e2); return PMF_OK; }
     // the identity cancels: direct pass (plain FMAs; num_bases > 128 has no MFMA residual kernel)
+    PMFCHK(materialize_w(c));
     const int gx = c->np / 64, gy = (int)(c->mp / 64);
     const int nb2 = gx * gy;
     DevTemps tmp;                       // frees `part` on every exit
@@ -1221,7 +1257,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
   char buf[96];
   if (c->algo == PMF_ALGO_SNMF && gram) {
     st.site = SITE_MATERIALIZE;                   // the only m-sized kernel of a Gram-space loop: W = V M, once
-    if (c->v_csr) {
+    if (use_csr(c)) {
       st.name = "k_csr_w_blocks(W = V M)";
       st.flops = st.exec_flops = 2.0 * nnz * k;
       st.bytes = 4.0 * m * k + 8.0 * nnz + 8.0 * (m + 1.0);      // W written once; CSR arrays read once
@@ -1231,7 +1267,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
       st.flops = st.exec_flops = 2.0 * m * n * k;
       st.bytes = 4.0 * (m * n + m * k);
     }
-  } else if (c->algo == PMF_ALGO_SNMF && c->v_csr) {
+  } else if (c->algo == PMF_ALGO_SNMF && use_csr(c)) {
     st.site = SITE_CSR_PASS;
     st.name = "k_snmf_csr_mfma (one pass per iteration)";
     st.flops = 4.0 * nnz * k + 4.0 * m * k * k;                  // SURVEY: SpMM, (.) inv, W^T V, W^T W
@@ -1299,8 +1335,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   *out = nullptr;
   if (algo < 0 || algo > 4) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF), 3 (BNMF) or 4 (RNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
-  if (k > 128 && algo != PMF_ALGO_NMF && algo != PMF_ALGO_BNMF)
-    return fail(nullptr, PMF_EINVAL, "num_bases > 128 is supported for NMF and BNMF only in this build");
+  if (k > 128 && algo == PMF_ALGO_RNMF)
+    return fail(nullptr, PMF_EINVAL, "RNMF: num_bases > 128 is not supported by this build");
   if (k > 1024) return fail(nullptr, PMF_EINVAL, "num_bases > 1024 is not supported by this build");
   if (algo == PMF_ALGO_NMFALS && k > 64)
     return fail(nullptr, PMF_EINVAL, "NMFALS: num_bases > 64 is not supported by this build");
@@ -1420,7 +1456,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);
@@ -1441,7 +1477,7 @@ int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(ensure_dv(c));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
-  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
+  c->have_v = true; c->v_csr = false; c->csr_dense = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
 }
@@ -1467,6 +1503,16 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false;
   c->c_valid = false;            // V^T V for the Gram-space loop is formed on first use (k_csr_gram)
+  c->csr_dense = false;
+  if (c->nb > 1) {               // num_bases > 128: no CSR kernel at that width -- the rows are expanded once
+    PMFCHK(ensure_dv(c));
+    HIPCHK(c, hipMemsetAsync(c->dV, 0, (size_t)c->mp * c->np * sizeof(float), c->stream));
+    hipLaunchKernelGGL(k_csr_densify, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,
+                       c->dVals, c->m, c->np, c->dV);
+    HIPCHK(c, hipGetLastError());
+    c->csr_dense = true;
+    PMFCHK(local_vnorm(c));
+  }
   return PMF_OK;
 }
 
@@ -1484,7 +1530,7 @@ int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(ensure_dv(c));
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
-  c->have_v = true; c->v_csr = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
+  c->have_v = true; c->v_csr = false; c->csr_dense = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
 }
@@ -1554,7 +1600,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   if (converged_at) *converged_at = -1;
   c->want_trace = ce;
   c->fixed_h_loop = cw && !ch && niter > 1 && c->algo == PMF_ALGO_NMF;
-  const bool fused = cw && ch && c->fused_wgs > 0 && !c->v_csr &&
+  const bool fused = cw && ch && c->fused_wgs > 0 && !use_csr(c) &&
                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_SNMF || c->algo == PMF_ALGO_BNMF ||
                       c->algo == PMF_ALGO_RNMF);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1566,14 +1612,14 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   // loop while the host reads back once per chunk instead of once per iteration.
   // ... and the fixed-basis loop (compute_w = False, nmf.py:56-65: coefficients for an existing basis):
   // (W^T V | W^T W) is formed once, every further iteration is the H-step kernel alone
-  const bool h_only = !cw && ch && ce && c->nb == 1 && !c->v_csr &&
+  const bool h_only = !cw && ch && ce && c->nb == 1 && !use_csr(c) &&
                       (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF);
   // (a host transport for the cross-rank sums blocks on the host every iteration: nothing to free-run)
   // SNMF with both updates on: the loop runs in Gram space (snmf_gram_iteration), W materialised at the end
   const bool gram = cw && ch && snmf_gram_ok(c, niter);
   if (gram) PMFCHK(ensure_vgram(c));
   choose_stat_site(c, gram);
-  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !c->v_csr)) && ce) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
+  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !use_csr(c) && c->nb == 1)) && ce) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 8;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182

@@ -556,3 +556,15 @@ __global__ __launch_bounds__(256, 1) void k_snmf_csr_mfma(const int64_t* __restr
       }
   }
 }
+
+// Dense image V[m][np] of the CSR rows (V zeroed beforehand): contexts with num_bases > 128 run the dense
+// kernels on it.  One thread per row, entries added in storage order (duplicates sum as scipy's toarray()).
+__global__ __launch_bounds__(256) void k_csr_densify(const int64_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ indices,
+                                                     const float* __restrict__ vals, int64_t m, int np,
+                                                     float* __restrict__ V) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= m) return;
+  float* row = V + r * np;
+  for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e) row[indices[e]] += vals[e];
+}

@@ -1,5 +1,6 @@
 // pmf_small.h -- the k x k / k x n sized kernels around the two big contractions.
 #pragma once
+#include <hip/hip_cooperative_groups.h>
 #include "pmf_dev.h"
 
 // G = H H^T (KP x KP, contraction over np columns), float64 accumulation.
@@ -37,6 +38,8 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
 // mode 1: BNMF rule (bnmf.py:79-82) H *= (P + 3 l H^2) / (S H + 2 l H^3 + l H + 1e-9).
 // mode 2: RNMF rule (rnmf.py:100-105) with P = W^T (S - data): H *= (|P| - P) / (2 (W^T W) H),
 //         no epsilon; kvalid / nvalid mask the zero padding (0/0 there).
+// mode 3: SNMF rule (snmf.py:72-91) for num_bases > 128 (k_snmf_h_mfma serves the rest):
+//         H *= sqrt((pos(P) + neg(S) H) / (neg(P) + pos(S) H + 1e-9)).
 __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ldh, int np, int KP,
                                                const float* __restrict__ PS, int bnmf, float lamb,
                                                int kvalid, int nvalid) {
@@ -49,10 +52,22 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
   __syncthreads();
   for (int kk = tid >> 4; kk < KP; kk += 16) {
     const float* srow = PS + (int64_t)kk * ldp + np;
-    float den = 0.f;
-    for (int j = 0; j < KP; ++j) den = fmaf(srow[j], hs[j * 16 + c], den);
     const float h = hs[kk * 16 + c];
     const float p = PS[(int64_t)kk * ldp + col];
+    if (bnmf == 3) {
+      float ap = 0.f, an = 0.f;
+      for (int j = 0; j < KP; ++j) {
+        const float ww = srow[j], hj = hs[j * 16 + c];
+        ap = fmaf((fabsf(ww) + ww) * 0.5f, hj, ap);              // snmf.py:73-74
+        an = fmaf((fabsf(ww) - ww) * 0.5f, hj, an);              // snmf.py:76-77
+      }
+      const float h1 = (fabsf(p) + p) * 0.5f + an;
+      const float h2 = (fabsf(p) - p) * 0.5f + ap + PMF_EPS_DEN;
+      H[(int64_t)kk * ldh + col] = h * sqrtf(h1 / h2);
+      continue;
+    }
+    float den = 0.f;
+    for (int j = 0; j < KP; ++j) den = fmaf(srow[j], hs[j * 16 + c], den);
     if (bnmf == 2) {
       const float r = h * ((fabsf(p) - p) / (2.0f * den));
       H[(int64_t)kk * ldh + col] = (kk < kvalid && col < nvalid) ? r : 0.f;
@@ -406,6 +421,40 @@ __global__ __launch_bounds__(TG * TG) void k_inverse_spd(const double* __restric
         if (Ginv64) Ginv64[(int64_t)r * ld + c] = (r < k && c < k) ? a[u][v] : (r == c ? 1.0 : 0.0);
       }
     }
+}
+
+// inv(G) for matrix orders beyond k_inverse_spd's register file (num_bases > 128): the same in-place
+// Gauss-Jordan without pivoting, float64, the matrix in global memory (L2) and spread over a cooperative
+// grid.  Step p maps every entry by
+//   a_rc - a_rp a_pc / a_pp  (r, c != p),   a_pc / a_pp  (row p),   -a_rp / a_pp  (column p),   1 / a_pp
+// from the state BEFORE the step, so the matrix ping-pongs between two buffers (A0 holds G on entry)
+// and ONE grid barrier per pivot is enough.  Identity padding (rows/cols >= k) is left alone: those
+// pivots are 1 with zero row and column.  The result ends in Ginv64.
+__global__ __launch_bounds__(1024) void k_inverse_spd_big(double* A0, double* A1, int KP, int k,
+                                                          double* __restrict__ Ginv64,
+                                                          const int* __restrict__ stop) {
+  if (stop != nullptr && *stop != 0) return;          // uniform over the grid: nobody reaches a barrier
+  cooperative_groups::grid_group grid = cooperative_groups::this_grid();
+  const int64_t gtid = (int64_t)blockIdx.x * 1024 + threadIdx.x, gsize = (int64_t)gridDim.x * 1024;
+  const int64_t E = (int64_t)KP * KP;
+  double* A = A0;
+  double* An = A1;
+  for (int p = 0; p < k; ++p) {
+    const double app = A[(int64_t)p * KP + p];
+    const double inv = 1.0 / app;
+    for (int64_t q = gtid; q < E; q += gsize) {
+      const int r = (int)(q / KP), c = (int)(q % KP);
+      const double arc = A[q];
+      double v;
+      if (r == p) v = (c == p) ? inv : arc * inv;
+      else if (c == p) v = -arc * inv;
+      else v = fma(-A[(int64_t)r * KP + p] * inv, A[(int64_t)p * KP + c], arc);
+      An[q] = v;
+    }
+    grid.sync();
+    { double* x = A; A = An; An = x; }
+  }
+  for (int64_t q = gtid; q < E; q += gsize) Ginv64[q] = A[q];
 }
 
 // SNMF W step, reassociated:  W = (V H^T) inv(H H^T) = V M^T  with  M^T = inv(H H^T) H  (k x n).
