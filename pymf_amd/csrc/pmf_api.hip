@@ -91,6 +91,7 @@ struct pmf_ctx {
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
   bool v_csr = false;
   bool csr_dense = false;       // CSR data with num_bases > 128: a dense image in dV serves the data paths (no CSR kernel at that width)
+  double* dQp = nullptr;        // k_nnqp_big (NMFALS, num_bases > 64): per-workgroup inverse images
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
@@ -412,7 +413,6 @@ int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
 
 int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: dense V only");
-  if (c->nb > 1) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases <= 128");
   if (c->n > PMF_NNDSVD_MAX_N)
     return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= " + std::to_string(PMF_NNDSVD_MAX_N) +
                 " (the Gram matrix is n x n and its eigen-decomposition O(n^3); pass the transposed problem for wide data)");
@@ -474,9 +474,10 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   // 4. U = V (v_i / s_i)  -> dW
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, np, np, B, np, nullptr, nullptr, c->dW));
   // 5. split norms over all ranks' rows, closed form
-  hipLaunchKernelGGL(k_split_norms, dim3((unsigned)nblk), dim3(256), 0, c->stream, c->dW, c->m, KP, rows_per_blk, part);
+  hipLaunchKernelGGL(k_split_norms, dim3((unsigned)nblk, (unsigned)((KP + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->m, KP,
+                     rows_per_blk, part);
   HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(256), 0, c->stream, part, nblk, KP, norms);
+  hipLaunchKernelGGL(k_split_sum, dim3((unsigned)((2 * KP + 255) / 256)), dim3(256), 0, c->stream, part, nblk, KP, norms);
   HIPCHK(c, hipGetLastError());
   PMFCHK(allreduce_sum(c, norms, (size_t)2 * KP, true));
   hipLaunchKernelGGL(k_nndsvd_finalize, dim3(1), dim3(1024), 0, c->stream, QT, ld, order, sv, norms, n, c->k, KP, np,
@@ -521,11 +522,35 @@ int launch_resid(pmf_ctx* c, bool rnmf, float lamb, const float* V = nullptr, co
   return fail(c, PMF_EINVAL, "bad NT");
 }
 
+// num_bases > 128: sum((V - W H)^2) over this rank's rows -> *dst (device), plain-FMA tiles; rnmf: D = S - V too
+int resid_bigk(pmf_ctx* c, bool rnmf, double* dst) {
+  const int gx = c->np / 64, gy = (int)(c->mp / 64);
+  const int nb2 = gx * gy;
+  DevTemps tmp;                       // frees `part` on every exit
+  double* part = nullptr;
+  PMFCHK(talloc(c, tmp, &part, (size_t)nb2));
+  if (rnmf)
+    hipLaunchKernelGGL(k_resid_bigk<true>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
+                       c->KP, c->dH, (int64_t)c->np, part, (float)c->lamb_w, c->dD);
+  else
+    hipLaunchKernelGGL(k_resid_bigk<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
+                       c->KP, c->dH, (int64_t)c->np, part, 0.f, (float*)nullptr);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, part, nb2, dst);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the scratch is freed on return
+  return PMF_OK;
+}
+
 int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2) in c->rnmf_err2
   const int nb = (int)(c->mp / 64);
   const float lamb = (float)c->lamb_w;
-  PMFCHK(launch_resid(c, true, lamb));
-  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 4);
+  if (c->nb > 1) {
+    PMFCHK(resid_bigk(c, true, c->dScal + 4));
+  } else {
+    PMFCHK(launch_resid(c, true, lamb));
+    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 4);
+  }
   HIPCHK(c, hipGetLastError());
   PMFCHK(allreduce_sum(c, c->dScal + 4, 1, true));
   HIPCHK(c, hipMemcpyAsync(&c->rnmf_err2, c->dScal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -540,15 +565,17 @@ int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2)
 // same kernel with W in the place of V.
 int bigk_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 0.0));
+  const bool rn = c->algo == PMF_ALGO_RNMF;      // rnmf.py:109-115: the contraction runs on D = S - data
+  if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
   for (int b = 0; b < c->nb; ++b)
-    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dV, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
+    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, rn ? c->dD : c->dV, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
                                          c->dW1 + b * 128, -1, -1, c->KP)));
   for (int b = 0; b < c->nb; ++b)
     PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dW, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
                                          c->dW2 + b * 128, -1, -1, c->KP)));
   const int64_t count = c->mp * c->KP;
   hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dW1, c->dW2, count,
-                     c->algo == PMF_ALGO_BNMF ? 1 : 0, (float)c->lamb_w);
+                     c->algo == PMF_ALGO_BNMF ? 1 : rn ? 2 : 0, (float)c->lamb_w, c->KP, c->m, c->k);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -557,7 +584,7 @@ int bigk_ps(pmf_ctx* c) {
   const int64_t ldp = (int64_t)c->np + c->KP;
   for (int b = 0; b < c->nb; ++b) {
     for (int pass = 0; pass < 2; ++pass) {                 // 0: W_b^T V -> P rows,  1: W_b^T W -> S rows
-      const float* X = pass == 0 ? c->dV : c->dW;
+      const float* X = pass == 0 ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : c->dW;
       const int xn = pass == 0 ? c->np : c->KP;
       dim3 grid((unsigned)c->nchunks, (unsigned)((xn + 255) / 256));
       hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, c->dW + b * 128, (int64_t)c->KP,
@@ -1065,8 +1092,25 @@ int snmf_update_h(pmf_ctx* c) {
 // ---- NMFALS ---------------------------------------------------------------------------------
 int nnqp_warm_flag(pmf_ctx* c) {   // dWarm[0] = 1 iff the QPs over the current dGd have unique minimisers
   if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
-  hipLaunchKernelGGL(k_spd_unique, dim3(1), dim3(64), 0, c->stream, c->dGd, c->KP, c->k, c->dWarm);
+  if (c->k <= 64) {
+    hipLaunchKernelGGL(k_spd_unique, dim3(1), dim3(64), 0, c->stream, c->dGd, c->KP, c->k, c->dWarm);
+  } else {
+    if (!c->dInvA) PMFCHK(dalloc(c, &c->dInvA, (size_t)c->KP * c->KP));
+    hipLaunchKernelGGL(k_spd_unique_big, dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dInvA, c->dWarm);
+  }
   HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+// num_bases > 64: k_nnqp_big keeps one inverse image per workgroup in global memory
+int nnqp_scratch(pmf_ctx* c, double** out) {
+  *out = nullptr;
+  if (c->k <= 64) return PMF_OK;
+  if (!c->dQp) {
+    const int64_t ks = 64 * nnqp_big_vpl(c->k);
+    PMFCHK(dalloc(c, &c->dQp, (size_t)(nnqp_big_blocks(c->k, std::max<int64_t>(c->m, c->n)) * ks * ks)));
+  }
+  *out = c->dQp;
   return PMF_OK;
 }
 
@@ -1075,8 +1119,10 @@ int als_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
   PMFCHK(nnqp_warm_flag(c));
+  double* qp = nullptr;
+  PMFCHK(nnqp_scratch(c, &qp));
   stat_begin(c, SITE_NNQP_W);
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, c->dWarm);
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, c->dWarm, qp);
   stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (W) failed");
   HIPCHK(c, hipGetLastError());
@@ -1092,7 +1138,9 @@ int als_update_h(pmf_ctx* c) {
   HIPCHK(c, hipGetLastError());
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
   PMFCHK(nnqp_warm_flag(c));
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, c->dWarm);
+  double* qp = nullptr;
+  PMFCHK(nnqp_scratch(c, &qp));
+  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, c->dWarm, qp);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
   HIPCHK(c, hipGetLastError());
   c->g_valid = false; c->num_valid = false;
@@ -1197,23 +1245,16 @@ int ensure_ps(pmf_ctx* c);
 int do_frobenius(pmf_ctx* c, double* out) {
   if (c->nb > 1) {            // num_bases > 128: the residual through the trace identity (no MFMA residual kernel at that width)
     if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
-    PMFCHK(ensure_ps(c));
-    PMFCHK(ensure_vnorm(c));
-    double e2 = 0.0;
-    PMFCHK(trace_e2(c, &e2));
-    if (e2 > 1e-3 * c->vnorm2) { *out = std::sqrt(e2); return PMF_OK; }
+    if (c->algo != PMF_ALGO_RNMF) {       // (RNMF's (P | S) are contractions with D = S - data, not with V)
+      PMFCHK(ensure_ps(c));
+      PMFCHK(ensure_vnorm(c));
+      double e2 = 0.0;
+      PMFCHK(trace_e2(c, &e2));
+      if (e2 > 1e-3 * c->vnorm2) { *out = std::sqrt(e2); return PMF_OK; }
+    }
     // the identity cancels: direct pass (plain FMAs; num_bases > 128 has no MFMA residual kernel)
     PMFCHK(materialize_w(c));
-    const int gx = c->np / 64, gy = (int)(c->mp / 64);
-    const int nb2 = gx * gy;
-    DevTemps tmp;                       // frees `part` on every exit
-    double* part = nullptr;
-    PMFCHK(talloc(c, tmp, &part, (size_t)nb2));
-    hipLaunchKernelGGL(k_resid_bigk, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
-                       c->KP, c->dH, (int64_t)c->np, part);
-    HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, part, nb2, c->dScal);
-    HIPCHK(c, hipGetLastError());
+    PMFCHK(resid_bigk(c, false, c->dScal));
     PMFCHK(allreduce_sum(c, c->dScal, 1, true));
     double ss = 0.0;
     HIPCHK(c, hipMemcpyAsync(&ss, c->dScal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1294,7 +1335,8 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
     }
   } else if (c->algo == PMF_ALGO_NMFALS) {
     st.site = SITE_NNQP_W;
-    snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
+    if (c->k <= 64) snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
+    else snprintf(buf, sizeof(buf), "k_nnqp_big<%d>(update_w)", nnqp_big_vpl(c->k));
     st.name = buf;
     st.bytes = 4.0 * (3.0 * m * k);               // right-hand sides read, warm start read, solution written
   } else if ((c->algo == PMF_ALGO_NMF) && c->nb == 1) {
@@ -1335,11 +1377,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   *out = nullptr;
   if (algo < 0 || algo > 4) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF), 3 (BNMF) or 4 (RNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
-  if (k > 128 && algo == PMF_ALGO_RNMF)
-    return fail(nullptr, PMF_EINVAL, "RNMF: num_bases > 128 is not supported by this build");
   if (k > 1024) return fail(nullptr, PMF_EINVAL, "num_bases > 1024 is not supported by this build");
-  if (algo == PMF_ALGO_NMFALS && k > 64)
-    return fail(nullptr, PMF_EINVAL, "NMFALS: num_bases > 64 is not supported by this build");
   if (n > (1 << 24)) return fail(nullptr, PMF_EINVAL, "n too large");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, PMF_EINVAL, "bad rank/nranks");
   if (nranks > 1 && !nccl_id) return fail(nullptr, PMF_EINVAL, "nccl_id required when nranks > 1");
@@ -1456,7 +1494,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);
@@ -1873,7 +1911,9 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       } else if (c->algo == PMF_ALGO_NMFALS) {  // nmfals.py:85-97: right-hand sides V H^T of the tile's rows, one QP per row
         float* Ft = c->dW1 + row0 * c->KP;
         PMFCHK(rowgemm<EPI_STORE>(c, T, c->np, c->np, c->dH, c->np, nullptr, nullptr, Ft, rows_p, rows));
-        const int qrc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm);
+        double* qp = nullptr;
+        PMFCHK(nnqp_scratch(c, &qp));
+        const int qrc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm, qp);
         if (qrc != PMF_OK) return fail(c, qrc, "nnqp launch (streamed W tile) failed");
         HIPCHK(c, hipGetLastError());
       } else {

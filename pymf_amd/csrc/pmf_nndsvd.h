@@ -150,8 +150,8 @@ __global__ __launch_bounds__(1024) void k_nndsvd_select(const double* __restrict
                                                         int* __restrict__ order, int* __restrict__ found) {
   __shared__ double sval[1024];
   __shared__ int sidx[1024];
-  __shared__ double ssv[128];
-  __shared__ int sord[128];
+  __shared__ double ssv[1024];
+  __shared__ int sord[1024];
   const int tid = threadIdx.x;
   constexpr int PER = PMF_NNDSVD_MAX_N / 1024;      // eigenvalues tid, tid + 1024, ... per thread
   double mine[PER];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_nndsvd_select(const double* __restrict
     __syncthreads();
   }
   if (tid == 0) found[0] = nfound;
-  if (tid < KP) { sv[tid] = tid < k ? ssv[tid] : 0.0; order[tid] = tid < k ? sord[tid] : 0; }
+  for (int i = tid; i < KP; i += 1024) { sv[i] = i < k ? ssv[i] : 0.0; order[i] = i < k ? sord[i] : 0; }
   for (int idx = tid; idx < KP * np; idx += 1024) {
     const int i = idx / np, c = idx % np;
     float b = 0.f;
@@ -199,28 +199,29 @@ __global__ __launch_bounds__(1024) void k_nndsvd_select(const double* __restrict
 }
 
 // part[blk][0][col] = sum of max(u,0)^2, part[blk][1][col] = sum of max(-u,0)^2 over the block's
-// rows of U ([.][KP], KP in {16,32,64,128}); float64.
+// rows of U ([.][KP], KP in {16,32,64} or a multiple of 128; blockIdx.y picks the group of 256 columns); float64.
 __global__ __launch_bounds__(256) void k_split_norms(const float* __restrict__ U, int64_t m, int KP,
                                                      int64_t rows_per_blk, double* __restrict__ part) {
   __shared__ double sh[2][256];
   const int tid = threadIdx.x;
-  const int col = tid % KP, rs = tid / KP, nrs = 256 / KP;
+  const int CW = KP < 256 ? KP : 256;
+  const int lc = tid % CW, col = blockIdx.y * CW + lc, rs = tid / CW, nrs = 256 / CW;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk;
   if (r1 > m) r1 = m;
   double p = 0.0, q = 0.0;
-  for (int64_t r = r0 + rs; r < r1; r += nrs) {
+  for (int64_t r = r0 + rs; r < r1 && col < KP; r += nrs) {
     const double u = (double)U[r * KP + col];
     if (u > 0.0) p += u * u; else q += u * u;
   }
   sh[0][tid] = p;
   sh[1][tid] = q;
   __syncthreads();
-  if (tid < KP) {
+  if (tid < CW && col < KP) {
     double a = 0.0, b = 0.0;
-    for (int j = 0; j < nrs; ++j) { a += sh[0][tid + j * KP]; b += sh[1][tid + j * KP]; }
-    part[((int64_t)blockIdx.x * 2 + 0) * KP + tid] = a;
-    part[((int64_t)blockIdx.x * 2 + 1) * KP + tid] = b;
+    for (int j = 0; j < nrs; ++j) { a += sh[0][tid + j * CW]; b += sh[1][tid + j * CW]; }
+    part[((int64_t)blockIdx.x * 2 + 0) * KP + col] = a;
+    part[((int64_t)blockIdx.x * 2 + 1) * KP + col] = b;
   }
 }
 

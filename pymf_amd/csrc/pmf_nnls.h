@@ -17,6 +17,7 @@
 // no cross-lane reductions except one arg-max, one sum and one min per outer iteration.
 // HA sits read-only in LDS; its symmetry makes every access a conflict-free row read.
 #pragma once
+#include <algorithm>
 #include "pmf_dev.h"
 #include "../../include/pymf_hip.h"
 
@@ -261,10 +262,319 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
   }
 }
 
+// ---- num_bases > 64: the same active-set method with the inverse in global memory --------------------
+// k_nnqp keeps row t of the passive block's inverse in lane t's registers, which ends at 64 variables.
+// Beyond that one wave still owns a problem, lane t holds variables t, t + 64, ... (VPL slots), and the
+// inverse A (symmetric, KS x KS, KS = 64 VPL) lives in a per-wave scratch image in global memory (L2/HBM),
+// addressed A[c * KS + v] so that a sweep over c reads consecutive v across the lanes.  Vectors that
+// every lane needs element by element (the border vector, f, x, a removed column) pass through one
+// KS-entry LDS buffer.  Only entries inside passive x passive are ever read, so nothing is zeroed
+// between problems.  Same pivoting rules, tolerances and tie-breaks as k_nnqp: the results agree
+// with it where both apply (k <= 64), and the minimiser is unique whenever HA is positive definite.
+// A generic path, not a fast one: every set change streams |P| * k doubles of A.
+__global__ __launch_bounds__(1024) void k_spd_unique_big(const double* __restrict__ Hd, int KP, int k,
+                                                         double* __restrict__ M /*[KP][KP] scratch*/,
+                                                         int* __restrict__ flag) {
+  __shared__ double d0[1024];
+  __shared__ double s_dmax;
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  for (int q = tid; q < KP * KP; q += 1024) M[q] = Hd[q];
+  for (int j = tid; j < k; j += 1024) d0[j] = Hd[(int64_t)j * KP + j];
+  if (tid == 0) s_ok = 1;
+  __syncthreads();
+  if (tid == 0) {
+    double dm = 0.0;
+    for (int j = 0; j < k; ++j) dm = fmax(dm, d0[j]);
+    s_dmax = dm;
+  }
+  __syncthreads();
+  const double dead = 1e-12 * s_dmax;
+  for (int j = 0; j < k; ++j) {
+    if (!(d0[j] > dead)) continue;                        // dead basis (uniform)
+    const double piv = M[(int64_t)j * KP + j];
+    if (!(piv > 1e-8 * d0[j])) { if (tid == 0) s_ok = 0; break; }
+    const int w = k - j;                                  // columns j .. k-1 of rows j+1 .. k-1
+    __syncthreads();                                      // everyone has read the pivot
+    for (int q = tid; q < (k - j - 1) * w; q += 1024) {
+      const int r = j + 1 + q / w, c = j + q % w;
+      if (!(d0[r] > dead)) continue;
+      const double l = M[(int64_t)r * KP + j] / piv;
+      // column j of row r is read by all of that row's threads and rewritten by one of them (c == j):
+      // it goes last, behind the barrier below
+      if (c != j) M[(int64_t)r * KP + c] = fma(-l, M[(int64_t)j * KP + c], M[(int64_t)r * KP + c]);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) flag[0] = s_ok;
+}
+
+template <int VPL>   // variables per lane: 2, 4, 8 or 16 (k <= 64 VPL)
+__global__ __launch_bounds__(64) void k_nnqp_big(const double* __restrict__ Hd, int KP, int k,
+                                                 const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
+                                                 float* __restrict__ X, int64_t x_sk, int64_t x_sp,
+                                                 int64_t nprob, const int* __restrict__ warm_flag,
+                                                 double* __restrict__ scratch) {
+  constexpr int KS = 64 * VPL;
+  __shared__ double vb[KS];
+  const bool warm = warm_flag != nullptr && *warm_flag != 0;
+  const int t = threadIdx.x;
+  double* __restrict__ A = scratch + (size_t)blockIdx.x * KS * KS;
+  bool act[VPL];
+  double hmax = 0.0;
+#pragma unroll
+  for (int s = 0; s < VPL; ++s) {
+    const int v = t + 64 * s;
+    act[s] = v < k;
+    if (act[s]) hmax = fmax(hmax, Hd[(int64_t)v * KP + v]);
+  }
+  hmax = wave_max_f64(hmax);
+  const double tol = 2.220446049250313e-15 * (double)k * hmax;
+  const unsigned long long tbit = 1ull << t;
+
+  for (int64_t prob = blockIdx.x; prob < nprob; prob += gridDim.x) {
+    double x[VPL], w[VPL], f[VPL];
+    unsigned long long pm[VPL], ban[VPL];
+#pragma unroll
+    for (int s = 0; s < VPL; ++s) {
+      f[s] = act[s] ? (double)F[(int64_t)(t + 64 * s) * f_sk + prob * f_sp] : 0.0;
+      x[s] = 0.0; w[s] = f[s]; pm[s] = 0ull; ban[s] = 0ull;
+    }
+
+    // acc[s] = sum over passive c of A[c][v] * coef(c), coef from the LDS vector or a row of HA
+    auto sweep_lds = [&](double (&acc)[VPL]) {
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) acc[s] = 0.0;
+#pragma unroll
+      for (int sc = 0; sc < VPL; ++sc) {
+        unsigned long long mb = pm[sc];
+        while (mb) {
+          const int c = 64 * sc + (int)__builtin_ctzll(mb);
+          mb &= mb - 1ull;
+          const double bc = vb[c];
+          const double* col = A + (size_t)c * KS + t;
+#pragma unroll
+          for (int s = 0; s < VPL; ++s) acc[s] = fma(col[64 * s], bc, acc[s]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) if (!(pm[s] & tbit)) acc[s] = 0.0;
+    };
+    auto put = [&](const double (&src)[VPL]) {               // vb[v] = src of variable v
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) vb[t + 64 * s] = src[s];
+      __syncthreads();
+    };
+
+    auto border = [&](int j, double rel_min) -> bool {
+      const double* __restrict__ hrow = Hd + (size_t)j * KP;   // HA[j][.] = HA[.][j]
+      double u[VPL];
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) u[s] = 0.0;
+#pragma unroll
+      for (int sc = 0; sc < VPL; ++sc) {
+        unsigned long long mb = pm[sc];
+        while (mb) {
+          const int c = 64 * sc + (int)__builtin_ctzll(mb);
+          mb &= mb - 1ull;
+          const double hc = hrow[c];
+          const double* col = A + (size_t)c * KS + t;
+#pragma unroll
+          for (int s = 0; s < VPL; ++s) u[s] = fma(col[64 * s], hc, u[s]);
+        }
+      }
+      double part = 0.0;
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) {
+        if (!(pm[s] & tbit)) u[s] = 0.0;
+        else part = fma(hrow[t + 64 * s], u[s], part);
+      }
+      const double hjj = hrow[j];
+      const double sig = hjj - wave_sum_f64(part);
+      if (!(sig > rel_min * hjj)) { ban[j >> 6] |= 1ull << (j & 63); return false; }
+      const double inv = pmf_rcp_f64(sig);
+      double vv[VPL];
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) vv[s] = (t + 64 * s == j) ? -1.0 : u[s];
+      put(vv);
+      pm[j >> 6] |= 1ull << (j & 63);
+#pragma unroll
+      for (int sc = 0; sc < VPL; ++sc) {
+        unsigned long long mb = pm[sc];
+        while (mb) {
+          const int c = 64 * sc + (int)__builtin_ctzll(mb);
+          mb &= mb - 1ull;
+          const double bc = vb[c];
+          double* col = A + (size_t)c * KS + t;
+#pragma unroll
+          for (int s = 0; s < VPL; ++s) {
+            if (!(pm[s] & tbit)) continue;
+            const bool fresh = (c == j) || (t + 64 * s == j);   // row / column j held nothing before
+            const double old = fresh ? 0.0 : col[64 * s];
+            col[64 * s] = fma(vv[s] * inv, bc, old);
+          }
+        }
+      }
+      return true;
+    };
+
+    auto inner = [&]() {
+      for (int it = 0; it < k + 2; ++it) {
+        put(f);
+        double sv[VPL];
+        sweep_lds(sv);
+        bool bad[VPL];
+        unsigned long long anybad = 0ull;
+#pragma unroll
+        for (int s = 0; s < VPL; ++s) {
+          bad[s] = (pm[s] & tbit) && !(sv[s] > 0.0);
+          anybad |= __ballot(bad[s]);
+        }
+        if (anybad == 0ull) {
+#pragma unroll
+          for (int s = 0; s < VPL; ++s) x[s] = sv[s];
+          break;
+        }
+        double ratio[VPL], rmin = 1.0e300;
+#pragma unroll
+        for (int s = 0; s < VPL; ++s) { ratio[s] = bad[s] ? x[s] / (x[s] - sv[s]) : 1.0e300; rmin = fmin(rmin, ratio[s]); }
+        double alpha = wave_min_f64(rmin);
+        if (!(alpha >= 0.0)) alpha = 0.0;
+        if (alpha > 1.0) alpha = 1.0;
+        double xm = 0.0;
+#pragma unroll
+        for (int s = 0; s < VPL; ++s) { x[s] = (pm[s] & tbit) ? fma(alpha, sv[s] - x[s], x[s]) : 0.0; xm = fmax(xm, x[s]); }
+        const double xmax = wave_max_f64(xm);
+        const double tiny = 1e-15 * fmax(1.0, xmax);
+        unsigned long long rm[VPL];
+#pragma unroll
+        for (int s = 0; s < VPL; ++s)
+          rm[s] = __ballot((pm[s] & tbit) && (x[s] <= tiny || (bad[s] && ratio[s] == alpha)));
+#pragma unroll
+        for (int sr = 0; sr < VPL; ++sr) {
+          while (rm[sr]) {
+            const int r = 64 * sr + (int)__builtin_ctzll(rm[sr]);
+            rm[sr] &= rm[sr] - 1ull;
+            double colr[VPL];                                  // inv[v][r] = inv[r][v]
+#pragma unroll
+            for (int s = 0; s < VPL; ++s) colr[s] = (pm[s] & tbit) ? A[(size_t)r * KS + t + 64 * s] : 0.0;
+            put(colr);
+            const double rarr = pmf_rcp_f64(vb[r]);
+            pm[r >> 6] &= ~(1ull << (r & 63));
+#pragma unroll
+            for (int sc = 0; sc < VPL; ++sc) {
+              unsigned long long mb = pm[sc];
+              while (mb) {
+                const int c = 64 * sc + (int)__builtin_ctzll(mb);
+                mb &= mb - 1ull;
+                const double arc = vb[c];
+                double* col = A + (size_t)c * KS + t;
+#pragma unroll
+                for (int s = 0; s < VPL; ++s)
+                  if (pm[s] & tbit) col[64 * s] = fma(-(colr[s] * rarr), arc, col[64 * s]);
+              }
+            }
+#pragma unroll
+            for (int s = 0; s < VPL; ++s) if (t + 64 * s == r) x[s] = 0.0;
+          }
+        }
+      }
+    };
+
+    auto dual = [&]() {
+      put(x);
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) w[s] = f[s];
+#pragma unroll
+      for (int sc = 0; sc < VPL; ++sc) {
+        unsigned long long mb = pm[sc];
+        while (mb) {
+          const int c = 64 * sc + (int)__builtin_ctzll(mb);
+          mb &= mb - 1ull;
+          const double xc = vb[c];
+          const double* hcol = Hd + (size_t)c * KP + t;        // HA[c][v] = HA[v][c]
+#pragma unroll
+          for (int s = 0; s < VPL; ++s) if (act[s]) w[s] = fma(-hcol[64 * s], xc, w[s]);
+        }
+      }
+    };
+
+    bool any_passive = false;
+    if (warm) {
+      double x0[VPL];
+      unsigned long long todo[VPL];
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) {
+        const float x0f = act[s] ? X[(int64_t)(t + 64 * s) * x_sk + prob * x_sp] : 0.f;
+        x0[s] = (x0f > 0.f) ? (double)x0f : 0.0;
+        todo[s] = __ballot(x0[s] > 0.0);
+      }
+#pragma unroll
+      for (int sj = 0; sj < VPL; ++sj) {
+        while (todo[sj]) {
+          const int j = 64 * sj + (int)__builtin_ctzll(todo[sj]);
+          todo[sj] &= todo[sj] - 1ull;
+          border(j, 1e-13);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) { ban[s] = 0ull; x[s] = (pm[s] & tbit) ? x0[s] : 0.0; any_passive |= pm[s] != 0ull; }
+      if (any_passive) { inner(); dual(); }
+    }
+
+    for (int outer = 0; outer < 3 * k + 3; ++outer) {
+      double mine[VPL], mx = -1.0e300;
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) {
+        mine[s] = (act[s] && !((pm[s] | ban[s]) & tbit)) ? w[s] : -1.0e300;
+        mx = fmax(mx, mine[s]);
+      }
+      const double best = wave_max_f64(mx);
+      if (!(best > tol)) break;
+      int j = -1;
+#pragma unroll
+      for (int s = 0; s < VPL; ++s) {                          // lowest index among ties
+        const unsigned long long eq = __ballot(mine[s] == best);
+        if (j < 0 && eq) j = 64 * s + (int)__builtin_ctzll(eq);
+      }
+      if (!border(j, 1e-13)) continue;
+      inner();
+      dual();
+    }
+#pragma unroll
+    for (int s = 0; s < VPL; ++s)
+      if (act[s]) X[(int64_t)(t + 64 * s) * x_sk + prob * x_sp] = (float)((pm[s] & tbit) ? x[s] : 0.0);
+    __syncthreads();
+  }
+}
+
+// scratch doubles k_nnqp_big needs for `blocks` workgroups
+static inline int nnqp_big_vpl(int k) { return k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 16; }
+static inline int64_t nnqp_big_blocks(int k, int64_t nprob) {
+  const int64_t KS = 64 * nnqp_big_vpl(k);
+  int64_t blocks = std::min<int64_t>(nprob, 4096);
+  const int64_t cap = ((int64_t)2 << 30) / (KS * KS * 8);      // at most 2 GiB of inverse images
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
 // F(var, prob) = F[var * f_sk + prob * f_sp]; X likewise.  Hd: [KP][KP] float64.
 static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, const float* F, int64_t f_sk,
-                              int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm = nullptr) {
-  if (k > 64) return PMF_EINVAL;
+                              int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm = nullptr,
+                              double* scratch = nullptr) {
+  if (k > 64) {                 // generic kernel; scratch: nnqp_big_blocks(k, nprob) * (64 VPL)^2 doubles
+    if (!scratch || k > 1024) return PMF_EINVAL;
+    const unsigned blocks = (unsigned)nnqp_big_blocks(k, nprob);
+    switch (nnqp_big_vpl(k)) {
+      case 2: hipLaunchKernelGGL((k_nnqp_big<2>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
+      case 4: hipLaunchKernelGGL((k_nnqp_big<4>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
+      case 8: hipLaunchKernelGGL((k_nnqp_big<8>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
+      default: hipLaunchKernelGGL((k_nnqp_big<16>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
+    }
+    return PMF_OK;
+  }
   const int KR = k <= 16 ? 16 : k <= 32 ? 32 : 64;
   const size_t smem = (size_t)KR * KR * sizeof(double);
   int64_t blocks = (nprob + 3) / 4;

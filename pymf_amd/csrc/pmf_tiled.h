@@ -490,14 +490,20 @@ __global__ __launch_bounds__(256) void k_reduce_slabs_block(const float* __restr
 }
 
 // W <- (W * Num) / (Den + 1e-9), elementwise over [rows][ld] (pymf/nmf.py:128-132); the zero padding stays 0
-// bnmf != 0: the BNMF rule W *= (Num + 3 l W^2) / (Den + 2 l W^3 + l W + 1e-9) (bnmf.py:87-90)
+// bnmf == 1: the BNMF rule W *= (Num + 3 l W^2) / (Den + 2 l W^3 + l W + 1e-9) (bnmf.py:87-90)
+// bnmf == 2: the RNMF rule W *= (|Num| - Num) / (2 Den) with Num = (S - data) H^T, no epsilon (rnmf.py:109-115);
+//            rows >= mvalid and columns >= kvalid of the [.][KP] buffers are padding (0/0 there): kept 0
 __global__ __launch_bounds__(256) void k_nmf_w_elem(float* __restrict__ W, const float* __restrict__ Num,
                                                     const float* __restrict__ Den, int64_t count, int bnmf,
-                                                    float lamb) {
+                                                    float lamb, int KP = 0, int64_t mvalid = 0, int kvalid = 0) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= count) return;
   const float w = W[q];
-  if (bnmf) {
+  if (bnmf == 2) {
+    const float x = Num[q];
+    const float r = w * ((fabsf(x) - x) / (2.0f * Den[q]));
+    W[q] = (q / KP < mvalid && (int)(q % KP) < kvalid) ? r : 0.f;
+  } else if (bnmf) {
     const float w1 = Num[q] + (3.0f * lamb) * (w * w);
     const float w2 = ((Den[q] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
     W[q] = w * (w1 / w2);
@@ -508,10 +514,13 @@ __global__ __launch_bounds__(256) void k_nmf_w_elem(float* __restrict__ W, const
 
 // Direct residual for num_bases > 128: part[block] = sum((V - W H)^2) over a 64 x 64 tile, plain float32
 // FMAs with LDS staging (a fallback for nearly exact fits, where the trace identity cancels -- not a hot path).
+// RNMF = true: additionally D = soft_threshold(V - W H, lamb) - V is stored (as k_resid<NT, true>).
+template <bool RNMF>
 __global__ __launch_bounds__(256) void k_resid_bigk(const float* __restrict__ V, int64_t ldv,
                                                     const float* __restrict__ W, int KP,
                                                     const float* __restrict__ H, int64_t ldh,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, float lamb = 0.f,
+                                                    float* __restrict__ D = nullptr) {
   __shared__ float Ws[64][17];
   __shared__ float Hs[16][64];
   __shared__ double wsum[4];
@@ -546,8 +555,15 @@ __global__ __launch_bounds__(256) void k_resid_bigk(const float* __restrict__ V,
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const float r = V[(r0 + ty + 16 * a) * ldv + c0 + tx + 16 * b] - acc[a][b];
+      const float v = V[(r0 + ty + 16 * a) * ldv + c0 + tx + 16 * b];
+      const float r = v - acc[a][b];
       s += (double)r * (double)r;
+      if (RNMF) {                                  // soft thresholding, rnmf.py:75-79
+        float sv = 0.f;
+        if (r > lamb) sv = r - lamb;
+        else if (r < -lamb) sv = r + lamb;
+        D[(r0 + ty + 16 * a) * ldv + c0 + tx + 16 * b] = sv - v;
+      }
     }
   s = wave_sum_f64(s);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;

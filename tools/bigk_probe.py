@@ -55,5 +55,16 @@ if __name__ == "__main__":
         run("NMFALS", 500, 400, 200, 2)
         run("NMFALS", 500, 300, 100, 2, hooks=True)
     elif what == "rnmf":
-        run("RNMF", 1000, 300, 160, 4)
-        run("RNMF", 1000, 300, 160, 3, hooks=True)
+        from pymf_amd.rnmf import RNMF
+        for (m, n, k, niter) in [(1000, 300, 160, 4), (700, 520, 260, 3)]:
+            rs = np.random.RandomState(m + k)
+            V = rs.random_sample((m, n)).astype(np.float32)
+            V.flat[rs.randint(0, V.size, size=V.size // 300)] += 5.0
+            np.random.seed(5)
+            mdl = RNMF(V, num_bases=k, lamb=1.0)
+            mdl.factorize(niter=niter)
+            np.random.seed(5)
+            o = oracle.RNMFOracle(V, num_bases=k, lamb=1.0)
+            o.factorize(niter=niter)
+            print("RNMF", (m, n, k), "relW %.2e relH %.2e relS %.2e ferr rel %.1e" %
+                  (rel(mdl.W, o.W), rel(mdl.H, o.H), rel(mdl.S, o.S), np.max(np.abs(mdl.ferr - o.ferr) / o.ferr)), flush=True)
