@@ -68,7 +68,7 @@ int pmf_nccl_unique_id(void* out);
  *   algo      PMF_ALGO_*
  *   m_local   rows of V (= rows of W) held by THIS rank (the whole matrix when nranks==1)
  *   n         columns of V (= columns of H), identical on all ranks
- *   k         num_bases
+ *   k         num_bases, 1 .. 1024 for every algorithm (beyond 128 -- 64 for NMFALS -- generic kernels run)
  *   rank,nranks,nccl_id   RCCL world; nranks==1 -> nccl_id may be NULL and RCCL is not touched
  *                         (a non-NULL id with nranks==1 creates a 1-rank communicator)
  */
@@ -141,7 +141,7 @@ int pmf_stream_tile(pmf_ctx* ctx, int64_t row0, int64_t rows, const float* tile,
 int pmf_stream_end(pmf_ctx* ctx, double* ferr, int32_t* needs_direct);
 
 /* NNDSVD initialisation (pymf/nndsvd.py:79-108 = NNDSVD.update_w, with the SVD of pymf/svd.py:125-148):
- * fills the context's W and H from the dense V already set.  Needs n <= 1024 (the Gram matrix
+ * fills the context's W and H from the dense V already set.  Needs n <= 4096 (the Gram matrix
  * data^T data is n x n; a wide matrix is handled by the caller on the transposed problem, as the
  * reference's SVD switches between its left and right forms, svd.py:237-246) and num_bases <= n.
  * rank_found (may be NULL) receives how many of the leading num_bases eigenvalues exceed the

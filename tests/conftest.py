@@ -21,6 +21,8 @@ def load_golden(name):
         m, n = (int(x) for x in d["V_shape"])
         u = np.random.RandomState(int(d["V_seed"])).random_sample((m, n))
         # seed 5 is the binary BNMF matrix (gen_golden.py), every other seeded V is U[0,1)
+        if "V_shift" in d:                 # gen_golden.py seeded(): (u - shift) rounded to float32
+            u = u - float(d["V_shift"])
         d["V"] = (u < 0.2).astype(np.float32) if name.startswith("bnmf") else u.astype(np.float32)
     return d
 

@@ -258,6 +258,32 @@ def main():
             d.update(W_nmf10=nmf_mdl.W, H_nmf10=nmf_mdl.H, ferr_nmf10=np.asarray(nmf_mdl.ferr))
         cases[tag] = d
 
+    # num_bases beyond the register-resident kernels (SNMF/RNMF/NNDSVD > 128, NMFALS > 64): the reference has
+    # no limit (snmf.py:69-70, nmfals.py:78-80, rnmf.py:109-115).  V by seed; mixed-sign data for SNMF.
+    def seeded(m_, n_, seed_, shift=0.0):
+        Vq = (np.random.RandomState(seed_).random_sample((m_, n_)) - shift).astype(np.float32)
+        return Vq, dict(V_seed=np.int64(seed_), V_shape=np.array([m_, n_], dtype=np.int64), V_shift=np.float64(shift))
+    Vq, dq = seeded(512, 320, 77, 0.3)
+    add("bigk_snmf_512x320_k160", SNMF, Vq, dq, 160, 4, 42, False)
+    Vq, dq = seeded(300, 200, 78)
+    add("bigk_nmfals_300x200_k72", ALS, Vq, dq, 72, 2, 42, False)
+    Vq, dq = seeded(260, 300, 79)
+    add("bigk_nmfals_260x300_k130", ALS, Vq, dq, 130, 2, 42, False)
+    Vq, dq = seeded(500, 300, 80)
+    mdl = NNDSVD(Vq, num_bases=150)
+    mdl.factorize()
+    cases["bigk_nndsvd_500x300_k150"] = dict(W=mdl.W, H=mdl.H, ferr=np.asarray(mdl.ferr, dtype=np.float64), k=np.int64(150), **dq)
+    rs_ = np.random.RandomState(81)
+    Vr = rs_.random_sample((300, 256))
+    out_idx = rs_.randint(0, Vr.size, size=Vr.size // 200)
+    Vr.flat[out_idx] += 4.0 * rs_.random_sample(out_idx.shape[0]) + 1.0
+    Vr = Vr.astype(np.float32)
+    np.random.seed(7)
+    mdl = RNMF(Vr, num_bases=140, lamb=1.0)
+    mdl.factorize(niter=6)
+    cases["bigk_rnmf_300x256_k140"] = dict(V=Vr, W=mdl.W, H=mdl.H, S=mdl.S, ferr=np.asarray(mdl.ferr, dtype=np.float64),
+                                           k=np.int64(140), niter=np.int64(6), seed=np.int64(7), lamb=np.float64(1.0))
+
     only = sys.argv[1:]          # e.g. `gen_golden.py nndsvd` rewrites only the nndsvd_* fixtures
     for name, d in cases.items():
         if only and not any(name.startswith(o) for o in only):

@@ -1,0 +1,203 @@
+"""GPU parity beyond the register-resident base counts: SNMF / RNMF / NNDSVD with num_bases > 128 and
+NMFALS / NMFNNLS with num_bases > 64 (the reference has no limit: snmf.py:69-70, nmfals.py:78-80,
+rnmf.py:109-115, nndsvd.py:92-106).  These widths run the generic paths -- base blocks of 128 on the
+tiled kernels, the cooperative float64 inverse (k_inverse_spd_big), the active-set QP with its inverse
+images in global memory (k_nnqp_big) -- against goldens produced by the reference itself
+(tests/golden/gen_golden.py, `bigk_*`) and the float64 oracles."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_fro, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import pymf_amd
+    from pymf_amd import _lib
+    assert _lib.device_count() >= 1
+    return pymf_amd
+
+
+def _run_golden(pm, cls_name, name):
+    g = load_golden(name)
+    mdl = getattr(pm, cls_name)(g["V"], num_bases=int(g["k"]))
+    mdl.W, mdl.H = g["W0"].copy(), g["H0"].copy()
+    mdl.factorize(niter=int(g["niter"]))
+    assert len(mdl.ferr) == len(g["ferr"])
+    return g, mdl
+
+
+def test_snmf_k160_vs_reference_golden(pm):
+    g, mdl = _run_golden(pm, "SNMF", "bigk_snmf_512x320_k160")
+    close(mdl.ferr, g["ferr"], rtol=1e-6, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-5 and rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-5
+
+
+@pytest.mark.parametrize("name", ["bigk_nmfals_300x200_k72", "bigk_nmfals_260x300_k130"])
+def test_nmfals_beyond_64_vs_reference_golden(pm, name):
+    """nmfals.py itself (exact-QP stand-in for cvxopt, gen_golden.load_reference_nmfals); k = 130 also
+    crosses the 128-base block boundary of the products around the QPs."""
+    g, mdl = _run_golden(pm, "NMFALS", name)
+    close(mdl.ferr, g["ferr"], rtol=1e-6, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-4 and rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-4
+
+
+def test_rnmf_k140_vs_reference_golden(pm):
+    from pymf_amd.rnmf import RNMF
+    g = load_golden("bigk_rnmf_300x256_k140")
+    np.random.seed(int(g["seed"]))
+    mdl = RNMF(g["V"], num_bases=int(g["k"]), lamb=float(g["lamb"]))
+    mdl.factorize(niter=int(g["niter"]))
+    close(mdl.ferr, g["ferr"], rtol=1e-6, what="mdl.ferr")
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 5e-5 and rel_fro(mdl.H, g["H"], what="mdl.H") < 5e-5
+    assert rel_fro(mdl.S, g["S"], what="mdl.S") < 5e-5
+
+
+def test_nndsvd_k150_vs_reference_golden(pm):
+    g = load_golden("bigk_nndsvd_500x300_k150")
+    mdl = pm.NNDSVD(g["V"], num_bases=int(g["k"]))
+    mdl.factorize()
+    # the trailing singular directions of a random matrix are close together: their vectors carry the float32
+    # Gram matrix's rounding amplified by 1 / gap (the reference forms the same product in float32 too)
+    assert rel_fro(mdl.W, g["W"], what="mdl.W") < 2e-3 and rel_fro(mdl.H, g["H"], what="mdl.H") < 2e-3
+    close(mdl.ferr, g["ferr"], rtol=1e-4, what="mdl.ferr")
+
+
+@pytest.mark.parametrize("shape,k,mode", [((3000, 400), 160, "loop"), ((3000, 400), 160, "pass"), ((3000, 400), 160, "hooks"),
+                                          ((2000, 700), 300, "loop"), ((1500, 1200), 520, "loop"), ((900, 1100), 1024, "loop")])
+def test_snmf_wide_vs_float64_oracle(pm, shape, k, mode):
+    """loop: factorize() (Gram space); pass: snmf_gram = 0, one pass over V per iteration; hooks: update_w /
+    update_h called one by one."""
+    from oracle import SNMFOracle
+    rs = np.random.RandomState(sum(shape) + k)
+    V = (rs.random_sample(shape) - 0.4).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    o = SNMFOracle(V.astype(np.float64), num_bases=k)
+    o.W, o.H = W0.copy(), H0.copy()
+    mdl = pm.SNMF(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    if mode == "hooks":
+        for _ in range(3):
+            mdl.update_w(); o.update_w()
+            mdl.update_h(); o.update_h()
+        assert abs(mdl.frobenius_norm() - o.frobenius_norm()) <= 1e-6 * o.frobenius_norm()
+    else:
+        if mode == "pass":
+            mdl._context().set_option("snmf_gram", 0)
+        mdl.factorize(niter=3)
+        o.factorize(niter=3)
+        close(mdl.ferr, o.ferr, rtol=1e-6, what="mdl.ferr")
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-5
+
+
+@pytest.mark.parametrize("hooks", [False, True])
+def test_snmf_wide_on_sparse_data(pm, hooks):
+    """scipy.sparse data with more than 128 bases: the rows are expanded once on the device (k_csr_densify) and
+    the dense kernels run; semantics = SNMF on data.toarray(), as for the CSR kernels."""
+    import scipy.sparse as sp
+    from oracle import SNMFOracle
+    rs = np.random.RandomState(3)
+    Vd = (rs.random_sample((2000, 300)) * (rs.random_sample((2000, 300)) < 0.1)).astype(np.float32)
+    W0, H0 = rs.random_sample((2000, 200)), rs.random_sample((200, 300))
+    o = SNMFOracle(Vd.astype(np.float64), num_bases=200)
+    o.W, o.H = W0.copy(), H0.copy()
+    mdl = pm.SNMF(sp.csr_matrix(Vd), num_bases=200)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    if hooks:
+        for _ in range(2):
+            mdl.update_w(); o.update_w()
+            mdl.update_h(); o.update_h()
+    else:
+        mdl.factorize(niter=3, compute_err=False)
+        o.factorize(niter=3, compute_err=False)
+    assert mdl.frobenius_norm() == -123456                      # nmf.py:109-112
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-5
+
+
+@pytest.mark.parametrize("cls_name,shape,k,hooks", [("NMFALS", (600, 200), 80, False), ("NMFALS", (500, 300), 100, True),
+                                                    ("NMFALS", (400, 380), 200, False), ("NMFNNLS", (300, 260), 96, False),
+                                                    ("NMFALS", (150, 700), 520, False)])
+def test_als_wide_vs_float64_oracle(pm, cls_name, shape, k, hooks):
+    """k_nnqp_big with 2, 4 and 16 variables per lane; the last case has more bases than rows (rank-deficient
+    H H^T: the cold-start path, as the reference test's rank-3 data)."""
+    import oracle
+    rs = np.random.RandomState(sum(shape) + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    ocls = getattr(oracle, "NMFALSOracle")
+    o = ocls(V.astype(np.float64), num_bases=k)
+    o.W, o.H = W0.copy(), H0.copy()
+    mdl = getattr(pm, cls_name)(V, num_bases=k)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    if hooks:
+        for _ in range(2):
+            mdl.update_w(); o.update_w()
+            mdl.update_h(); o.update_h()
+    else:
+        mdl.factorize(niter=2)
+        o.factorize(niter=2)
+        close(mdl.ferr, o.ferr, rtol=1e-6, what="mdl.ferr")
+    if k < min(shape):
+        assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-4 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-4
+    # the fit itself is what a degenerate problem pins down
+    assert abs(mdl.frobenius_norm() - o.frobenius_norm()) <= 1e-5 * max(o.frobenius_norm(), 1.0)
+
+
+def test_nnqp_big_equals_register_kernel(pm):
+    """The generic QP kernel and the register-resident one implement the same pivoting rules: on a k = 64 problem
+    solved as-is and embedded in a 65-variable problem whose extra variable can never enter (f = -1), the first
+    64 coordinates agree to rounding."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(4)
+    m, n = 900, 120
+    V = rs.random_sample((m, n)).astype(np.float32)
+    outs = []
+    for k in (64, 65):
+        H = np.zeros((k, n), dtype=np.float32)
+        H[:64] = np.random.RandomState(5).random_sample((64, n))
+        if k == 65:
+            H[64] = 0.0                                      # dead basis: zero row of H H^T, stays out
+        ctx = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+        ctx.set_v_dense(V); ctx.set_w(np.zeros((m, k), dtype=np.float32)); ctx.set_h(H)
+        ctx.update_w()
+        outs.append(ctx.get_w())
+        ctx.close()
+    assert np.all(outs[1][:, 64] == 0.0)
+    assert rel_fro(outs[1][:, :64], outs[0], what="k_nnqp_big vs k_nnqp") < 1e-6
+
+
+def test_rnmf_wide_vs_float64_oracle(pm):
+    from pymf_amd.rnmf import RNMF
+    from oracle import RNMFOracle
+    rs = np.random.RandomState(8)
+    V = rs.random_sample((700, 520)).astype(np.float32)
+    V.flat[rs.randint(0, V.size, size=V.size // 300)] += 5.0
+    np.random.seed(5)
+    mdl = RNMF(V, num_bases=260, lamb=1.0)
+    mdl.factorize(niter=3)
+    np.random.seed(5)
+    o = RNMFOracle(V, num_bases=260, lamb=1.0)
+    o.factorize(niter=3)
+    close(mdl.ferr, o.ferr, rtol=1e-6, what="mdl.ferr")
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < 5e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 5e-6
+    assert rel_fro(mdl.S, o.S, what="mdl.S") < 5e-6
+    # hooks one by one (S exists after factorize)
+    mdl.update_w(); o.update_w()
+    mdl.update_h(); o.update_h()
+    assert rel_fro(mdl.W, o.W, what="hooks W") < 5e-5 and rel_fro(mdl.H, o.H, what="hooks H") < 5e-6
+
+
+def test_nndsvd_wide_bases_vs_float64_oracle(pm):
+    from oracle import nndsvd_closed_form
+    rs = np.random.RandomState(11)
+    r = 190
+    A = rs.random_sample((1500, r)) * (1.0 + np.arange(r))[None, ::-1]
+    V = (A @ rs.random_sample((r, 400)) + 0.05 * rs.random_sample((1500, 400))).astype(np.float32)
+    mdl = pm.NNDSVD(V, num_bases=180)
+    mdl.factorize()
+    W, H = nndsvd_closed_form(V, 180)
+    assert rel_fro(mdl.W, W, what="mdl.W") < 1e-3 and rel_fro(mdl.H, H, what="mdl.H") < 1e-3
+    ref_err = np.linalg.norm(V.astype(np.float64) - W @ H)
+    assert abs(mdl.ferr[0] - ref_err) <= 1e-3 * max(ref_err, 1e-3)

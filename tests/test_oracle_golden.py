@@ -167,3 +167,32 @@ def test_nndsvd_oracle_matches_reference_golden(name):
     tolc = 1e-10 if g["V"].dtype == np.float64 else 2e-4
     assert rel_fro(Wc, g["W"]) < tolc and rel_fro(Hc, g["H"]) < tolc
     assert (Wc >= 0).all() and (Hc >= 0).all()
+
+
+# ---- beyond the register-resident base counts (SNMF / RNMF / NNDSVD > 128, NMFALS > 64): `bigk_*` goldens ----
+def test_oracles_match_reference_goldens_at_wide_base_counts():
+    from oracle import RNMFOracle, NNDSVDOracle, nndsvd_closed_form
+    g = load_golden("bigk_snmf_512x320_k160")
+    o = SNMFOracle(g["V"], num_bases=int(g["k"]))
+    o.W, o.H = g["W0"].copy(), g["H0"].copy()
+    o.factorize(niter=int(g["niter"]))
+    assert rel_fro(o.W, g["W"]) < 1e-8 and rel_fro(o.H, g["H"]) < 1e-8
+    np.testing.assert_allclose(o.ferr, g["ferr"], rtol=1e-9)
+    for name in ("bigk_nmfals_300x200_k72", "bigk_nmfals_260x300_k130"):
+        g = load_golden(name)
+        o = NMFALSOracle(g["V"], num_bases=int(g["k"]))
+        o.W, o.H = g["W0"].copy(), g["H0"].copy()
+        o.factorize(niter=int(g["niter"]))
+        assert rel_fro(o.W, g["W"]) < 1e-6 and rel_fro(o.H, g["H"]) < 1e-6, name
+        np.testing.assert_allclose(o.ferr, g["ferr"], rtol=1e-7)
+    g = load_golden("bigk_rnmf_300x256_k140")
+    np.random.seed(int(g["seed"]))
+    o = RNMFOracle(g["V"], num_bases=int(g["k"]), lamb=float(g["lamb"]))
+    o.factorize(niter=int(g["niter"]))
+    assert rel_fro(o.W, g["W"]) < 1e-12 and rel_fro(o.H, g["H"]) < 1e-12 and rel_fro(o.S, g["S"]) < 1e-12
+    g = load_golden("bigk_nndsvd_500x300_k150")
+    o = NNDSVDOracle(g["V"], num_bases=150)
+    o.factorize()
+    assert rel_fro(o.W, g["W"]) < 1e-12 and rel_fro(o.H, g["H"]) < 1e-12
+    Wc, Hc = nndsvd_closed_form(g["V"], 150)
+    assert rel_fro(Wc, g["W"]) < 2e-3 and rel_fro(Hc, g["H"]) < 2e-3      # float32 Gram matrix in the reference, small gaps
