@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -28,16 +29,13 @@
 #include "pmf_fused.h"
 #include "pmf_coop.h"
 #include "pmf_nnls.h"
+#include "pmf_inv.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
 
 namespace {
 
 constexpr int PMF_HGRAM_MAX_WGS = 64;
-#ifndef PMF_INV8_TG
-#define PMF_INV8_TG 32          // the 128 x 128 inverse: 32 x 32 threads with 4 x 4 entries each (4 waves per SIMD)
-#endif
-constexpr int PMF_INV8_B = 128 / PMF_INV8_TG;   // workgroups of k_nmf_h_gram (one or more 64-column panels each)
 
 std::string g_create_error;
 
@@ -669,17 +667,18 @@ bool nmf_h_gram(pmf_ctx* c, int* rc) {
   return false;
 }
 
-template <int NT>
+template <int NT, int CT>
 int launch_snmf_h(pmf_ctx* c) {
-  constexpr size_t smem = snmf_h_smem_bytes<NT>();
+  constexpr size_t smem = snmf_h_smem_bytes<NT, CT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_h_mfma<NT>),
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_snmf_h_mfma<NT, CT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_snmf_h_mfma<NT>), dim3((unsigned)(c->np / 64)), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS, c->stop_arg);
+  hipLaunchKernelGGL((k_snmf_h_mfma<NT, CT>), dim3((unsigned)(c->np / (16 * CT))), dim3(1024), smem, c->stream, c->dH, c->np,
+                     c->dPS, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -690,11 +689,12 @@ int snmf_h_step(pmf_ctx* c) {   // snmf.py:72-91 on MFMA, one workgroup per 64-c
                        (int64_t)c->np, c->np, c->KP, c->dPS, 3, 0.f, c->k, (int)c->n);
     return PMF_OK;
   }
+  const bool narrow = c->np <= 256;   // few 64-column panels: 16-column workgroups spread the step over more CUs
   switch (c->NT) {
-    case 1: return launch_snmf_h<1>(c);
-    case 2: return launch_snmf_h<2>(c);
-    case 4: return launch_snmf_h<4>(c);
-    case 8: return launch_snmf_h<8>(c);
+    case 1: return launch_snmf_h<1, 4>(c);
+    case 2: return launch_snmf_h<2, 4>(c);
+    case 4: return narrow ? launch_snmf_h<4, 1>(c) : launch_snmf_h<4, 4>(c);
+    case 8: return narrow ? launch_snmf_h<8, 1>(c) : launch_snmf_h<8, 4>(c);
   }
   return fail(c, PMF_EINVAL, "bad NT");
 }
@@ -819,10 +819,10 @@ int nmf_fused_iteration(pmf_ctx* c) {
 // inv(H H^T) in float64 (Gauss-Jordan in registers, identity on the padding), then M^T = inv(H H^T) H in
 // float64, rounded once: dMT [KP][np] for the dense kernels, dW1 = M [np][KP] for the CSR kernels.
 int launch_inverse(pmf_ctx* c) {   // dGinvD = inv(dGd), float64
-  if (c->KP <= 64) {
-    hipLaunchKernelGGL((k_inverse_spd<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
+  if (c->KP <= 64) {                       // blocked Gauss-Jordan on the float64 MFMA (pmf_inv.h)
+    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvD, c->stop_arg);
   } else if (c->KP <= 128) {
-    hipLaunchKernelGGL((k_inverse_spd<PMF_INV8_B, PMF_INV8_TG>), dim3(1), dim3(PMF_INV8_TG * PMF_INV8_TG), 0, c->stream, c->dGd, c->KP, c->k, (float*)nullptr, c->dGinvD);
+    hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvD, c->stop_arg);
   } else {                         // num_bases > 128: the matrix in L2, a cooperative grid (k_inverse_spd_big)
     const size_t E = (size_t)c->KP * c->KP;
     if (!c->dInvA) { PMFCHK(dalloc(c, &c->dInvA, E)); PMFCHK(dalloc(c, &c->dInvB, E)); }

@@ -1,0 +1,214 @@
+// pmf_inv.h -- inv(H H^T) for SNMF (pymf/snmf.py:69-70) as a BLOCKED Gauss-Jordan on the float64 MFMA.
+//
+// An unblocked elimination (round 1: k_inverse_spd, one workgroup barrier and one LDS round trip per
+// pivot) takes 73 us at k = 128 -- 60 % of a Gram-space SNMF iteration.  Here the
+// matrix (order 16 NBLK, NBLK = 4 or 8) is cut into 16 x 16 tiles that live in the MFMA C/D register
+// layout of v_mfma_f64_16x16x4_f64 (lane l, register r  <->  row (l >> 4) + 4 r, column l & 15); wave
+// w owns block row w / (NBLK / 4) and four consecutive block columns.  Block step p of the in-place
+// inversion is
+//     D      = inv(A_pp)                         (one wave, in registers, 16 pivots)
+//     R_j    = D A_pj                 (j != p)   new row panel            A_pp <- D
+//     A_ij  -= A_ip R_j           (i, j != p)    everything else
+//     A_ip   = -A_ip D                (i != p)   new column panel
+// Two facts keep every operand in registers or one LDS copy away, with no transposes:
+//  * the C/D layout of a tile T is at the same time the B-operand layout of T and the A-operand
+//    layout of T^T (k-step s of a 16-deep product takes C register s);
+//  * the in-place state is sign-symmetric: A_ip = (A_pi)^T when block i is still to be processed and
+//    -(A_pi)^T when it has been -- so A_ip is never needed as such, the row panel p serves for both.
+// Per step: row panel p is in LDS (C layout) -> barrier -> eight waves form one R_j each and publish
+// it -> barrier -> the owners of row p take D and the R_j, all other waves update their four tiles
+// (16 MFMAs each).  The serial part, inv(A_pp), is looked ahead: during step p the owner of tile
+// (p+1, p+1) updates that tile FIRST and hands it over (LDS + flag, no barrier) to a wave of block
+// row p -- idle in this step -- which inverts it on the VALU while the others keep the MFMA busy.
+// The matrix is scaled to unit diagonal first (inv(G) = S inv(S G S) S): every pivot is then <= 1,
+// which makes the one-FMA-per-entry form of the 16 x 16 elimination free of cancellation.
+#pragma once
+#include "pmf_dev.h"
+#include "pmf_nnls.h"   // readlane_f64
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Index of element (row, col) of a 16 x 16 tile kept in LDS the way store_tile() below writes it.
+__device__ __forceinline__ int tile_lds_index(int row, int col) {
+  const int l = 16 * (row & 3) + col, r = row >> 2;     // C layout: lane l, register r
+  return (r >> 1) * 128 + 2 * l + (r & 1);
+}
+
+// In-wave inverse of an SPD 16 x 16 tile with diagonal <= 1: src, dst as store_tile() writes tiles.
+// Lane (g, cc) holds rows 4g .. 4g+3 of column cc, so a pivot costs FOUR FMAs per lane.  Pivot q: the
+// row q goes into a 16-entry LDS line; every lane takes from it its column's entry
+// a[q][cc] and -- the state of an in-place Gauss-Jordan on a symmetric matrix is sign-symmetric,
+// a[r][q] = a[q][r] for r not yet eliminated and -a[q][r] for r < q -- the four column entries
+// a[4g+u][q] of its rows as well (one 32-byte read).  The pivot itself travels as a scalar
+// (v_readlane) so that its reciprocal is under way while the line is in flight.  Entry update in one FMA,
+//   a_rc + pc_r pr_c,  pc_r = -a_rq (r != q), 1 - a_qq (r = q);  pr_c = a_qc / a_qq (c != q), 1 + 1 / a_qq (c = q),
+// which yields a_qc / a_qq in row q, -a_rq / a_qq in column q and 1 / a_qq in the corner.
+template <int Q>
+__device__ __forceinline__ void inv16_pivot(double (&a)[4], double* __restrict__ line /*[4][16]*/, int g, int cc) {
+  constexpr int QG = Q >> 2, QU = Q & 3;
+  const double app = readlane_f64(a[QU], 16 * QG + Q);
+  // every lane group stores its own row 4g + QU (straight-line code: a store under `if (g == QG)` lets the
+  // compiler run the other groups' reads first); the pivot row is the line of group QG
+  line[16 * g + cc] = a[QU];
+  const double d = pmf_rcp_f64(app);
+  const double prow = line[16 * QG + cc];
+  const double2 q01 = *reinterpret_cast<const double2*>(line + 16 * QG + 4 * g);
+  const double2 q23 = *reinterpret_cast<const double2*>(line + 16 * QG + 4 * g + 2);
+  const double quad[4] = {q01.x, q01.y, q23.x, q23.y};
+  const double prq = (cc == Q) ? 1.0 + d : prow * d;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 4 * g + u;
+    const double pc = (r == Q) ? 1.0 - app : (r < Q ? quad[u] : -quad[u]);
+    a[u] = fma(pc, prq, a[u]);
+  }
+}
+
+__device__ __forceinline__ void inv16_wave(const double* __restrict__ src, double* __restrict__ dst,
+                                           double* __restrict__ line /* [4][16] doubles, wave-private */, int lane) {
+  const int cc = lane & 15, g = lane >> 4;
+  double a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = src[tile_lds_index(4 * g + u, cc)];
+  inv16_pivot<0>(a, line, g, cc);   inv16_pivot<1>(a, line, g, cc);   inv16_pivot<2>(a, line, g, cc);   inv16_pivot<3>(a, line, g, cc);
+  inv16_pivot<4>(a, line, g, cc);   inv16_pivot<5>(a, line, g, cc);   inv16_pivot<6>(a, line, g, cc);   inv16_pivot<7>(a, line, g, cc);
+  inv16_pivot<8>(a, line, g, cc);   inv16_pivot<9>(a, line, g, cc);   inv16_pivot<10>(a, line, g, cc);  inv16_pivot<11>(a, line, g, cc);
+  inv16_pivot<12>(a, line, g, cc);  inv16_pivot<13>(a, line, g, cc);  inv16_pivot<14>(a, line, g, cc);  inv16_pivot<15>(a, line, g, cc);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dst[tile_lds_index(4 * g + u, cc)] = a[u];
+}
+
+template <int NBLK>   // matrix order 16 NBLK (identity padded beyond k): 4 -> 64, 8 -> 128
+__global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
+                                                                             double* __restrict__ Ginv64,
+                                                                             const int* __restrict__ stop) {
+  if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep the inverse
+  constexpr int CW = NBLK / 4;                 // waves per block row
+  constexpr int KP = 16 * NBLK;
+  __shared__ __attribute__((aligned(16))) double pold[2][NBLK][256];   // row panel p before the step, double buffered
+  __shared__ __attribute__((aligned(16))) double pR[NBLK][256];        // R_j = D A_pj
+  __shared__ __attribute__((aligned(16))) double dsrc[256];            // the diagonal tile on its way into inv16_wave
+  __shared__ __attribute__((aligned(16))) double dD[2][256];           // D of step p in dD[p & 1]
+  __shared__ __attribute__((aligned(32))) double line[64];   // inv16_wave's pivot rows, one per lane group
+  __shared__ double sc[KP];                    // 1 / sqrt(g_ii)
+  __shared__ int dflag;                        // = la once tile (la, la) of the look-ahead is in dsrc
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bi = wv / CW, j0 = 4 * (wv % CW);
+  const int g = lane >> 4, cc = lane & 15;
+  for (int i = tid; i < KP; i += 64 * NBLK * CW) {
+    const double gii = i < k ? Gd[(int64_t)i * ld + i] : 1.0;
+    sc[i] = gii > 0.0 ? 1.0 / sqrt(gii) : 1.0;
+  }
+  if (tid == 0) dflag = 0;
+  __syncthreads();
+  f64x4 c[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * bi + g + 4 * r, col = 16 * (j0 + t) + cc;
+      c[t][r] = (row < k && col < k) ? Gd[(int64_t)row * ld + col] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
+    }
+  const int nsteps = (k + 15) / 16;            // blocks beyond k are identity: nothing to eliminate
+
+  // a tile in LDS: registers (0, 1) of all lanes, then registers (2, 3): two conflict-free 16-byte accesses per lane
+  auto store_tile = [&](double* dstp, const f64x4& v) {
+    reinterpret_cast<double2*>(dstp)[lane] = double2{v[0], v[1]};
+    reinterpret_cast<double2*>(dstp + 128)[lane] = double2{v[2], v[3]};
+  };
+  auto load_tile = [&](const double* srcp) {
+    const double2 lo = reinterpret_cast<const double2*>(srcp)[lane];
+    const double2 hi = reinterpret_cast<const double2*>(srcp + 128)[lane];
+    return f64x4{lo.x, lo.y, hi.x, hi.y};
+  };
+
+  if (bi == 0 && j0 == 0) {                    // D of step 0
+    store_tile(dsrc, c[0]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    inv16_wave(dsrc, dD[0], line, lane);
+  }
+  if (bi == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) store_tile(pold[0][j0 + t], c[t]);
+  }
+  for (int p = 0; p < nsteps; ++p) {
+    __syncthreads();                           // pold[p & 1] and dD[p & 1] are in place
+    const f64x4 D = load_tile(dD[p & 1]);
+    const int la = p + 1;                      // look-ahead: tile (la, la) is brought up to date and inverted during this step
+    const bool owns_diag = (bi >> 2) == (wv % CW);               // tile (bi, bi) is one of this wave's four
+    const bool la_wave = la < nsteps && bi == la && owns_diag;
+    if (owns_diag && bi != p) {                // R_j = D A_pj for j = bi (both operands are in LDS: any wave could)
+      const f64x4 apj = load_tile(pold[p & 1][bi]);
+      f64x4 rj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) rj = mfma_f64(D[s], apj[s], rj);     // D is symmetric: its C layout is its A layout
+      if (la_wave) {                           // A_ll - A_lp R_l with A_lp = (A_pl)^T: the same tile once more, as A operand
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (j0 + t == la) {
+            f64x4 acc = c[t];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_f64(-apj[s], rj[s], acc);
+            c[t] = acc;
+            store_tile(dsrc, acc);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&dflag, la, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      store_tile(pR[bi], rj);
+    }
+    __syncthreads();                           // R_j are in place
+    if (bi == p) {                             // these waves have no update to do in this step ...
+      if (j0 == 0 && la < nsteps) {            // ... so one of them inverts the look-ahead tile
+        while (__hip_atomic_load(&dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != la) __builtin_amdgcn_s_sleep(1);
+        inv16_wave(dsrc, dD[la & 1], line, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = (j0 + t == p) ? D : load_tile(pR[j0 + t]);   // new row panel
+    } else {
+      const double msig = (bi < p) ? 1.0 : -1.0;                 // -sigma_i
+      f64x4 ap = load_tile(pold[p & 1][bi]);                     // (A_pi)^T as A operand, times -sigma_i
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ap[s] *= msig;
+      // Straight-line over the four tiles (the special cases are operand choices, not branches), so that the
+      // four loads go out together and the four MFMA chains interleave:
+      //   j == p           column panel, -A_ip D:  B operand D, accumulator 0
+      //   look-ahead tile  already up to date:     A operand 0
+      //   otherwise        A_ij - A_ip R_j
+      f64x4 bop[4], acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + t;
+        bop[t] = load_tile(j == p ? dD[p & 1] : pR[j]);
+        acc[t] = c[t];
+        if (j == p) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double a_op = (la_wave && j0 + t == la) ? 0.0 : ap[s];
+          acc[t] = mfma_f64(a_op, bop[t][s], acc[t]);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = acc[t];
+      if (bi == p + 1) {                                         // row panel of the next step
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store_tile(pold[(p + 1) & 1][j0 + t], c[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * bi + g + 4 * r, col = 16 * (j0 + t) + cc;
+      if (row < ld && col < ld)
+        Ginv64[(int64_t)row * ld + col] = (row < k && col < k) ? c[t][r] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
+    }
+}

@@ -278,28 +278,30 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
 // tiles (mt, ct) = (q / 4, q % 4), q = w, w + 16, ...; S is split into its positive and negative
 // parts in registers as the A fragments are read, so pos(WW) H and neg(WW) H are two accumulator
 // chains over the same operands.  LDS layout and staging as in k_nmf_h_gram.
-template <int NT>
-constexpr size_t snmf_h_smem_bytes() { return (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * 68) * sizeof(float); }
+// CT = column tiles per workgroup: 4 (64-column panels) or 1 (16-column panels, for narrow H: at n = 128
+// two 64-column workgroups leave the step latency-bound on two CUs -- 14.7 us at k = 128 -- eight don't).
+template <int NT, int CT>
+constexpr size_t snmf_h_smem_bytes() { return (size_t)(16 * NT * (16 * NT + 4) + 16 * NT * (16 * CT + 4)) * sizeof(float); }
 
-template <int NT>
+template <int NT, int CT>
 __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int np,
                                                       const float* __restrict__ PS,
                                                       const int* __restrict__ stop) {
   if (stop != nullptr && *stop != 0) return;
-  constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
-  constexpr int HT = NT * 4, HTW = (HT + 15) / 16;
+  constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 16 * CT + 4;
+  constexpr int HT = NT * CT, HTW = (HT + 15) / 16;
   const int64_t ldp = (int64_t)np + KP;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* ss = sm;                    // [KP][KP+4]   WW = W^T W
-  float* hs = ss + KP * LDS_S;       // [KP][68]     H panel
+  float* hs = ss + KP * LDS_S;       // [KP][16 CT + 4]   H panel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
-  const int c0 = 64 * blockIdx.x;
+  const int c0 = 16 * CT * blockIdx.x;
   float pv[HTW][4];
 #pragma unroll
   for (int h = 0; h < HTW; ++h) {
-    const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
+    const int q = wv + 16 * h, mt = q / CT, ct = q % CT;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i] : 0.f;
@@ -309,8 +311,8 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
     *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) =
         *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
   }
-  for (int q = tid; q < KP * 16; q += 1024) {
-    const int r = q >> 4, c4 = q & 15;
+  for (int q = tid; q < KP * 4 * CT; q += 1024) {
+    const int r = q / (4 * CT), c4 = q % (4 * CT);
     *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) =
         *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
   }
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
   for (int h = 0; h < HTW; ++h) {
     const int q = wv + 16 * h;
     if (q >= HT) break;
-    const int mt = q >> 2, ct = q & 3;
+    const int mt = q / CT, ct = q % CT;
     f32x4 accp[2], accn[2];            // 2 chains each
 #pragma unroll
     for (int e = 0; e < 2; ++e) { accp[e] = f32x4{0.f, 0.f, 0.f, 0.f}; accn[e] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -348,84 +350,10 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
   }
 }
 
-// inv(G) for the Gram matrix G = H H^T (symmetric positive definite when H has full row rank, which
-// snmf.py:69-70 needs anyway): in-place float64 Gauss-Jordan WITHOUT pivoting -- on an SPD matrix
-// every pivot is a positive Schur complement and the elimination is as stable as Cholesky.
-// The 16 B x 16 B (identity-padded) matrix lives in REGISTERS of 256 threads (one wave per SIMD):
-// thread (ty, tx) of 16 x 16 owns rows {ty + 16 u} x columns {tx + 16 v}, u, v < B.  Per pivot only
-// the pivot row and column go through LDS (double buffered => ONE barrier per pivot), and the step is
-// ONE rank-one update for every entry: with the pivot column's entry p replaced by a_pp - 1 and the
-// scaled pivot row's entry p by 1 + 1/a_pp,
-//   a_rc - pc[r] pr[c]  gives  a_pc / a_pp (row p),  -a_rp / a_pp (column p),  1 / a_pp (corner)
-// and the ordinary Schur update elsewhere.  Pivots are taken in the order p = pl + 16 pu (pu outer,
-// unrolled), any order being as good as another for an SPD matrix, so "which of my B rows is the
-// pivot row" is a compile-time fact.  Writes float32 inv(G)^T into GinvT[ld][ld] (identity on the
-// padding) so that a B[n][k] MFMA operand reads inv[k][n].
-// 128 x 128: 153 us as 1024 threads x 16 entries with per-entry case selects -> see DESIGN 3.3.
-template <int B, int TG = 16>   // TG x TG threads, each B x B entries: matrix order TG * B
-__global__ __launch_bounds__(TG * TG) void k_inverse_spd(const double* __restrict__ Gd, int ld, int k,
-                                                         float* __restrict__ GinvT,
-                                                         double* __restrict__ Ginv64 = nullptr) {
-  constexpr int KP = TG * B;
-  __shared__ double prow[2][KP];
-  __shared__ double pcol[2][KP];
-  const int tid = threadIdx.x, tx = tid % TG, ty = tid / TG;
-  double a[B][B];
-#pragma unroll
-  for (int u = 0; u < B; ++u)
-#pragma unroll
-    for (int v = 0; v < B; ++v) {
-      const int r = ty + TG * u, c = tx + TG * v;
-      a[u][v] = (r < k && c < k) ? Gd[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
-    }
-  int step = 0;
-#pragma unroll
-  for (int pu = 0; pu < B; ++pu) {
-    for (int pl = 0; pl < TG; ++pl) {
-      const int p = pl + TG * pu;
-      if (p >= k) break;                                // identity padding: nothing to eliminate
-      const int buf = step & 1;
-      ++step;
-      if (ty == pl) {                                   // owners of row p
-#pragma unroll
-        for (int v = 0; v < B; ++v) prow[buf][tx + TG * v] = a[pu][v];
-      }
-      if (tx == pl) {                                   // owners of column p
-#pragma unroll
-        for (int u = 0; u < B; ++u) pcol[buf][ty + TG * u] = a[u][pu];
-      }
-      __syncthreads();
-      const double app = prow[buf][p];
-      const double d = pmf_rcp_f64(app);
-      double pr[B], pc[B];
-#pragma unroll
-      for (int v = 0; v < B; ++v) pr[v] = prow[buf][tx + TG * v] * d;
-#pragma unroll
-      for (int u = 0; u < B; ++u) pc[u] = -pcol[buf][ty + TG * u];
-      // the pivot's own row / column entry: p = pl + TG pu, so only register pu of the owners can be it
-      if (tx == pl) pr[pu] = 1.0 + d;
-      if (ty == pl) pc[pu] = 1.0 - app;
-#pragma unroll
-      for (int u = 0; u < B; ++u)
-#pragma unroll
-        for (int v = 0; v < B; ++v) a[u][v] = fma(pc[u], pr[v], a[u][v]);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < B; ++u)
-#pragma unroll
-    for (int v = 0; v < B; ++v) {
-      const int r = ty + TG * u, c = tx + TG * v;     // GinvT[c][r] = inv[r][c]
-      if (r < ld && c < ld) {
-        if (GinvT) GinvT[(int64_t)c * ld + r] = (r < k && c < k) ? (float)a[u][v] : (r == c ? 1.f : 0.f);
-        if (Ginv64) Ginv64[(int64_t)r * ld + c] = (r < k && c < k) ? a[u][v] : (r == c ? 1.0 : 0.0);
-      }
-    }
-}
-
-// inv(G) for matrix orders beyond k_inverse_spd's register file (num_bases > 128): the same in-place
-// Gauss-Jordan without pivoting, float64, the matrix in global memory (L2) and spread over a cooperative
-// grid.  Step p maps every entry by
+// inv(G), G = H H^T, for matrix orders beyond k_inverse_spd_mfma (pmf_inv.h; num_bases > 128): in-place
+// Gauss-Jordan without pivoting (on an SPD matrix every pivot is a positive Schur complement and the
+// elimination is as stable as Cholesky), float64, the matrix in global memory (L2) and spread over a
+// cooperative grid.  Step p maps every entry by
 //   a_rc - a_rp a_pc / a_pp  (r, c != p),   a_pc / a_pp  (row p),   -a_rp / a_pp  (column p),   1 / a_pp
 // from the state BEFORE the step, so the matrix ping-pongs between two buffers (A0 holds G on entry)
 // and ONE grid barrier per pivot is enough.  Identity padding (rows/cols >= k) is left alone: those

@@ -1,4 +1,4 @@
-"""time of one Gram-space SNMF iteration at k = n = 128 (dominated by k_inverse_spd<8>)"""
+"""time of one Gram-space SNMF iteration at k = n = 128 (k_inverse_spd_mfma is its longest kernel)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
