@@ -846,7 +846,7 @@ int launch_inverse(pmf_ctx* c) {   // dGinvD = inv(dGd), float64
 int snmf_inverse(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(launch_inverse(c));
-  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(256), 0, c->stream, c->dH,
+  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(64), 0, c->stream, c->dH,
                      (int64_t)c->np, c->np, c->KP, c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT,
                      use_csr(c) ? c->dW1 : (float*)nullptr);
   HIPCHK(c, hipGetLastError());
@@ -962,15 +962,15 @@ int snmf_gram_iteration(pmf_ctx* c) {
   c->trace_ready = false;
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(launch_inverse(c));
-  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dH, (int64_t)np, np, KP,
+  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dH, (int64_t)np, np, KP,
                      c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? c->dW1 : (float*)nullptr, c->dMTd, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   // P = M^T C  (KP x np), float64 kept for S, float32 into (P | S)
-  hipLaunchKernelGGL((k_dgemm_small<false>), dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dMTd,
+  hipLaunchKernelGGL((k_dgemm_mfma<false>), dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dMTd,
                      (int64_t)np, c->dC, (int64_t)np, np, c->dPd, (int64_t)np, c->dPS, ldp, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   // S = P M = P (M^T)^T  (KP x KP)
-  hipLaunchKernelGGL((k_dgemm_small<true>), dim3((unsigned)(KP / 16), (unsigned)(KP / 16)), dim3(256), 0, c->stream, c->dPd,
+  hipLaunchKernelGGL((k_dgemm_mfma<true>), dim3((unsigned)(KP / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dPd,
                      (int64_t)np, c->dMTd, (int64_t)np, np, (double*)nullptr, (int64_t)0, c->dPS + np, ldp, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   c->w_implicit = true;       // dW is stale from here on: W = V M with the M just formed

@@ -212,3 +212,76 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
         Ginv64[(int64_t)row * ld + col] = (row < k && col < k) ? c[t][r] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
     }
 }
+
+// ---- the k x n sized float64 products of the SNMF W step / Gram-space loop on the float64 MFMA -------
+// (M^T = inv(H H^T) H, P = M^T C, S = P M: 128 x 128 x 128 each at cfg5 -- latency-bound as 16 x 16 LDS
+// tiles on the VALU, 7 us apiece; here one wave per 16 x 16 tile takes its operands straight from L2 in
+// MFMA operand order and runs two accumulator chains.)
+// acc(16 x 16) = A[r0 .. r0+15][0 .. K) * B, B stored [K][N] (TRANSB = false) or [N][K] (TRANSB = true);
+// K a multiple of 16.  Result in C/D layout: lane l, register r <-> row (l >> 4) + 4 r, column l & 15.
+template <bool TRANSB, typename TB>
+__device__ __forceinline__ f64x4 tile_dgemm(const double* __restrict__ A, int64_t lda, const TB* __restrict__ B,
+                                            int64_t ldb, int K, int r0, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const double* ap = A + (int64_t)(r0 + i) * lda + g;                                  // A[r0 + i][4 s + g]
+  const TB* bp = TRANSB ? B + (int64_t)(c0 + i) * ldb + g : B + (int64_t)g * ldb + c0 + i;   // B[4 s + g][c0 + i]
+  const int64_t bstep = TRANSB ? 4 : 4 * ldb;
+  f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+  for (int s0 = 0; s0 < K / 4; s0 += 4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = ap[4 * (s0 + u)]; b[u] = (double)bp[(int64_t)(s0 + u) * bstep]; }
+    acc0 = mfma_f64(a[0], b[0], acc0);
+    acc1 = mfma_f64(a[1], b[1], acc1);
+    acc0 = mfma_f64(a[2], b[2], acc0);
+    acc1 = mfma_f64(a[3], b[3], acc1);
+  }
+  return acc0 + acc1;
+}
+
+// C[M x N] = A[M x K] B (float64); writes the float64 result (Cd) and/or its float32 rounding (Cf).
+// grid = (N / 16, M / 16), 64 threads.
+template <bool TRANSB>
+__global__ __launch_bounds__(64) void k_dgemm_mfma(const double* __restrict__ A, int64_t lda,
+                                                   const double* __restrict__ B, int64_t ldb, int K,
+                                                   double* __restrict__ Cd, int64_t ldcd,
+                                                   float* __restrict__ Cf, int64_t ldcf,
+                                                   const int* __restrict__ stop) {
+  if (stop != nullptr && *stop != 0) return;
+  const int lane = threadIdx.x, c0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
+  const f64x4 acc = tile_dgemm<TRANSB, double>(A, lda, B, ldb, K, r0, c0, lane);
+  const int col = c0 + (lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = r0 + g + 4 * r;
+    if (Cd) Cd[row * ldcd + col] = acc[r];
+    if (Cf) Cf[row * ldcf + col] = (float)acc[r];
+  }
+}
+
+// SNMF W step, reassociated:  W = (V H^T) inv(H H^T) = V M^T  with  M^T = inv(H H^T) H  (k x n).
+// H H^T of a square-ish H is ill-conditioned (k = n = 128, uniform H: cond ~ 1e7); multiplying a
+// float32 V H^T by a float32 copy of the inverse loses cond * 1e-7 of W -- the reference's own
+// all-float32 path is off by 2-12 % there.  M^T is a k x n matrix: it is formed
+// HERE in float64 from the float64 inverse and only then rounded, so the big product V M^T sees
+// operands that are exact to float32 rounding and nothing is amplified; it also drops the m k^2
+// product from the pass.  Writes MT [KP][np] float32 (dense kernels: the "H" operand), M [np][KP]
+// float32 (CSR kernels gather rows of it) and MTd float64 (Gram-space loop); any may be null.
+// grid = (np / 16, KP / 16), 64 threads.
+__global__ __launch_bounds__(64) void k_snmf_mt(const float* __restrict__ H, int64_t ldh, int np, int KP,
+                                                const double* __restrict__ Ginv64, float* __restrict__ MT,
+                                                float* __restrict__ M, double* __restrict__ MTd = nullptr,
+                                                const int* __restrict__ stop = nullptr) {
+  if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep M
+  const int lane = threadIdx.x, col0 = blockIdx.x * 16, kp0 = blockIdx.y * 16;
+  const f64x4 acc = tile_dgemm<false, float>(Ginv64, KP, H, ldh, KP, kp0, col0, lane);
+  const int col = col0 + (lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = kp0 + g + 4 * r;
+    if (MT) MT[row * np + col] = (float)acc[r];
+    if (MTd) MTd[row * np + col] = acc[r];
+    if (M) M[(int64_t)col * KP + row] = (float)acc[r];
+  }
+}

@@ -385,71 +385,6 @@ __global__ __launch_bounds__(1024) void k_inverse_spd_big(double* A0, double* A1
   for (int64_t q = gtid; q < E; q += gsize) Ginv64[q] = A[q];
 }
 
-// SNMF W step, reassociated:  W = (V H^T) inv(H H^T) = V M^T  with  M^T = inv(H H^T) H  (k x n).
-// H H^T of a square-ish H is ill-conditioned (k = n = 128, uniform H: cond ~ 1e7); multiplying a
-// float32 V H^T by a float32 copy of the inverse loses cond * 1e-7 of W -- the reference's own
-// all-float32 path is off by 2-12 % there.  M^T is a k x n matrix: it is formed
-// HERE in float64 from the float64 inverse and only then rounded, so the big product V M^T sees
-// operands that are exact to float32 rounding and nothing is amplified; it also drops the m k^2
-// product from the pass.  Writes both layouts: MT [KP][np] (dense kernels: the "H" operand) and
-// M [np][KP] (CSR kernels gather rows of it).  grid = (np / 16, KP / 16), 256 threads.
-__global__ __launch_bounds__(256) void k_snmf_mt(const float* __restrict__ H, int64_t ldh, int np, int KP,
-                                                 const double* __restrict__ Ginv64, float* __restrict__ MT,
-                                                 float* __restrict__ M, double* __restrict__ MTd = nullptr,
-                                                 const int* __restrict__ stop = nullptr) {
-  if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep M
-  __shared__ double gs[16][17];    // inv[kp0 + r][k0 + c]
-  __shared__ double hs[16][17];    // H[k0 + r][col0 + c]
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int col0 = blockIdx.x * 16, kp0 = blockIdx.y * 16;
-  double s = 0.0;                  // MT[kp0 + ty][col0 + tx]
-  for (int k0 = 0; k0 < KP; k0 += 16) {
-    gs[ty][tx] = Ginv64[(int64_t)(kp0 + ty) * KP + k0 + tx];
-    hs[ty][tx] = (double)H[(int64_t)(k0 + ty) * ldh + col0 + tx];
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) s = fma(gs[ty][kk], hs[kk][tx], s);
-    __syncthreads();
-  }
-  const float r = (float)s;
-  if (MT) MT[(int64_t)(kp0 + ty) * np + col0 + tx] = r;
-  if (MTd) MTd[(int64_t)(kp0 + ty) * np + col0 + tx] = s;
-  if (M) {                         // transposed through LDS so that both stores are row-contiguous
-    gs[ty][tx] = s;
-    __syncthreads();
-    M[(int64_t)(col0 + ty) * KP + kp0 + tx] = (float)gs[tx][ty];
-  }
-}
-
-// Small float64 product for the k x n sized algebra of the Gram-space SNMF loop:
-//   C[M x N] = A[M x K] B,  B stored [K x N] (TRANSB = false) or [N x K] (TRANSB = true);
-// all dimensions multiples of 16, 16 x 16 tiles through LDS, grid = (N / 16, M / 16), 256 threads.
-// Writes the float64 result (Cd) and/or its float32 rounding (Cf); either may be null.
-template <bool TRANSB>
-__global__ __launch_bounds__(256) void k_dgemm_small(const double* __restrict__ A, int64_t lda,
-                                                     const double* __restrict__ B, int64_t ldb, int K,
-                                                     double* __restrict__ Cd, int64_t ldcd,
-                                                     float* __restrict__ Cf, int64_t ldcf,
-                                                     const int* __restrict__ stop) {
-  if (stop != nullptr && *stop != 0) return;
-  __shared__ double as[16][17];
-  __shared__ double bs[16][17];    // bs[kk][col]
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int c0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
-  double s = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    as[ty][tx] = A[(int64_t)(r0 + ty) * lda + k0 + tx];
-    if (TRANSB) bs[tx][ty] = B[(int64_t)(c0 + ty) * ldb + k0 + tx];
-    else bs[ty][tx] = B[(int64_t)(k0 + ty) * ldb + c0 + tx];
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) s = fma(as[ty][kk], bs[kk][tx], s);
-    __syncthreads();
-  }
-  if (Cd) Cd[(int64_t)(r0 + ty) * ldcd + c0 + tx] = s;
-  if (Cf) Cf[(int64_t)(r0 + ty) * ldcf + c0 + tx] = (float)s;
-}
-
 // out = a + b over count floats (count a multiple of 4): RNMF's S = D + V for pmf_rnmf_get_s_f32.
 __global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ a, const float* __restrict__ b, int64_t count,
                                                  float* __restrict__ out) {
