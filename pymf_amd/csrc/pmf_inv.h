@@ -219,19 +219,30 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
 // MFMA operand order and runs two accumulator chains.)
 // acc(16 x 16) = A[r0 .. r0+15][0 .. K) * B, B stored [K][N] (TRANSB = false) or [N][K] (TRANSB = true);
 // K a multiple of 16.  Result in C/D layout: lane l, register r <-> row (l >> 4) + 4 r, column l & 15.
-template <bool TRANSB, typename TB>
-__device__ __forceinline__ f64x4 tile_dgemm(const double* __restrict__ A, int64_t lda, const TB* __restrict__ B,
+template <bool TRANSB, typename TB, typename TA = double>
+__device__ __forceinline__ f64x4 tile_dgemm(const TA* __restrict__ A, int64_t lda, const TB* __restrict__ B,
                                             int64_t ldb, int K, int r0, int c0, int lane) {
   const int i = lane & 15, g = lane >> 4;
-  const double* ap = A + (int64_t)(r0 + i) * lda + g;                                  // A[r0 + i][4 s + g]
+  const TA* ap = A + (int64_t)(r0 + i) * lda + g;                                      // A[r0 + i][4 s + g]
   const TB* bp = TRANSB ? B + (int64_t)(c0 + i) * ldb + g : B + (int64_t)g * ldb + c0 + i;   // B[4 s + g][c0 + i]
   const int64_t bstep = TRANSB ? 4 : 4 * ldb;
   f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-  for (int s0 = 0; s0 < K / 4; s0 += 4) {
+  // 16 k-steps per round: their 32 loads are in flight together (one L2 round trip per 64 columns of K)
+  int s0 = 0;
+  for (; s0 + 16 <= K / 4; s0 += 16) {
+    double a[16], b[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { a[u] = (double)ap[4 * (s0 + u)]; b[u] = (double)bp[(int64_t)(s0 + u) * bstep]; }
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+      acc0 = mfma_f64(a[u], b[u], acc0);
+      acc1 = mfma_f64(a[u + 1], b[u + 1], acc1);
+    }
+  }
+  for (; s0 < K / 4; s0 += 4) {
     double a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = ap[4 * (s0 + u)]; b[u] = (double)bp[(int64_t)(s0 + u) * bstep]; }
+    for (int u = 0; u < 4; ++u) { a[u] = (double)ap[4 * (s0 + u)]; b[u] = (double)bp[(int64_t)(s0 + u) * bstep]; }
     acc0 = mfma_f64(a[0], b[0], acc0);
     acc1 = mfma_f64(a[1], b[1], acc1);
     acc0 = mfma_f64(a[2], b[2], acc0);
@@ -283,5 +294,37 @@ __global__ __launch_bounds__(64) void k_snmf_mt(const float* __restrict__ H, int
     if (MT) MT[row * np + col] = (float)acc[r];
     if (MTd) MTd[row * np + col] = acc[r];
     if (M) M[(int64_t)col * KP + row] = (float)acc[r];
+  }
+}
+
+// G = H H^T (KP x KP, contraction over the np columns; float32 H, float64 products and sums).
+// grid = (KP / 16, KP / 16), 256 threads: wave w of the four takes the columns [w np / 4, (w + 1) np / 4)
+// (np is a multiple of 64), the four partial tiles are added in wave order.
+// Gf: float32 copy (MFMA operand), Gd: float64 copy (SNMF inverse, NMFALS Hessian); rows / columns >= k
+// (padding) get `pad_diag` on the diagonal and 0 elsewhere.
+__global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64_t ldh, int np,
+                                              int KP, int k, double pad_diag,
+                                              float* __restrict__ Gf, double* __restrict__ Gd) {
+  __shared__ double part[3][4][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ra = blockIdx.x * 16, rb = blockIdx.y * 16;
+  const int kq = np / 4;
+  f64x4 acc = tile_dgemm<true, float, float>(H + wv * kq, ldh, H + wv * kq, ldh, kq, ra, rb, lane);
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wv - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    const int gb = rb + (lane & 15), g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
+      const int ga = ra + g + 4 * r;
+      if (ga >= k || gb >= k) v = (ga == gb) ? pad_diag : 0.0;
+      Gf[(int64_t)ga * KP + gb] = (float)v;
+      if (Gd) Gd[(int64_t)ga * KP + gb] = v;
+    }
   }
 }

@@ -3,36 +3,6 @@
 #include <hip/hip_cooperative_groups.h>
 #include "pmf_dev.h"
 
-// G = H H^T (KP x KP, contraction over np columns), float64 accumulation.
-// grid = (KP/16, KP/16), block = 256: thread (a = tid>>4, b = tid&15) of tile (bx, by).
-// Gf: float32 copy (MFMA operand), Gd: float64 copy (SNMF inverse, NMFALS Hessian).
-// Rows/cols >= k (padding) get `pad_diag` on the diagonal and 0 elsewhere.
-__global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64_t ldh, int np,
-                                              int KP, int k, double pad_diag,
-                                              float* __restrict__ Gf, double* __restrict__ Gd) {
-  __shared__ float ha[16][65];
-  __shared__ float hb[16][65];
-  const int tid = threadIdx.x;
-  const int a = tid >> 4, b = tid & 15;
-  const int ra = blockIdx.x * 16, rb = blockIdx.y * 16;
-  double acc = 0.0;
-  for (int c0 = 0; c0 < np; c0 += 64) {
-    for (int q = tid; q < 16 * 64; q += 256) {
-      const int r = q >> 6, c = q & 63;
-      ha[r][c] = H[(int64_t)(ra + r) * ldh + c0 + c];
-      hb[r][c] = H[(int64_t)(rb + r) * ldh + c0 + c];
-    }
-    __syncthreads();
-#pragma unroll 16
-    for (int c = 0; c < 64; ++c) acc = fma((double)ha[a][c], (double)hb[b][c], acc);
-    __syncthreads();
-  }
-  const int ga = ra + a, gb = rb + b;
-  if (ga >= k || gb >= k) acc = (ga == gb) ? pad_diag : 0.0;
-  Gf[(int64_t)ga * KP + gb] = (float)acc;
-  if (Gd) Gd[(int64_t)ga * KP + gb] = acc;
-}
-
 // NMF H step (pymf/nmf.py:122-126): H <- (H * P) / (S H + 1e-9), P = W^T V, S = W^T W.
 // PS: [KP][np + KP] (P | S).  One block per 16 columns of H; in place.
 // mode 1: BNMF rule (bnmf.py:79-82) H *= (P + 3 l H^2) / (S H + 2 l H^3 + l H + 1e-9).
