@@ -162,6 +162,8 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
       }
       store_tile(pR[bi], rj);
     }
+    f64x4 ap = {0.0, 0.0, 0.0, 0.0};
+    if (bi != p) ap = load_tile(pold[p & 1][bi]);                // (A_pi)^T, the A operand of this step's updates: at hand since the first barrier
     __syncthreads();                           // R_j are in place
     if (bi == p) {                             // these waves have no update to do in this step ...
       if (j0 == 0 && la < nsteps) {            // ... so one of them inverts the look-ahead tile
@@ -172,7 +174,6 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
       for (int t = 0; t < 4; ++t) c[t] = (j0 + t == p) ? D : load_tile(pR[j0 + t]);   // new row panel
     } else {
       const double msig = (bi < p) ? 1.0 : -1.0;                 // -sigma_i
-      f64x4 ap = load_tile(pold[p & 1][bi]);                     // (A_pi)^T as A operand, times -sigma_i
 #pragma unroll
       for (int s = 0; s < 4; ++s) ap[s] *= msig;
       // Straight-line over the four tiles (the special cases are operand choices, not branches), so that the
