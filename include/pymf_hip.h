@@ -46,7 +46,8 @@ enum {
   PMF_EINVAL = -1,   /* bad argument / unsupported shape / call order */
   PMF_EHIP = -2,     /* a HIP runtime call failed */
   PMF_ENCCL = -3,    /* an RCCL call failed */
-  PMF_ENOMEM = -4    /* device or host allocation failed */
+  PMF_ENOMEM = -4,   /* device or host allocation failed */
+  PMF_ESINGULAR = -5 /* SNMF: H H^T is singular (the reference's np.linalg.inv raises LinAlgError, snmf.py:69) */
 };
 
 enum { PMF_ALGO_NMF = 0, PMF_ALGO_NMFALS = 1, PMF_ALGO_SNMF = 2, PMF_ALGO_BNMF = 3, PMF_ALGO_RNMF = 4 };

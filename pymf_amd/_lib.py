@@ -17,7 +17,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PMF_LIB") or os.path.join(_HERE, "csrc", "libpymf_hip.so")   # PMF_LIB: A/B builds
 
-PMF_OK, PMF_EINVAL, PMF_EHIP, PMF_ENCCL, PMF_ENOMEM = 0, -1, -2, -3, -4
+PMF_OK, PMF_EINVAL, PMF_EHIP, PMF_ENCCL, PMF_ENOMEM, PMF_ESINGULAR = 0, -1, -2, -3, -4, -5
 ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF, ALGO_RNMF = 0, 1, 2, 3, 4
 COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
 STREAM_RESID = 8
@@ -99,6 +99,8 @@ def load():
 
 
 def check(rc, ctx=None):
+    if rc == PMF_ESINGULAR:                 # what the reference's np.linalg.inv raises (snmf.py:69)
+        raise np.linalg.LinAlgError("Singular matrix")
     if rc != PMF_OK:
         msg = load().pmf_last_error(ctx)
         err = PmfError("libpymf_hip error %d: %s" % (rc, (msg or b"").decode("utf-8", "replace")))

@@ -89,6 +89,7 @@ struct pmf_ctx {
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
   bool v_csr = false;
   bool csr_dense = false;       // CSR data with num_bases > 128: a dense image in dV serves the data paths (no CSR kernel at that width)
+  int* dSing = nullptr;         // SNMF: raised by the inverse kernels when H H^T has a zero pivot (check_singular)
   double* dQp = nullptr;        // k_nnqp_big (NMFALS, num_bases > 64): per-workgroup inverse images
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
@@ -818,11 +819,24 @@ int nmf_fused_iteration(pmf_ctx* c) {
 // ---- SNMF -----------------------------------------------------------------------------------
 // inv(H H^T) in float64 (Gauss-Jordan in registers, identity on the padding), then M^T = inv(H H^T) H in
 // float64, rounded once: dMT [KP][np] for the dense kernels, dW1 = M [np][KP] for the CSR kernels.
+// snmf.py:69: np.linalg.inv raises LinAlgError("Singular matrix") on a zero pivot; the inverse kernels raise
+// dSing instead, read back wherever the host synchronises anyway (end of pmf_update_w / pmf_factorize / a streamed pass).
+int check_singular(pmf_ctx* c) {
+  if (c->algo != PMF_ALGO_SNMF || !c->dSing) return PMF_OK;
+  int flag = 0;
+  HIPCHK(c, hipMemcpyAsync(&flag, c->dSing, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!flag) return PMF_OK;
+  HIPCHK(c, hipMemsetAsync(c->dSing, 0, sizeof(int), c->stream));
+  return fail(c, PMF_ESINGULAR, "SNMF: H H^T is singular (the reference's np.linalg.inv raises LinAlgError, snmf.py:69)");
+}
+
 int launch_inverse(pmf_ctx* c) {   // dGinvD = inv(dGd), float64
+  if (!c->dSing) PMFCHK(dalloc(c, &c->dSing, 1));
   if (c->KP <= 64) {                       // blocked Gauss-Jordan on the float64 MFMA (pmf_inv.h)
-    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvD, c->stop_arg);
+    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvD, c->stop_arg, c->dSing);
   } else if (c->KP <= 128) {
-    hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvD, c->stop_arg);
+    hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dGinvD, c->stop_arg, c->dSing);
   } else {                         // num_bases > 128: the matrix in L2, a cooperative grid (k_inverse_spd_big)
     const size_t E = (size_t)c->KP * c->KP;
     if (!c->dInvA) { PMFCHK(dalloc(c, &c->dInvA, E)); PMFCHK(dalloc(c, &c->dInvB, E)); }
@@ -835,7 +849,8 @@ int launch_inverse(pmf_ctx* c) {   // dGinvD = inv(dGd), float64
     double *a_ = c->dInvA, *b_ = c->dInvB, *o_ = c->dGinvD;
     int kp_ = c->KP, k_ = c->k;
     const int* stop_ = c->stop_arg;
-    void* args[] = {&a_, &b_, &kp_, &k_, &o_, &stop_};
+    int* sing_ = c->dSing;
+    void* args[] = {&a_, &b_, &kp_, &k_, &o_, &stop_, &sing_};
     HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_inverse_spd_big), dim3(wgs), dim3(1024), args, 0,
                                          c->stream));
   }
@@ -1494,7 +1509,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing})
     if (p) hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) hipEventDestroy(e);
@@ -1585,9 +1600,22 @@ int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
   return PMF_OK;
 }
 
+// The padding of W ([mp][KP]) and H ([KP][np]) is zero by construction and stays zero under every update
+// rule -- unless a factor went non-finite (0 * nan = nan), e.g. behind a singular H H^T.  A fresh factor
+// from the host therefore comes with fresh padding.
+static int zero_padding(pmf_ctx* c, float* buf, int64_t ld, int64_t rows_total, int64_t rows_valid, int64_t cols_valid) {
+  if (ld > cols_valid && rows_valid > 0)
+    HIPCHK(c, hipMemset2DAsync(buf + cols_valid, (size_t)ld * sizeof(float), 0, (size_t)(ld - cols_valid) * sizeof(float),
+                               (size_t)rows_valid, c->stream));
+  if (rows_total > rows_valid)
+    HIPCHK(c, hipMemsetAsync(buf + rows_valid * ld, 0, (size_t)(rows_total - rows_valid) * ld * sizeof(float), c->stream));
+  return PMF_OK;
+}
+
 int pmf_set_w_f32(pmf_ctx* c, const float* W) {
   if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(zero_padding(c, c->dW, c->KP, c->mp, c->m, c->k));
   PMFCHK(upload_padded(c, c->dW, c->KP, W, c->k, c->m, c->k));
   c->have_w = true; c->ps_valid = false; c->w_implicit = false;
   return PMF_OK;
@@ -1601,6 +1629,7 @@ int pmf_get_w_f32(pmf_ctx* c, float* W) {
 int pmf_set_h_f32(pmf_ctx* c, const float* H) {
   if (!c || !H) return fail(c, PMF_EINVAL, "pmf_set_h_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(zero_padding(c, c->dH, c->np, c->KP, c->k, c->n));
   PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
   c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
   return PMF_OK;
@@ -1615,7 +1644,7 @@ int pmf_update_w(pmf_ctx* c) {
   PMFCHK(need(c, true, true, true));
   PMFCHK(do_update_w(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return PMF_OK;
+  return check_singular(c);
 }
 int pmf_update_h(pmf_ctx* c) {
   PMFCHK(need(c, true, true, true));
@@ -1780,7 +1809,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   c->last_loop_ms = ms;
   if (ce) for (int q = done; q < niter; ++q) ferr[q] = 0.0;   // as np.zeros(niter) leaves them (nmf.py:179-180)
   if (iters_done) *iters_done = done;
-  return PMF_OK;
+  return check_singular(c);
 }
 
 int pmf_set_lambda(pmf_ctx* c, double lamb_w, double lamb_h) {
@@ -1991,7 +2020,7 @@ int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
     *ferr = std::sqrt(e2 > 0.0 ? e2 : 0.0);
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return PMF_OK;
+  return check_singular(c);
 }
 
 int pmf_nndsvd_init(pmf_ctx* c, int32_t* rank_found) {

@@ -85,7 +85,8 @@ __device__ __forceinline__ void inv16_wave(const double* __restrict__ src, doubl
 template <int NBLK>   // matrix order 16 NBLK (identity padded beyond k): 4 -> 64, 8 -> 128
 __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
                                                                              double* __restrict__ Ginv64,
-                                                                             const int* __restrict__ stop) {
+                                                                             const int* __restrict__ stop,
+                                                                             int* __restrict__ singular = nullptr) {
   if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep the inverse
   constexpr int CW = NBLK / 4;                 // waves per block row
   constexpr int KP = 16 * NBLK;
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
       }
     }
   }
+  bool bad = false;                            // a zero pivot (LAPACK's "singular matrix") leaves inf / nan behind
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * bi + g + 4 * r, col = 16 * (j0 + t) + cc;
-      if (row < ld && col < ld)
-        Ginv64[(int64_t)row * ld + col] = (row < k && col < k) ? c[t][r] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
+      const double v = (row < k && col < k) ? c[t][r] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
+      bad |= !(fabs(v) <= 1.7e308);
+      if (row < ld && col < ld) Ginv64[(int64_t)row * ld + col] = v;
     }
+  if (singular != nullptr && __ballot(bad) != 0ull && lane == 0) *singular = 1;
 }
 
 // ---- the k x n sized float64 products of the SNMF W step / Gram-space loop on the float64 MFMA -------

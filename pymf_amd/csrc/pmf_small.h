@@ -330,7 +330,8 @@ __global__ __launch_bounds__(1024) void k_snmf_h_mfma(float* __restrict__ H, int
 // pivots are 1 with zero row and column.  The result ends in Ginv64.
 __global__ __launch_bounds__(1024) void k_inverse_spd_big(double* A0, double* A1, int KP, int k,
                                                           double* __restrict__ Ginv64,
-                                                          const int* __restrict__ stop) {
+                                                          const int* __restrict__ stop,
+                                                          int* __restrict__ singular) {
   if (stop != nullptr && *stop != 0) return;          // uniform over the grid: nobody reaches a barrier
   cooperative_groups::grid_group grid = cooperative_groups::this_grid();
   const int64_t gtid = (int64_t)blockIdx.x * 1024 + threadIdx.x, gsize = (int64_t)gridDim.x * 1024;
@@ -352,7 +353,9 @@ __global__ __launch_bounds__(1024) void k_inverse_spd_big(double* A0, double* A1
     grid.sync();
     { double* x = A; A = An; An = x; }
   }
-  for (int64_t q = gtid; q < E; q += gsize) Ginv64[q] = A[q];
+  bool bad = false;                                   // a zero pivot leaves inf / nan behind
+  for (int64_t q = gtid; q < E; q += gsize) { const double v = A[q]; bad |= !(fabs(v) <= 1.7e308); Ginv64[q] = v; }
+  if (singular != nullptr && bad) *singular = 1;
 }
 
 // out = a + b over count floats (count a multiple of 4): RNMF's S = D + V for pmf_rnmf_get_s_f32.

@@ -314,10 +314,15 @@ class NMF(object):
     def update_w(self):                                        # nmf.py:128-132
         ctx = self._sync_to_device()
         rows = self._stream_rows()
-        if rows:
-            self._stream_iteration(ctx, rows, True, False, False)
-        else:
-            ctx.update_w()
+        try:
+            if rows:
+                self._stream_iteration(ctx, rows, True, False, False)
+            else:
+                ctx.update_w()
+        except Exception:                                      # e.g. SNMF: LinAlgError behind a singular H H^T
+            self._w_fp = self._h_fp = None                     # the host arrays go up again with the next call
+            self._host_stale.clear()
+            raise
         self._pull(ctx, True, False)
 
     def converged(self, i):                                    # nmf.py:134-139
@@ -367,8 +372,15 @@ class NMF(object):
                     self.ferr = self.ferr[:conv_at]
             return
         else:
-            ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
-                                                conv_eps=self._EPS)
+            try:
+                ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
+                                                    conv_eps=self._EPS)
+            except Exception:
+                # the device factors are in an unknown state (e.g. behind a singular H H^T): the host arrays
+                # are what the object holds, and they go up again with the next call
+                self._w_fp = self._h_fp = None
+                self._host_stale.clear()
+                raise
         self._last_iters = done
         self._pull(ctx, compute_w and done > 0, compute_h and done > 0)
 

@@ -80,6 +80,7 @@ def test_bad_arguments_return_einval(lib):
     """pmf_ctx_create validates its arguments BEFORE it touches a device, so the status is PMF_EINVAL
     with or without a GPU -- and a valid shape without a GPU is PMF_EHIP, not EINVAL."""
     lib.load()
+    assert (lib.PMF_OK, lib.PMF_EINVAL, lib.PMF_EHIP, lib.PMF_ENCCL, lib.PMF_ENOMEM, lib.PMF_ESINGULAR) == (0, -1, -2, -3, -4, -5)
     assert _create_code(lib, lib.ALGO_NMF, 0, 4, 2) == lib.PMF_EINVAL          # m < 1
     assert _create_code(lib, lib.ALGO_NMF, 4, 0, 2) == lib.PMF_EINVAL          # n < 1
     assert _create_code(lib, lib.ALGO_NMF, 4, 4, 0) == lib.PMF_EINVAL          # k < 1

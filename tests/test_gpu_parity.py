@@ -1059,3 +1059,26 @@ def test_fused8_rnmf_free_run_and_reproducibility(pm):
         np.testing.assert_array_equal(a[0], b_[0])
         np.testing.assert_array_equal(a[1], b_[1])
         np.testing.assert_allclose(a[2], b_[2], rtol=1e-12)
+
+
+def test_snmf_singular_gram_raises_linalgerror(pm):
+    """snmf.py:69: np.linalg.inv(H H^T) raises LinAlgError('Singular matrix') when H has a zero row; so do the
+    device inverses (a zero pivot, reported through PMF_ESINGULAR), hook by hook and from factorize()."""
+    rs = np.random.RandomState(2)
+    V = (rs.random_sample((300, 40)) - 0.3).astype(np.float32)
+    for k in (5, 70, 150):                                      # k_inverse_spd_mfma<4>, <8>, k_inverse_spd_big
+        n = 40 if k <= 40 else 200
+        Vk = V if n == 40 else (rs.random_sample((300, n)) - 0.3).astype(np.float32)
+        H0 = rs.random_sample((k, n))
+        H0[k // 2] = 0.0
+        mdl = pm.SNMF(Vk, num_bases=k)
+        mdl.W, mdl.H = rs.random_sample((300, k)), H0.copy()
+        with pytest.raises(np.linalg.LinAlgError):
+            mdl.update_w()
+        mdl = pm.SNMF(Vk, num_bases=k)
+        mdl.W, mdl.H = rs.random_sample((300, k)), H0.copy()
+        with pytest.raises(np.linalg.LinAlgError):
+            mdl.factorize(niter=2)
+        mdl.H = rs.random_sample((k, n))                        # the object stays usable
+        mdl.factorize(niter=2)
+        assert np.isfinite(mdl.W).all() and np.isfinite(mdl.ferr).all()
