@@ -246,27 +246,44 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
     for (int st = 0; st < ST; ++st) S[mt][st] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int64_t r = r_begin; r < r_end; r += 16) {
-    float af[NT][4], bf[4][4];
+  // The operands of a 16-row step come straight from L2/HBM (full-width vector loads, no LDS): the loads of
+  // step r + 16 are issued BEFORE the MFMAs of step r, so a load has one step's MFMAs (512 cycles at NT = 4)
+  // plus the other waves' to come back instead of stalling the step it belongs to.
+  struct Operands {
+    f32x4 w[NT >= 4 ? NT / 4 : 1][4];     // W rows r + 4 kq + j: bases NT i .. NT i + NT - 1
+    f32x4 v[4];                           // V rows r + 4 kq + j: columns c0 + 4 i .. + 3
+  };
+  auto fetch = [&](int64_t r, Operands& o) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t row = r + 4 * kq + j;   // k index of MFMA step j for this lane group
-      const float* wr = W + row * ldw + NT * i;         // bases NT*i .. NT*i + NT-1
+      const float* wr = W + row * ldw + NT * i;
       if (NT >= 4) {
 #pragma unroll
-        for (int q = 0; q < NT / 4; ++q) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) af[4 * q + e][j] = w4[e];
-        }
+        for (int q = 0; q < NT / 4; ++q) o.w[q][j] = *reinterpret_cast<const f32x4*>(wr + 4 * q);
       } else {
+        f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < NT; ++e) af[e][j] = wr[e];
+        for (int e = 0; e < NT; ++e) w4[e] = wr[e];
+        o.w[0][j] = w4;
       }
-      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
-      if (pact) v4 = *reinterpret_cast<const f32x4*>(V + row * ldv + c0 + 4 * i);   // columns 4i..4i+3
+      o.v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pact) o.v[j] = *reinterpret_cast<const f32x4*>(V + row * ldv + c0 + 4 * i);
+    }
+  };
+  Operands cur, nxt;
+  if (r_begin < r_end) fetch(r_begin, cur);
+  for (int64_t r = r_begin; r < r_end; r += 16) {
+    const bool more = r + 16 < r_end;
+    if (more) fetch(r + 16, nxt);
+    __builtin_amdgcn_sched_barrier(0);      // keep the requests ahead of this step's MFMAs
+    float af[NT][4], bf[4][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bf[e][j] = v4[e];
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int e = 0; e < NT; ++e) af[e][j] = cur.w[e / 4][j][e % 4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bf[e][j] = cur.v[j][e];
     }
     if (pact) {
 #pragma unroll
@@ -291,6 +308,7 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
             S[mt][st] = mfma16(af[mt][j], b, S[mt][st]);
           }
     }
+    if (more) cur = nxt;
   }
 
   // tile (mt, nt), lane (c = i, q = kq), register jj  <->  base NT*(4q + jj) + mt,  column 4c + nt
