@@ -192,13 +192,13 @@ void stat_begin(pmf_ctx* c, int site) {
       s.ev.push_back(e);
     }
   }
-  hipEventRecord(s.ev[s.used], c->stream);
+  (void)hipEventRecord(s.ev[s.used], c->stream);   // profiling aid: a failed record only loses a sample
 }
 void stat_end(pmf_ctx* c, int site) {
   if (!c->profile || c->stat.site != site) return;
   KernelStat& s = c->stat;
   if (s.used + 2 > s.ev.size()) return;
-  hipEventRecord(s.ev[s.used + 1], c->stream);
+  (void)hipEventRecord(s.ev[s.used + 1], c->stream);
   s.used += 2;
 }
 
@@ -1500,24 +1500,24 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
 
 int pmf_ctx_destroy(pmf_ctx* c) {
   if (!c) return PMF_OK;
-  hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
-  if (c->comm) ncclCommDestroy(c->comm);
+  (void)hipSetDevice(c->device);   // teardown: there is nobody to report a failing release to
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
   for (void* p : {(void*)c->dV, (void*)c->dW, (void*)c->dH, (void*)c->dG, (void*)c->dPS, (void*)c->dSlab,
                   (void*)c->dW1, (void*)c->dGinvT, (void*)c->dD, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
                   (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing})
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
-    if (e) hipEventDestroy(e);
-  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-  for (hipEvent_t e : c->stat.ev) hipEventDestroy(e);
-  if (c->ev0) hipEventDestroy(c->ev0);
-  if (c->ev1) hipEventDestroy(c->ev1);
-  if (c->stream) hipStreamDestroy(c->stream);
+    if (e) (void)hipEventDestroy(e);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  for (hipEvent_t e : c->stat.ev) (void)hipEventDestroy(e);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return PMF_OK;
 }
@@ -1541,7 +1541,7 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
     return fail(c, PMF_EINVAL, "pmf_set_v_csr_f32: bad arguments");
   if (c->algo != PMF_ALGO_SNMF) return fail(c, PMF_EINVAL, "CSR input is only wired for SNMF");
   HIPCHK(c, hipSetDevice(c->device));
-  for (void* p : {(void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals}) if (p) hipFree(p);
+  for (void* p : {(void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals}) if (p) HIPCHK(c, hipFree(p));
   c->dIndptr = nullptr; c->dIndices = nullptr; c->dVals = nullptr;
   PMFCHK(dalloc(c, &c->dIndptr, (size_t)c->mp + 1));
   PMFCHK(dalloc(c, &c->dIndices, (size_t)nnz));
