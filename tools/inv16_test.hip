@@ -8,11 +8,11 @@ __global__ void k(const double* A, double* out) {
   __shared__ double src[256], dst[256];
   __shared__ __attribute__((aligned(32))) double line[64];
   const int lane = threadIdx.x, g = lane >> 4, cc = lane & 15;
-  for (int r = 0; r < 4; ++r) src[r * 64 + lane] = A[(g + 4 * r) * 16 + cc];
+  for (int r = 0; r < 4; ++r) src[tile_lds_index(g + 4 * r, cc)] = A[(g + 4 * r) * 16 + cc];
   __syncthreads();
   inv16_wave(src, dst, line, lane);
   __syncthreads();
-  for (int r = 0; r < 4; ++r) out[(g + 4 * r) * 16 + cc] = dst[r * 64 + lane];
+  for (int r = 0; r < 4; ++r) out[(g + 4 * r) * 16 + cc] = dst[tile_lds_index(g + 4 * r, cc)];
 }
 int main() {
   double H[16][40], A[256], I[256];
