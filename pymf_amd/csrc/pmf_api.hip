@@ -85,6 +85,11 @@ struct pmf_ctx {
   int* dStop = nullptr;         // [0] 0 run / 1 converged / 2 identity cancels, [1] iteration
   int* dWarm = nullptr;         // k_nnqp: warm start allowed (k_spd_unique)
   const int* stop_arg = nullptr;   // what the loop kernels get: dStop while free-running, else NULL
+  // free-running loop: the error / convergence test of iteration conv_iter (>= 0) is still to be evaluated, from
+  // conv_ntt pairs of trace terms at conv_tt; the next one-pass launch does it in its prologue (FusedCtl)
+  int conv_iter = -1, conv_ntt = 0;
+  const double* conv_tt = nullptr;
+  double conv_eps = 0.0;
   // CSR V (SNMF sparse path)
   int64_t* dIndptr = nullptr; int32_t* dIndices = nullptr; float* dVals = nullptr; int64_t nnz = 0;
   bool v_csr = false;
@@ -292,6 +297,21 @@ int allreduce_sum(pmf_ctx* c, void* p, size_t count, bool f64) {
 bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != nullptr; }
 
 int allreduce_ps(pmf_ctx* c) { return allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false); }
+
+// What a one-pass launch needs to know about the free-running loop around it; hands over (and clears) the
+// pending convergence test.
+FusedCtl take_fused_ctl(pmf_ctx* c) {
+  FusedCtl ctl{};
+  ctl.stop = c->stop_arg ? c->dStop : nullptr;
+  ctl.conv_iter = -1;
+  if (ctl.stop && c->conv_iter >= 0) {
+    ctl.tt = c->conv_tt; ctl.ntt = c->conv_ntt; ctl.ferr = c->dFerr;
+    ctl.vnorm2 = c->vnorm2; ctl.eps = c->conv_eps; ctl.nsamp = (double)c->n;
+    ctl.conv_iter = c->conv_iter;
+    c->conv_iter = -1;
+  }
+  return ctl;
+}
 
 // ---- CSR (SNMF) ----------------------------------------------------------------------------
 template <int NT>
@@ -787,10 +807,11 @@ int nmf_fused_pass(pmf_ctx* c) {
     c->ps_valid = true;
     return PMF_OK;
   }
+  const FusedCtl ctl = take_fused_ctl(c);
   stat_begin(c, SITE_FUSED);
   const int lrc = launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
                                c->np, rn ? c->dD : c->dV, c->dW, c->dH, Gsrc, c->mp, c->fused_wgs, (float)c->lamb_w,
-                               c->dSlab, c->stop_arg, ngp);
+                               c->dSlab, ctl, ngp);
   stat_end(c, SITE_FUSED);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -884,9 +905,10 @@ int snmf_fused_pass(pmf_ctx* c) {
   c->ps_valid = false;
   c->trace_ready = false;
   PMFCHK(snmf_inverse(c));
+  const FusedCtl ctl = take_fused_ctl(c);
   stat_begin(c, SITE_FUSED);
   const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dMT, nullptr, c->mp,
-                               c->fused_wgs, 0.f, c->dSlab, c->stop_arg);
+                               c->fused_wgs, 0.f, c->dSlab, ctl);
   stat_end(c, SITE_FUSED);
   if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -1687,7 +1709,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   if (gram) PMFCHK(ensure_vgram(c));
   choose_stat_site(c, gram);
   const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !use_csr(c) && c->nb == 1)) && ce) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
-  constexpr int kHostIters = 1, kChunk = 8;
+  constexpr int kHostIters = 1, kChunk = 32;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
     if (free_run) {
@@ -1713,13 +1735,19 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
           hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
           tt = c->dScal;
         }
-        if (lrc == PMF_OK) {
+        // the next launch of the chunk is a one-pass kernel: it evaluates this iteration's error and the
+        // convergence test in its prologue (FusedCtl) -- no launch of its own for them
+        const bool fold = fused && !c->fused8 && !h_only && j + 1 < chunk && c->algo != PMF_ALGO_SNMF;
+        if (lrc == PMF_OK && fold) {
+          c->conv_iter = i + j; c->conv_tt = tt; c->conv_ntt = ntt; c->conv_eps = conv_eps;
+        } else if (lrc == PMF_OK) {
           hipLaunchKernelGGL(k_conv_check, dim3(1), dim3(64), 0, c->stream, tt, ntt, c->vnorm2, conv_eps,
                              (double)c->n, i + j, c->dFerr, c->dStop);
           if (hipGetLastError() != hipSuccess) lrc = fail(c, PMF_EHIP, "k_conv_check launch failed");
         }
       }
       c->stop_arg = nullptr;
+      c->conv_iter = -1;
       PMFCHK(lrc);
       int hstop[2] = {0, -1};
       HIPCHK(c, hipMemcpyAsync(hstop, c->dStop, sizeof(hstop), hipMemcpyDeviceToHost, c->stream));

@@ -49,6 +49,25 @@
 #define PMF_STAMP(var) do { } while (0)
 #endif
 
+
+// Slab / W-row stores.  A/B switches (diagnostic builds): PMF_SLAB_SC1 / PMF_SLAB_NT, PMF_W_NT.
+__device__ __forceinline__ void slab_store16(f32x4* p, f32x4 v) {
+#if defined(PMF_SLAB_SC1)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif defined(PMF_SLAB_NT)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void wrow_store(float* p, float v) {
+#if defined(PMF_W_NT)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt range");
@@ -80,6 +99,20 @@ __device__ __forceinline__ f32x4 vtile_read4(const float* base, int row, int chu
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
 enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2, FUSED_RNMF = 3 };   // RNMF: V is D = S - data
 
+// Free-running pmf_factorize loops.  stop: a launch enqueued behind a converged iteration is a no-op.
+// conv_iter >= 0: the error and the convergence test of THAT (the previous) iteration, nmf.py:134-139,
+// 198-202, are still to be evaluated from the trace terms its H step left in tt -- every workgroup does
+// it for itself while its first tiles are in flight (same data, same arithmetic: the same decision
+// everywhere; workgroup 0 records it), which saves the k_conv_check launch between two iterations:
+// 4.8 us of a 67 us iteration at 65 536 x 512, k = 32.  Same expressions as k_conv_check (pmf_small.h).
+struct FusedCtl {
+  int* stop;            // [0] 0 run / 1 converged / 2 the trace identity cancels, [1] iteration; or NULL
+  const double* tt;     // ntt pairs (<P,H>, <S,G>)
+  double* ferr;         // device error history
+  double vnorm2, eps, nsamp;
+  int ntt, conv_iter;
+};
+
 template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
                                                        float* __restrict__ W,
@@ -87,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
                                                        const float* __restrict__ G, int blk_per,
                                                        int blk_extra, float lamb,
                                                        float* __restrict__ slab,
-                                                       const int* __restrict__ stop, int ngp
+                                                       const FusedCtl ctl, int ngp
 #ifdef PMF_STAMPS
                                                        , unsigned long long* __restrict__ dbg
 #endif
@@ -102,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   constexpr bool SPREAD = (NPANEL == 4);
   constexpr bool SNMF = (MODE == FUSED_SNMF);
   // free-running loops (pmf_factorize): a launch enqueued behind a converged iteration is a no-op
-  if (stop != nullptr && *stop != 0) return;
+  if (ctl.stop != nullptr && *ctl.stop != 0) return;
 #ifdef PMF_STAMPS
   unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
   PMF_STAMP(tk0);
@@ -204,6 +237,23 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           g += *reinterpret_cast<const f32x4*>(G + (size_t)w * KP * KP + bas * KP + 4 * c);
         *reinterpret_cast<f32x4*>(sG + rg * 256 + drow * 64 + dchunk * 4) = g;
       }
+    }
+  }
+  if (ctl.stop != nullptr && ctl.conv_iter >= 0) {   // the previous iteration's error and convergence test
+    double t0 = ctl.tt[0], t1 = ctl.tt[1];
+    for (int q = 1; q < ctl.ntt; ++q) { t0 += ctl.tt[2 * q]; t1 += ctl.tt[2 * q + 1]; }
+    const double e2 = ctl.vnorm2 - 2.0 * t0 + t1;
+    int st = 0;
+    if (!(e2 > 1e-3 * ctl.vnorm2)) {
+      st = 2;
+    } else {
+      const double f = sqrt(e2);
+      if (blockIdx.x == 0 && tid == 0) ctl.ferr[ctl.conv_iter] = f;
+      if (ctl.conv_iter > 1 && fabs(f - ctl.ferr[ctl.conv_iter - 1]) / ctl.nsamp < ctl.eps) st = 1;
+    }
+    if (st != 0) {                                   // uniform over the grid: W has not been touched
+      if (blockIdx.x == 0 && tid == 0) { ctl.stop[1] = ctl.conv_iter; ctl.stop[0] = st; }
+      return;
     }
   }
   wait_vmcnt<0>();
@@ -406,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           if (MODE == FUSED_RNMF) w = dd[nt][j] != 0.f ? wold[nt][j] * w : 0.f;   // 0/0 on the zero padding
           wn[nt][j] = w;
 #ifndef PMF_ABLATE_WSTORE
-          if (SPLIT == 1 || half == 0) wdst[j * KP + nt] = w;
+          if (SPLIT == 1 || half == 0) wrow_store(&wdst[j * KP + nt], w);
 #endif
         }
       s_mfmas(4 * NSM / 5, NSM);
@@ -418,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         for (int j = 0; j < 4; ++j) {
           const float w = num[nt][j];                        // W = V (inv(H H^T) H)^T, snmf.py:67-70 reassociated
           wn[nt][j] = w;
-          wdst[j * KP + nt] = w;
+          wrow_store(&wdst[j * KP + nt], w);
 #pragma unroll
           for (int mt = 0; mt <= nt; ++mt) S[mt][nt] = mfma16(wp[mt][j], wp[nt][j], S[mt][nt]);
         }
@@ -522,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   if (SPLIT == 1) {
     f32x4* out = reinterpret_cast<f32x4*>(slab) + (size_t)blockIdx.x * NTU * 64 + lane;
     for (int t = wv; t < NTU; t += 4)
-      out[t * 64] = ex[t * 64 + lane] + ex[(size_t)NTU * 64 + t * 64 + lane];
+      slab_store16(&out[t * 64], ex[t * 64 + lane] + ex[(size_t)NTU * 64 + t * 64 + lane]);
   } else {
     // region h holds the P tiles of panels h * NPANEL .. (summed over the two pairs); S lives in
     // region 0.  The slab is tile-major over ALL panels: P tile (mt, 4 * panel + e), then S.
@@ -530,10 +580,10 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     f32x4* out = reinterpret_cast<f32x4*>(slab) + (size_t)blockIdx.x * NTUT * 64 + lane;
     for (int t = wv; t < 2 * NT * NTP; t += 4) {
       const int h = t / (NT * NTP), q = t % (NT * NTP), mt = q / NTP, nt = q % NTP;
-      out[(mt * NTPT + h * NTP + nt) * 64] = ex[(size_t)h * NTU * 64 + q * 64 + lane];
+      slab_store16(&out[(mt * NTPT + h * NTP + nt) * 64], ex[(size_t)h * NTU * 64 + q * 64 + lane]);
     }
     for (int t = wv; t < NT * (NT + 1) / 2; t += 4)
-      out[(NT * NTPT + t) * 64] = ex[(NT * NTP + t) * 64 + lane];
+      slab_store16(&out[(NT * NTPT + t) * 64], ex[(NT * NTP + t) * 64 + lane]);
   }
 #ifdef PMF_STAMPS
   PMF_STAMP(tk3);
@@ -585,7 +635,7 @@ static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF
 
 template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
-                          int64_t mp, int wgs, float lamb, float* slab, const int* stop, int ngp) {
+                          int64_t mp, int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp) {
   const int nblk = (int)(mp / 16), nw = wgs * (SPLIT == 2 ? 2 : 4);   // waves, or pairs of waves
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL, SPLIT>();
@@ -598,21 +648,21 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
     attr_done = true;
   }
   hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE, SPLIT>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
-                     blk_extra, lamb, slab, stop, ngp);
+                     blk_extra, lamb, slab, ctl, ngp);
   return PMF_OK;
 }
 
 // G: H H^T [KP][KP] float32 (NMF, BNMF, RNMF).  FUSED_SNMF: H is M^T = inv(H H^T) H and G is unused.
 static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
                                const float* H, const float* G, int64_t mp, int wgs, float lamb,
-                               float* slab, const int* stop = nullptr, int ngp = 0) {
+                               float* slab, const FusedCtl& ctl, int ngp = 0) {
   if (!fused_shape_ok(NT, np) && fused_shape_split(NT, np) && mode != FUSED_SNMF) {
     const int skey = NT * 10 + np / 128;
 #define PMF_FUSED_SPLIT_CASE(K, A, B)                                                                   \
   case K:                                                                                               \
-    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
-           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
-                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp);
+    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
+                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp);
     switch (skey) {
       PMF_FUSED_SPLIT_CASE(14, 1, 4)
       PMF_FUSED_SPLIT_CASE(23, 2, 3)
@@ -624,10 +674,10 @@ static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const fl
   const int key = NT * 10 + np / 64;
 #define PMF_FUSED_CASE(K, A, B)                                                                  \
   case K:                                                                                        \
-    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
-           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
-           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp) \
-                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, stop, ngp);
+    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
+           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
+                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp);
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
     PMF_FUSED_CASE(12, 1, 2)

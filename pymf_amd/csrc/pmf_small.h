@@ -77,13 +77,14 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
                                                      float* Gpart, double* t1part, unsigned* ticket,
                                                      const int* __restrict__ stop, int final_sum) {
   __shared__ double red[2][16];
-  if (stop != nullptr && *stop != 0) return;
   __shared__ unsigned s_last;
   constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
   constexpr int HT = NT * 4;                  // H-step tiles of a panel
   constexpr int HTW = (HT + 15) / 16;         // ... per wave
   constexpr int GT = NT * NT;                 // G tiles
   constexpr int GTW = (GT + 15) / 16;
+  constexpr int SQ = (KP * (KP / 4) + 1023) / 1024;   // 16-byte pieces of S / of an H panel per thread
+  constexpr int HQ = (KP * 16 + 1023) / 1024;
   const int64_t ldp = (int64_t)np + KP;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* ss = sm;                    // [KP][KP+4]   S = W^T W
@@ -93,22 +94,18 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   const int npanel = np >> 6;
-  for (int q = tid; q < KP * (KP / 4); q += 1024) {
-    const int r = q / (KP / 4), c4 = q % (KP / 4);
-    *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) =
-        *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
-  }
-  f32x4 ge[GTW][4];
-#pragma unroll
-  for (int g = 0; g < GTW; ++g)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ge[g][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  double t1 = 0.0;
-
-  for (int p = blockIdx.x; p < npanel; p += gridDim.x) {
+  // Everything the first panel needs is requested in ONE round trip -- S, the H panel, this wave's P values
+  // (accumulator layout) and the stop flag -- and only then written to LDS: the kernel is a chain of memory
+  // latencies (a k x n sized problem on a handful of CUs), three of them in a row before this order.
+  f32x4 sreg[SQ], hreg[HQ];
+  float pv[HTW][4];
+  auto load_panel = [&](int p) {
     const int c0 = 64 * p;
-    // this wave's P values (accumulator layout) ride in the same round trip as the staging loads
-    float pv[HTW][4];
+#pragma unroll
+    for (int u = 0; u < HQ; ++u) {
+      const int q = tid + 1024 * u, r = q >> 4, c4 = q & 15;
+      if (q < KP * 16) hreg[u] = *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
+    }
 #pragma unroll
     for (int h = 0; h < HTW; ++h) {
       const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
@@ -116,11 +113,44 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
       for (int r = 0; r < 4; ++r)
         pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i] : 0.f;
     }
-    __syncthreads();                                  // the previous panel's images are free
-    for (int q = tid; q < KP * 16; q += 1024) {
-      const int r = q >> 4, c4 = q & 15;
-      *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) =
-          *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
+  };
+#pragma unroll
+  for (int u = 0; u < SQ; ++u) {
+    const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
+    if (q < KP * (KP / 4)) sreg[u] = *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
+  }
+  if (blockIdx.x < npanel) load_panel(blockIdx.x);
+  if (stop != nullptr && *stop != 0) return;
+#pragma unroll
+  for (int u = 0; u < SQ; ++u) {
+    const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
+    if (q < KP * (KP / 4)) *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) = sreg[u];
+  }
+  // accumulator chains per G tile: four where a wave owns one tile (independent MFMAs back to back); at
+  // num_bases > 64 a wave owns four tiles -- already four independent chains, and 64 accumulator registers
+  // in four chains each spilled (128-register budget at 16 waves per workgroup)
+  constexpr int NCH = GTW >= 4 ? 1 : 4;
+  f32x4 ge[GTW][NCH];
+#pragma unroll
+  for (int g = 0; g < GTW; ++g)
+#pragma unroll
+    for (int e = 0; e < NCH; ++e) ge[g][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto gsum = [&](int g) -> f32x4 {
+    if (NCH == 1) return ge[g][0];
+    return (ge[g][0] + ge[g][NCH > 1 ? 1 : 0]) + (ge[g][NCH > 2 ? 2 : 0] + ge[g][NCH > 3 ? 3 : 0]);
+  };
+  double t1 = 0.0;
+
+  for (int p = blockIdx.x; p < npanel; p += gridDim.x) {
+    const int c0 = 64 * p;
+    if (p != blockIdx.x) {                            // (grids of fewer workgroups than panels: np > 4096)
+      __syncthreads();                                // the previous panel's images are free
+      load_panel(p);
+    }
+#pragma unroll
+    for (int u = 0; u < HQ; ++u) {
+      const int q = tid + 1024 * u, r = q >> 4, c4 = q & 15;
+      if (q < KP * 16) *reinterpret_cast<f32x4*>(hs + r * LDS_H + 4 * c4) = hreg[u];
     }
     __syncthreads();
     // ---- H step ----
@@ -169,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(hn + (16 * mt + i) * LDS_H + 16 * t + 4 * kq);
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(hn + (16 * nt + i) * LDS_H + 16 * t + 4 * kq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ge[g][e] = mfma16(a4[e], b4[e], ge[g][e]);
+        for (int e = 0; e < 4; ++e) ge[g][e % NCH] = mfma16(a4[e], b4[e], ge[g][e % NCH]);
       }
     }
   }
@@ -181,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
     const int q = wv + 16 * g;
     if (q >= GT) break;
     const int mt = q / NT, nt = q % NT;
-    const f32x4 gs = (ge[g][0] + ge[g][1]) + (ge[g][2] + ge[g][3]);
+    const f32x4 gs = gsum(g);
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[(16 * mt + 4 * kq + r) * KP + 16 * nt + i] = gs[r];
   }
@@ -196,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
       const int q = wv + 16 * g;
       if (q >= GT) break;
       const int mt = q / NT, nt = q % NT;
-      const f32x4 gs = (ge[g][0] + ge[g][1]) + (ge[g][2] + ge[g][3]);
+      const f32x4 gs = gsum(g);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         t2 = fma((double)ss[(16 * mt + 4 * kq + r) * LDS_S + 16 * nt + i], (double)gs[r], t2);

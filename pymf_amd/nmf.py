@@ -23,6 +23,7 @@ current host arrays.
 """
 import logging
 import os
+import sys
 
 import numpy as np
 
@@ -86,6 +87,15 @@ class NMF(object):
     #: uploaded again when they changed (the reference reads self.data[:,:] afresh every time).
     #: False: `data` is uploaded once per object; call invalidate_data() after editing it in place.
     check_data = True
+    #: W and H live on the device between calls.  The reference updates the arrays the caller may be
+    #: holding IN PLACE (`w = mdl.W; mdl.factorize(); w` has changed, nmf.py:125-126,131-132), so after
+    #: every call the host arrays are brought up to date -- unless nobody but this object can see them:
+    #: an array that the object owns outright (CPython reference count: no other name, no view of it
+    #: alive) cannot be observed between two calls, and it is refreshed when `.W` / `.H` is next read
+    #: instead (768 MiB less over PCIe and through the float64 conversion per call at 1 048 576 x 256,
+    #: k = 64).  The same test spares the digest of an array that was not handed out since it was last
+    #: made equal to the device copy.  True: refresh after every call, digest before every call.
+    eager_factors = False
 
     def __init__(self, data, num_bases=4):
         def setup_logging():                                   # nmf.py:73-90
@@ -105,7 +115,8 @@ class NMF(object):
         self._v_fp = None        # ... and the digest of its bytes at upload time
         self._w_fp = None        # digest of the host W/H the device copies equal
         self._h_fp = None
-        self._host_stale = set() # factors whose DEVICE copy is newer than the host array (hook loop)
+        self._host_stale = set() # factors whose DEVICE copy is newer than the host array
+        self._handed = set()     # factors whose host array was read through .W / .H since it was last synchronised
         self._defer_pull = False
         self._in_loop = False
 
@@ -118,12 +129,30 @@ class NMF(object):
         if name in self.__dict__.get("_host_stale", ()):
             self._refresh_host(name)
             arr = self.__dict__["_" + name]
+        self.__dict__.setdefault("_handed", set()).add(name)   # the caller may edit it in place from now on
         return arr
 
     def _factor_set(self, name, value):
         self.__dict__["_" + name] = value
         self.__dict__.setdefault("_host_stale", set()).discard(name)
         self.__dict__["_%s_fp" % name.lower()] = None          # host is newer: upload at the next call
+
+    def _has(self, name):
+        """hasattr(self, 'W') without reading the property (a read refreshes the host array)."""
+        return ("_" + name) in self.__dict__
+
+    def _held_elsewhere(self, name):
+        """May anybody but this object see (or edit) the host array of W / H?  False only for a plain
+        ndarray that owns its memory and has no reference besides this object's (CPython refcount: the
+        attribute itself and the argument of getrefcount -- a name the caller kept, or a live view,
+        shows up as a third)."""
+        d = self.__dict__
+        key = "_" + name
+        if self.eager_factors or not hasattr(sys, "getrefcount"):
+            return True
+        if type(d[key]) is not np.ndarray or d[key].base is not None or not d[key].flags.owndata:
+            return True
+        return sys.getrefcount(d[key]) > 2
 
     def _factor_del(self, name):
         try:
@@ -238,7 +267,12 @@ class NMF(object):
         for name, fp_attr, setter in (("W", "_w_fp", ctx.set_w), ("H", "_h_fp", ctx.set_h)):
             if name in self._host_stale:          # the device copy is the newer one
                 continue
-            arr = self.__dict__["_" + name] if ("_" + name) in self.__dict__ else getattr(self, name)
+            if not self._has(name):
+                getattr(self, name)               # AttributeError, as the reference's self.W would raise
+            if (getattr(self, fp_attr) is not None and name not in self._handed
+                    and not self._held_elsewhere(name)):
+                continue                          # equal to the device copy and out of everybody's reach since
+            arr = self.__dict__["_" + name]
             if not np.issubdtype(np.asarray(arr).dtype, np.floating):
                 # reference: `W *= dot(...)` on an integer W raises UFuncTypeError
                 raise TypeError("%s must be a floating-point array" % name)
@@ -246,6 +280,8 @@ class NMF(object):
             if getattr(self, fp_attr) != fp:
                 setter(arr)
                 setattr(self, fp_attr, fp)
+            del arr
+            self._handed.discard(name)
         return ctx
 
     def _refresh_host(self, name):
@@ -269,17 +305,25 @@ class NMF(object):
             if not want:
                 continue
             self._host_stale.add(name)
-            if not self._defer_pull:
+            if not self._defer_pull and self._held_elsewhere(name):
+                self._refresh_host(name)          # somebody holds the array: the reference's in-place update
+
+    def _flush_host(self, force=False):
+        for name in sorted(self._host_stale):
+            if force or self._held_elsewhere(name):
                 self._refresh_host(name)
 
-    def _flush_host(self):
-        for name in sorted(self._host_stale):
-            self._refresh_host(name)
+    def __getstate__(self):                       # pickling / copying: host arrays up to date, no device handle
+        self._flush_host(force=True)
+        st = dict(self.__dict__)
+        st["_ctx"] = None
+        st["_v_src"] = st["_v_fp"] = st["_w_fp"] = st["_h_fp"] = None
+        return st
 
     # ---- reference surface ----------------------------------------------------------
     def frobenius_norm(self):
         """||data - W H||_F (nmf.py:100-114); -123456 without W/H or for sparse data."""
-        if hasattr(self, 'H') and hasattr(self, 'W') and not _is_sparse(self.data):
+        if self._has('H') and self._has('W') and not _is_sparse(self.data):
             rows = self._stream_rows()
             if rows:
                 return self._stream_pass(self._sync_to_device(), rows, resid=True)[0]
@@ -350,9 +394,9 @@ class NMF(object):
         else:
             self._logger.setLevel(logging.ERROR)
 
-        if not hasattr(self, 'W'):                             # nmf.py:173-174
+        if not self._has('W'):                                 # nmf.py:173-174
             self.init_w()
-        if not hasattr(self, 'H'):                             # nmf.py:176-177
+        if not self._has('H'):                                 # nmf.py:176-177
             self.init_h()
 
         if compute_err:                                        # nmf.py:179-180

@@ -28,7 +28,7 @@ int main(int argc, char** argv){
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for(int it=0; it<5; ++it){
     hipEventRecord(e0);
-    k_nmf_fused<ST_NT,ST_NPANEL,STAMP_MODE,ST_SPLIT><<<wgs,256,smem>>>(V,W,H,G,(int)(mp/16/(wgs*(ST_SPLIT==2?2:4))),(int)((mp/16)%(wgs*(ST_SPLIT==2?2:4))),0.f,slab,nullptr,0,dbg);
+    k_nmf_fused<ST_NT,ST_NPANEL,STAMP_MODE,ST_SPLIT><<<wgs,256,smem>>>(V,W,H,G,(int)(mp/16/(wgs*(ST_SPLIT==2?2:4))),(int)((mp/16)%(wgs*(ST_SPLIT==2?2:4))),0.f,slab,FusedCtl{nullptr,nullptr,nullptr,0.0,0.0,0.0,0,-1},0,dbg);
     hipEventRecord(e1); CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms,e0,e1);
     std::vector<unsigned long long> h(wgs*4*8); CK(hipMemcpy(h.data(),dbg,h.size()*8,hipMemcpyDeviceToHost));
