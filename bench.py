@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--cols", dest="n", type=int, default=0)
     ap.add_argument("--bases", dest="k", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-class-rate", action="store_true",
+                    help="skip config.class_factorize_iters_per_sec (pymf_amd.<Class>.factorize on the same inputs)")
     ap.add_argument("--preroll-ms", type=float, default=PREROLL_MS_DEFAULT,
                     help="disclosed device pre-conditioning: untimed iterations of the same loop for about this "
                          "many ms of device time BEFORE the W counted warm-up steps (the chip's clock/power "
@@ -229,20 +231,27 @@ def main():
                            nranks=w.size, nccl_id=w.nccl_id)
     data = "synthetic"
     nnz_local = 0
+    host = {}                    # host copies for the class-level measurement (1 rank, numpy fill)
+    want_class = (w.size == 1 and not args.no_class_rate)
     if args.config == "cfg5":
         ip, ix, vv = gen_csr(m, n, 0.01, lo, hi, fast=(args.fill != "numpy"))
         nnz_local = int(vv.shape[0])
         ctx.set_v_csr(ip, ix, vv)
+        if want_class:
+            import scipy.sparse as sp
+            host["V"] = sp.csr_matrix((vv, ix, ip), shape=(hi - lo, n))
         del ip, ix, vv
         if args.fill != "numpy":
             data = "synthetic (Poisson/uniform CSR stand-in of the BASELINE density)"
-        if args.snmf_gram >= 0:
-            ctx.set_option("snmf_gram", args.snmf_gram)
+        # headline loop: W written in every iteration (snmf_gram = 2); --snmf-gram overrides
+        ctx.set_option("snmf_gram", args.snmf_gram if args.snmf_gram >= 0 else 2)
     elif args.fill == "device":
         ctx.fill_v_uniform(1234, lo)
     else:
         V = gen_rows(np.random.RandomState(1234), m, n, lo, hi)
         ctx.set_v_dense(V)
+        if want_class:
+            host["V"] = V
         del V
     if args.fill == "device" and args.config != "cfg5":
         ctx.fill_w_uniform(42, lo)
@@ -250,8 +259,13 @@ def main():
     else:
         np.random.seed(42)
         rs = np.random.mtrand._rand            # the global legacy stream, as np.random.random uses
-        ctx.set_w(gen_rows(rs, m, k, lo, hi))
-        ctx.set_h(np.random.random((k, n)))
+        W0 = gen_rows(rs, m, k, lo, hi)
+        H0 = np.random.random((k, n))
+        ctx.set_w(W0)
+        ctx.set_h(H0)
+        if want_class and "V" in host:
+            host["W"], host["H"] = W0, H0
+        del W0, H0
 
     # ---- disclosed pre-conditioning (untimed, reported as "preroll_ms" / "preroll_iters") ----
     preroll_iters, preroll_ms = 0, 0.0
@@ -276,10 +290,11 @@ def main():
     t0 = time.perf_counter()
     _, done, conv = ctx.factorize(args.steps, compute_err=False)
     ctx.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0         # this rank's K steps are done; the closing barrier (a TCP round
+    dist.barrier()                        # trip through rank 0) is not part of anybody's K steps
     assert done == args.steps and conv < 0, "timed run was shortened (%d of %d)" % (done, args.steps)
-    dt = dist.allreduce_max(dt)
+    rank_dt = dist.allgather_float(dt)    # every rank's own K steps; `value` uses the slowest
+    dt = max(rank_dt)
     stats = ctx.kernel_stats()
     all_ms = ctx.kernel_launch_ms()
     launch_ms = np.sort(all_ms)
@@ -296,26 +311,71 @@ def main():
         t1 = time.perf_counter()
         _, done_e, conv_e = ctx.factorize(ne, compute_err=True)
         ctx.synchronize()
+        dt_e = time.perf_counter() - t1
         dist.barrier()
-        rate_err = done_e / dist.allreduce_max(time.perf_counter() - t1)
+        rate_err = done_e / dist.allreduce_max(dt_e)
 
-    # cfg5, for transparency: the same loop with one pass over the CSR rows in EVERY iteration (the form in
-    # which W is rewritten each iteration, as the reference's update_w does) -- not the headline value
-    rate_pass_per_iter, rate_w_every_iter = None, None
-    if args.config == "cfg5" and args.snmf_gram != 0:
-        rates = []
-        for opt in (2, 0):        # 2: Gram-space iteration + W = V M written every iteration; 0: round 1's one-pass CSR kernel
-            ctx.set_option("snmf_gram", opt)
-            ctx.factorize(2, compute_err=False)
+    # cfg5: `value` is the loop that writes W = V M in EVERY iteration (what the reference's update_w does,
+    # snmf.py:67-70).  Beside it: the Gram-space loop that materialises W once per factorize() -- as an
+    # amortised rate for this K, taken apart into its fixed cost and its per-iteration cost, and COLD (fresh
+    # V: the one-time C = V^T V inside the measured call) -- and round 1's one-pass CSR kernel.
+    gram_loop, rate_pass_per_iter = None, None
+    if args.config == "cfg5" and args.snmf_gram == -1:
+        def timed(steps):
             ctx.synchronize()
             dist.barrier()
             t2 = time.perf_counter()
-            ctx.factorize(args.steps, compute_err=False)
+            ctx.factorize(steps, compute_err=False)
             ctx.synchronize()
+            d = time.perf_counter() - t2
             dist.barrier()
-            rates.append(args.steps / dist.allreduce_max(time.perf_counter() - t2))
-        rate_w_every_iter, rate_pass_per_iter = rates
-        ctx.set_option("snmf_gram", args.snmf_gram)
+            return dist.allreduce_max(d)
+        ctx.set_option("snmf_gram", 1)
+        ctx.factorize(2, compute_err=False)
+        t_k, t_2k = timed(args.steps), timed(2 * args.steps)
+        per_it = max(t_2k - t_k, 0.0) / args.steps
+        ctx.invalidate_v()                       # forget C = V^T V (and everything else derived from V)
+        t_cold = timed(args.steps)
+        gram_loop = {"iters_per_sec_amortised_over_steps": args.steps / t_k, "steps": args.steps,
+                     "per_iteration_ms": per_it * 1e3, "fixed_ms_per_factorize": max(t_k - args.steps * per_it, 0.0) * 1e3,
+                     "cold_factorize_ms": t_cold * 1e3,
+                     "cold_iters_per_sec": args.steps / t_cold,
+                     "note": "W = V M written once per factorize(); cold = first call on fresh data, C = V^T V formed inside"}
+        ctx.set_option("snmf_gram", 0)
+        ctx.factorize(2, compute_err=False)
+        rate_pass_per_iter = args.steps / timed(args.steps)
+        ctx.set_option("snmf_gram", 2)
+
+    # class-level rate: pymf_amd.<Class>(data).factorize(K) on the same inputs, SECOND call on an object whose
+    # data and factors are resident (the first call uploads); default settings, and with check_data off
+    class_rate = None
+    if want_class and w.rank == 0 and "W" in host:
+        import pymf_amd
+        per_step_s = dt / args.steps
+        kc = args.steps if per_step_s > 2e-3 else max(args.steps, 100)
+        cls = {"NMF": pymf_amd.NMF, "NMFALS": pymf_amd.NMFALS, "SNMF": pymf_amd.SNMF}[algo_name]
+        mdl = cls(host["V"], num_bases=k)
+        mdl.W, mdl.H = host.pop("W"), host.pop("H")
+        class_rate = {"steps": kc}
+        try:
+            mdl.factorize(niter=2, compute_err=False)
+            for key, chk in (("iters_per_sec", True), ("iters_per_sec_check_data_off", False)):
+                mdl.check_data = chk
+                d3, ov = None, None
+                for _rep in range(3):            # best of three calls (a 256-thread host digests 1 GiB in 5 ms -- or 70)
+                    t3 = time.perf_counter()
+                    mdl.factorize(niter=kc, compute_err=False)
+                    d = time.perf_counter() - t3
+                    if d3 is None or d < d3:
+                        d3, ov = d, (d - mdl._ctx.last_loop_ms() * 1e-3) * 1e3
+                class_rate[key] = kc / d3
+                class_rate["call_overhead_ms" + ("" if chk else "_check_data_off")] = ov
+            _ = mdl.W                            # the read that refreshes the host array (not inside the rate)
+        finally:
+            if mdl._ctx is not None:
+                mdl._ctx.close()
+        del mdl
+    host.clear()
 
     if w.rank == 0:
         mean_s = stats["mean_ms"] * 1e-3
@@ -348,6 +408,7 @@ def main():
             "preroll_ms": preroll_ms,
             "preroll_iters": preroll_iters,
             "ms_per_step": dt / args.steps * 1e3,
+            "rank_ms_per_step": [x / args.steps * 1e3 for x in rank_dt],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -357,9 +418,15 @@ def main():
                                    "compute_err=False" % (args.config, cfg_index, cfg_desc, m, n, k, w.size),
                        "m": m, "n": n, "k": k, "algo": algo_name, "path": ctx.path_name,
                        "collective": collective,
-                       "compute_err_true_iters_per_sec": rate_err},
+                       "compute_err_true_iters_per_sec": rate_err,
+                       "class_factorize": class_rate},
             "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": traffic, "kernel": stats["name"], "launches": stats["launches"],
+                         "traffic": traffic,
+                         "traffic_source": ("profiles/traffic.json: rocprofv3 PMC passes of this kernel on this shape "
+                                            "(2 x FETCH_SIZE + WRITE_SIZE per launch), collected by tools/pmc_configs.sh -- "
+                                            "a recorded constant, not counted in this run") if traffic is not None
+                                           else "none recorded for this kernel / shape / rank count",
+                         "kernel": stats["name"], "launches": stats["launches"],
                          "mean_kernel_ms": stats["mean_ms"],
                          "min_kernel_ms": float(launch_ms[0]) if len(launch_ms) else None,
                          "median_kernel_ms": float(np.median(launch_ms)) if len(launch_ms) else None,
@@ -373,16 +440,30 @@ def main():
                          "kernel_share_of_timed_region": stats["launches"] * mean_s / dt if dt > 0 else 0.0},
         }
         if algo_name == "NMFALS":
-            out["roofline"]["note"] = ("k_nnqp is bound by VALU issue, not by HBM or MFMA: float64 active-set updates with lane = "
-                                       "variable cost ~17 k wave instructions per QP at ~3.9 cycles each (rocprofv3 SQ_INSTS_VALU, "
-                                       "profiles/r02_pmc_summary.csv; model in DESIGN.md 3.4) -- the hbm fraction above only says that "
-                                       "memory is not the limit")
+            # k_nnqp is bound by VALU issue (float64 active-set updates, lane = variable): neither HBM nor MFMA.
+            # Recorded constants (rocprofv3 SQ_INSTS_VALU per W-step launch, profiles/r02_pmc_summary.csv, and the
+            # DFMA count of DESIGN.md 3.4) against the live launch time: float64 flop/s vs the 78.6 TFLOP/s vector
+            # peak, and wave instructions/s vs one per 4 cycles per SIMD.
+            qps = float(hi - lo)
+            fma_flop = 2.0 * 2.24e5 * qps * (k / 64.0) ** 3          # ~|P|^3-sized work, measured at k = 64
+            valu_instr = 16.6e3 * qps * (k / 64.0) ** 2
+            if mean_s > 0:
+                out["roofline"].update(bound="valu_f64", achieved=fma_flop / mean_s / 1e12, peak=78.6, unit="TFLOP/s",
+                                       frac=fma_flop / mean_s / 1e12 / 78.6)
+                out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": valu_instr,
+                                                 "achieved_Ginstr_per_s": valu_instr / mean_s / 1e9,
+                                                 "peak_Ginstr_per_s": 1024 * 2.4 / 4.0 * 1e0 * 1e0,
+                                                 "frac": valu_instr / mean_s / 1e9 / (1024 * 2.4 / 4.0),
+                                                 "source": "SQ_INSTS_VALU per QP recorded in profiles/r02_pmc_summary.csv (16.6 k at k = 64)"}
+            out["roofline"]["note"] = ("float64 flop = 2 x DFMA count of the active-set updates (2.24e5 FMA per 64-variable QP, "
+                                       "DESIGN.md 3.4); the kernel sits at the VALU ISSUE limit (valu_issue.frac), two thirds of the "
+                                       "slots being v_readlane broadcasts of the lane = variable layout")
         if args.config == "cfg5":
             out["config"]["nnz_local"] = nnz_local
-            out["config"]["w_written_every_iteration_iters_per_sec"] = rate_w_every_iter
+            out["config"]["gram_space_loop_w_once_per_factorize"] = gram_loop
             out["config"]["one_pass_csr_kernel_iters_per_sec"] = rate_pass_per_iter
-            out["config"]["loop"] = ("Gram space: one k x n sized iteration per step, W = V M materialised once "
-                                     "inside the timed region" if stats["name"].startswith("k_csr_w")
+            out["config"]["loop"] = ("k x n sized Gram-space iteration (P = M^T (V^T V), S = P M) + W = V M written in EVERY "
+                                     "iteration, as the reference's update_w does" if stats["name"].startswith("k_csr_w")
                                      else "one pass over the CSR rows per iteration")
         if w.size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, m, n, k)

@@ -11,8 +11,17 @@ every collective is a gather to rank 0 followed by a broadcast (a star: the
 payloads are a few hundred bytes).  The launch contract
 (`python -m torch.distributed.run ...`) provides RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT; nothing else of torch is used.
+
+Who may join: the listener binds to the interface MASTER_ADDR resolves to (loopback for a one-node
+launch) and admits a connection only after a challenge-response on a shared secret -- rank 0 sends a
+random nonce, the peer answers HMAC-SHA256(key, nonce | rank).  The key comes from PYMF_DIST_SECRET;
+a loopback rendezvous without it derives one from the launcher's env (every local user could do the
+same: the protection there is the loopback bind), a NON-loopback rendezvous without it is refused.
+Frames are length-prefixed and capped (PYMF_DIST_MAX_FRAME, default 1 GiB).  This is job plumbing for
+a trusted cluster network, not a hardened service: anyone holding the secret can feed the sums.
 """
 import hashlib
+import hmac
 import json
 import os
 import socket
@@ -21,8 +30,10 @@ import time
 
 import numpy as np
 
-_MAGIC = b"PYMFAMD1"
+_MAGIC = b"PYMFAMD2"
 _PORT_SPAN = 32
+_MAX_FRAME = int(os.environ.get("PYMF_DIST_MAX_FRAME", str(1 << 30)))
+_HANDSHAKE_TIMEOUT = 2.0
 
 
 class World(object):
@@ -78,31 +89,49 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > _MAX_FRAME:
+        raise ConnectionError("pymf_amd.dist: a %d-byte frame exceeds PYMF_DIST_MAX_FRAME (%d)" % (n, _MAX_FRAME))
     return _recv_exact(sock, n)
 
 
-def _token(addr, port, size):
+def _is_loopback(ip):
+    return ip == "localhost" or ip.startswith("127.") or ip == "::1"
+
+
+def _key(addr, port, size, bind_ip):
+    """HMAC key of the rendezvous: PYMF_DIST_SECRET, or -- loopback only -- a value every rank of this
+    launch can derive from its env."""
+    secret = os.environ.get("PYMF_DIST_SECRET", "")
+    if secret:
+        return hashlib.sha256(b"pymf_amd.dist|" + secret.encode()).digest()
+    if not _is_loopback(bind_ip):
+        raise RuntimeError("pymf_amd.dist: MASTER_ADDR=%s is not a loopback address; set PYMF_DIST_SECRET (the same random "
+                           "value on every rank) so that only this job's ranks can join the rendezvous" % addr)
     s = "%s|%s|%d|%s" % (addr, port, size, os.environ.get("TORCHELASTIC_RUN_ID", ""))
-    return hashlib.sha256(s.encode()).digest()[:16]
+    return hashlib.sha256(s.encode()).digest()
+
+
+def _mac(key, *parts):
+    return hmac.new(key, b"|".join(parts), hashlib.sha256).digest()
 
 
 # ---- rendezvous ------------------------------------------------------------------------------
-def _serve(addr, base_port, size, token, timeout):
+def _serve(bind_ip, base_port, size, key, timeout):
     global _LISTENER
     lst = None
     for port in range(base_port, base_port + _PORT_SPAN):
         s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         try:
-            s.bind(("" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+            s.bind((bind_ip, port))                  # the interface MASTER_ADDR names, never all of them
             s.listen(size + 8)
             lst = s
             break
         except OSError:
             s.close()
     if lst is None:
-        raise RuntimeError("pymf_amd.dist: no free port in [%d, %d); set PYMF_DIST_PORT" %
-                           (base_port, base_port + _PORT_SPAN))
+        raise RuntimeError("pymf_amd.dist: no free port on %s in [%d, %d); set PYMF_DIST_PORT" %
+                           (bind_ip, base_port, base_port + _PORT_SPAN))
     _LISTENER = lst
     peers = {}
     deadline = time.time() + timeout
@@ -114,16 +143,17 @@ def _serve(addr, base_port, size, token, timeout):
             raise RuntimeError("pymf_amd.dist: only %d of %d ranks joined within %.0f s" %
                                (len(peers) + 1, size, timeout))
         try:
-            conn.settimeout(5.0)
-            hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
-            if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):len(_MAGIC) + 16] != token:
+            conn.settimeout(_HANDSHAKE_TIMEOUT)      # a stranger can hold the accept loop this long at most
+            nonce = os.urandom(16)
+            conn.sendall(_MAGIC + nonce)
+            hello = _recv_exact(conn, len(_MAGIC) + 4 + 32)
+            rbytes = hello[len(_MAGIC):len(_MAGIC) + 4]
+            (r,) = struct.unpack("<i", rbytes)
+            good = hello[:len(_MAGIC)] == _MAGIC and hmac.compare_digest(hello[-32:], _mac(key, b"join", nonce, rbytes))
+            if not good or r < 1 or r >= size or r in peers:
                 conn.close()                         # not one of this job's ranks
                 continue
-            (r,) = struct.unpack("<i", hello[-4:])
-            if r < 1 or r >= size or r in peers:
-                conn.close()
-                continue
-            conn.sendall(_MAGIC + token)
+            conn.sendall(_MAGIC + _mac(key, b"ack", nonce, rbytes))
             conn.settimeout(None)
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             peers[r] = conn
@@ -132,9 +162,9 @@ def _serve(addr, base_port, size, token, timeout):
     return peers
 
 
-def _join(addr, base_port, rank, token, timeout):
+def _join(addr, base_port, rank, key, timeout):
     deadline = time.time() + timeout
-    hello = _MAGIC + token + struct.pack("<i", rank)
+    rbytes = struct.pack("<i", rank)
     while time.time() < deadline:
         for port in range(base_port, base_port + _PORT_SPAN):
             try:
@@ -143,12 +173,15 @@ def _join(addr, base_port, rank, token, timeout):
                 continue
             try:
                 s.settimeout(5.0)
-                s.sendall(hello)
-                ack = _recv_exact(s, len(_MAGIC) + 16)
-                if ack == _MAGIC + token:
-                    s.settimeout(None)
-                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    return {0: s}
+                greet = _recv_exact(s, len(_MAGIC) + 16)
+                if greet[:len(_MAGIC)] == _MAGIC:
+                    nonce = greet[len(_MAGIC):]
+                    s.sendall(_MAGIC + rbytes + _mac(key, b"join", nonce, rbytes))
+                    ack = _recv_exact(s, len(_MAGIC) + 32)
+                    if ack[:len(_MAGIC)] == _MAGIC and hmac.compare_digest(ack[len(_MAGIC):], _mac(key, b"ack", nonce, rbytes)):
+                        s.settimeout(None)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        return {0: s}
             except (OSError, ConnectionError):
                 pass
             s.close()
@@ -172,9 +205,13 @@ def init_from_env(make_nccl_id=None, timeout=None):
     mport = os.environ.get("MASTER_PORT", "29500")
     base = int(os.environ.get("PYMF_DIST_PORT", "0") or 0) or int(mport) + 1
     timeout = float(timeout if timeout is not None else os.environ.get("PYMF_DIST_TIMEOUT", "300"))
-    token = _token(addr, mport, size)
+    try:
+        bind_ip = "127.0.0.1" if addr == "localhost" else socket.gethostbyname(addr)
+    except OSError:
+        raise RuntimeError("pymf_amd.dist: MASTER_ADDR=%s does not resolve" % addr)
+    key = _key(addr, mport, size, bind_ip)
     _WORLD = World(rank, size, local_rank, None)
-    _PEERS = _serve(addr, base, size, token, timeout) if rank == 0 else _join(addr, base, rank, token, timeout)
+    _PEERS = _serve(bind_ip, base, size, key, timeout) if rank == 0 else _join(bind_ip, base, rank, key, timeout)
     if make_nccl_id is None and transport() == "host":
         return _WORLD                                  # no RCCL communicator will be created
     if make_nccl_id is None:
@@ -224,6 +261,10 @@ def allreduce_max(x):
 
 def allgather_int(x):
     return [struct.unpack("<q", p)[0] for p in allgather_bytes(struct.pack("<q", int(x)))]
+
+
+def allgather_float(x):
+    return [struct.unpack("<d", p)[0] for p in allgather_bytes(struct.pack("<d", float(x)))]
 
 
 def allreduce_sum_array(a):

@@ -61,9 +61,9 @@ class NNDSVD(NMF):
             self._logger.setLevel(logging.INFO)
         else:
             self._logger.setLevel(logging.ERROR)
-        if not hasattr(self, 'W'):
+        if not self._has('W'):
             self.init_w()
-        if not hasattr(self, 'H'):
+        if not self._has('H'):
             self.init_h()
         if compute_err:
             self.ferr = np.zeros(1)

@@ -76,9 +76,9 @@ class RNMF(NMF):
 
     def factorize(self, niter=1, show_progress=False,
                   compute_w=True, compute_h=True, compute_err=True):
-        if not hasattr(self, 'W'):                              # nmf.py:173-177 order: W, then H (+ S)
+        if not self._has('W'):                              # nmf.py:173-177 order: W, then H (+ S)
             self.init_w()
-        if not hasattr(self, 'H'):
+        if not self._has('H'):
             self.init_h()
         if niter > 0 and (compute_w or compute_h):
             self._require_s()

@@ -105,3 +105,54 @@ def test_class_level_multi_rank_path_on_one_gpu():
     (PYMF_DIST_TRANSPORT=host -> pmf_set_host_allreduce): NMF / SNMF / RNMF / NNDSVD objects fed
     their row blocks must reproduce the unsharded oracle."""
     _spawn_workers("_dist_class_worker.py", 2, extra_env={"PYMF_DIST_TRANSPORT": "host", "LOCAL_RANK": "0"})
+
+
+# ---- who may join the rendezvous (pymf_amd/dist.py: bind, challenge-response, frame cap) ----------------
+def test_non_loopback_rendezvous_needs_a_secret(monkeypatch):
+    from pymf_amd import dist
+    monkeypatch.delenv("PYMF_DIST_SECRET", raising=False)
+    with pytest.raises(RuntimeError, match="PYMF_DIST_SECRET"):
+        dist._key("10.1.2.3", "29500", 2, "10.1.2.3")
+    monkeypatch.setenv("PYMF_DIST_SECRET", "s3cret")
+    k1 = dist._key("10.1.2.3", "29500", 2, "10.1.2.3")
+    monkeypatch.setenv("PYMF_DIST_SECRET", "other")
+    assert k1 != dist._key("10.1.2.3", "29500", 2, "10.1.2.3")
+    monkeypatch.delenv("PYMF_DIST_SECRET")
+    assert dist._key("127.0.0.1", "29500", 2, "127.0.0.1")           # loopback: derived from the launcher's env
+
+
+def test_wrong_key_and_strangers_cannot_join_and_frames_are_capped():
+    """Rank 0's accept loop against: a peer with the wrong key, a peer that sends garbage, then the real rank 1.
+    Only the last one is admitted; afterwards an over-long frame header is refused."""
+    import struct
+    import threading
+    from pymf_amd import dist
+    key, bad = b"k" * 32, b"x" * 32
+    port = _free_port()
+    result = {}
+
+    def serve():
+        try:
+            result["peers"] = dist._serve("127.0.0.1", port, 2, key, timeout=30.0)
+        except Exception as e:       # pragma: no cover
+            result["err"] = e
+
+    th = threading.Thread(target=serve)
+    th.start()
+    with pytest.raises(RuntimeError):
+        dist._join("127.0.0.1", port, 1, bad, timeout=1.0)          # never acknowledged
+    s = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+    s.sendall(b"GET / HTTP/1.0\r\n\r\n" + b"\0" * 64)                 # a stranger
+    s.close()
+    mine = dist._join("127.0.0.1", port, 1, key, timeout=20.0)
+    th.join(timeout=30.0)
+    assert "err" not in result and list(result["peers"]) == [1]
+    try:
+        mine[0].sendall(struct.pack("<Q", dist._MAX_FRAME + 1))
+        with pytest.raises(ConnectionError, match="PYMF_DIST_MAX_FRAME"):
+            dist._recv(result["peers"][1])
+    finally:
+        mine[0].close()
+        result["peers"][1].close()
+        dist._LISTENER.close()
+        dist._LISTENER = None

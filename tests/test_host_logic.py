@@ -80,3 +80,122 @@ def test_stream_switches():
 def test_row_span_single_rank():
     m = pymf_amd.NMF(np.ones((37, 5), dtype=np.float32), num_bases=2)
     assert m._row_span() == (0, 37, 37) and m._global_rows() == 37
+
+
+class _CountingCtx(object):
+    """Test double of _lib.Context (NumPy float64 math through the oracle's functions) that counts what
+    crosses the boundary: uploads of W / H and downloads of them."""
+
+    def __init__(self, m, n, k):
+        self.m, self.n, self.k = m, n, k
+        self.up = {"W": 0, "H": 0, "V": 0}
+        self.down = {"W": 0, "H": 0}
+
+    def set_v_dense(self, V):
+        self.V = np.asarray(V, dtype=np.float64)
+        self.up["V"] += 1
+
+    def set_w(self, W):
+        self.W = np.array(W, dtype=np.float64)
+        self.up["W"] += 1
+
+    def set_h(self, H):
+        self.H = np.array(H, dtype=np.float64)
+        self.up["H"] += 1
+
+    def get_w(self):
+        self.down["W"] += 1
+        return self.W.astype(np.float32)
+
+    def get_h(self):
+        self.down["H"] += 1
+        return self.H.astype(np.float32)
+
+    def invalidate_v(self):
+        pass
+
+    def factorize(self, niter, compute_w=True, compute_h=True, compute_err=True, conv_eps=1e-8):
+        import oracle
+        for _ in range(niter):
+            if compute_w:
+                oracle.nmf_update_w(self.V, self.W, self.H)
+            if compute_h:
+                oracle.nmf_update_h(self.V, self.W, self.H)
+        return (np.ones(max(niter, 1)) if compute_err else None), niter, -1
+
+
+def _model_with_double(m=40, n=12, k=3, seed=0):
+    rs = np.random.RandomState(seed)
+    mdl = pymf_amd.NMF(rs.rand(m, n).astype(np.float32), num_bases=k)
+    mdl._ctx = _CountingCtx(m, n, k)
+    mdl.W, mdl.H = rs.rand(m, k), rs.rand(k, n)
+    return mdl
+
+
+def test_factors_stay_on_the_device_between_calls_when_nobody_can_see_the_host_arrays():
+    """`mdl.factorize(); mdl.factorize(); mdl.W`: the host arrays belong to the object alone, so they are
+    brought up to date when they are read -- one download of W and H in all, one upload."""
+    import oracle
+    mdl = _model_with_double()
+    ref = oracle.NMFOracle(mdl.data, num_bases=3)
+    ref.W, ref.H = mdl.__dict__["_W"].copy(), mdl.__dict__["_H"].copy()
+    ctx = mdl._ctx
+    mdl.factorize(niter=2, compute_err=False)
+    mdl.factorize(niter=3, compute_err=False)
+    assert ctx.up == {"W": 1, "H": 1, "V": 1} and ctx.down == {"W": 0, "H": 0}
+    ref.factorize(niter=5, compute_err=False)
+    np.testing.assert_allclose(mdl.W, ref.W, rtol=1e-6)      # the read refreshes (float32 transport)
+    np.testing.assert_allclose(mdl.H, ref.H, rtol=1e-6)
+    assert ctx.down == {"W": 1, "H": 1}
+    mdl.factorize(niter=1, compute_err=False)                 # handed out, unchanged: digested, not uploaded
+    assert ctx.up["W"] == 1 and ctx.up["H"] == 1
+
+
+def test_held_arrays_are_updated_in_place_after_every_call():
+    """`w = mdl.W; mdl.factorize(); w` has changed (nmf.py:131-132 writes in place): an array somebody
+    else holds -- a name, or a view of it -- is refreshed eagerly."""
+    mdl = _model_with_double(seed=1)
+    w = mdl.W
+    before = w.copy()
+    mdl.factorize(niter=1, compute_err=False)
+    assert mdl._ctx.down["W"] == 1 and not np.array_equal(w, before) and mdl.W is w
+    assert mdl._ctx.down["H"] == 0                            # nobody holds H
+    hv = mdl.H[:1]                                            # a live VIEW keeps the base reachable
+    assert mdl._ctx.down["H"] == 1
+    mdl.factorize(niter=1, compute_err=False)
+    assert mdl._ctx.down["H"] == 2
+    del hv
+
+
+def test_in_place_edit_through_the_attribute_reaches_the_device():
+    mdl = _model_with_double(seed=2)
+    mdl.factorize(niter=1, compute_err=False)
+    mdl.H[0, 0] += 1.0                                        # read (refresh) + edit in place
+    expect = mdl.__dict__["_H"].copy()
+    mdl.factorize(niter=0, compute_err=False)
+    assert mdl._ctx.up["H"] == 2
+    np.testing.assert_allclose(mdl._ctx.H, expect.astype(np.float32), rtol=1e-6)
+
+
+def test_eager_factors_switch_and_views_of_user_memory():
+    mdl = _model_with_double(seed=3)
+    mdl.eager_factors = True
+    mdl.factorize(niter=1, compute_err=False)
+    assert mdl._ctx.down == {"W": 1, "H": 1}
+    big = np.random.rand(40, 8)
+    m2 = _model_with_double(seed=4)
+    m2.W = big[:, :3]                                         # a view of the caller's buffer: never lazy
+    assert m2._held_elsewhere("W")
+    m2.factorize(niter=1, compute_err=False)
+    assert m2._ctx.down["W"] == 1
+    np.testing.assert_allclose(big[:, :3], m2._ctx.W, rtol=1e-6)
+
+
+def test_pickling_flushes_the_host_arrays():
+    import pickle
+    mdl = _model_with_double(seed=5)
+    mdl.factorize(niter=2, compute_err=False)
+    assert mdl._host_stale == {"W", "H"}
+    clone = pickle.loads(pickle.dumps(mdl))
+    assert clone._ctx is None and clone._host_stale == set()
+    np.testing.assert_allclose(clone.__dict__["_W"], mdl._ctx.W, rtol=1e-6)
