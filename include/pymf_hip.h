@@ -174,7 +174,10 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *                k x n sized data, W materialised once after the last iteration -- instead of one pass
  *                over V per iteration: -1 automatic (default: CSR data always, dense data from about
  *                n / 2k iterations on), 0 never, 1 whenever the shape allows (n <= 1024), 2 as 1 but W = V M is
- *                written in EVERY iteration (what the reference's update_w does; same results). */
+ *                written in EVERY iteration (what the reference's update_w does; same results).
+ *   "force_tiled" 1: every path of this context takes the any-shape two-pass kernels (k_rowgemm / k_colgemm)
+ *                even where a one-pass kernel covers the shape; 0 gives the one-pass kernels back.  For tests
+ *                and measurements of the any-shape kernels on the bench shapes. */
 int pmf_set_option(pmf_ctx* ctx, const char* name, int64_t value);
 
 /* Host transport for the cross-rank sums, for set-ups in which the ranks cannot form an RCCL communicator

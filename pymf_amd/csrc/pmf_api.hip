@@ -99,6 +99,9 @@ struct pmf_ctx {
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
+  int fused_wgs_hidden = 0;     // pmf_set_option("force_tiled", 1) parks fused_wgs / fused8 here: every path then takes the
+  bool fused8_hidden = false;   // any-shape two-pass kernels (k_rowgemm / k_colgemm) -- test and measurement aid
+  std::string path_hidden;
   bool fused8 = false;          // ... and it is the cooperative form (pmf_coop.h: 64 < k <= 128, or k <= 64 with n > 256)
   int coop_bt = 0, coop_rb = 0; // its base tiles per wave / row blocks per tile
   bool have_v = false, have_w = false, have_h = false, g_valid = false;
@@ -953,16 +956,18 @@ int ensure_vgram(pmf_ctx* c) {
     const int wgs = use_lds ? 256 : 32;            // global images are E doubles each: fewer of them
     double* slabs = nullptr;
     PMFCHK(talloc(c, tmp, &slabs, (size_t)wgs * E));   // zeroed
+    const size_t smem = (use_lds ? E * sizeof(double) : 0) + gram_stage_bytes();
     static bool attr_done_dev[PMF_MAX_DEVICES] = {};
     bool& attr_done = attr_done_dev[pmf_current_device()];
     if (!attr_done) {
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_gram), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_gram), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(128 * 1024 + gram_stage_bytes())));
       attr_done = true;
     }
-    hipLaunchKernelGGL(k_csr_gram, dim3((unsigned)wgs), dim3(256), use_lds ? E * sizeof(double) : 0, c->stream, c->dIndptr,
+    hipLaunchKernelGGL(k_csr_gram, dim3((unsigned)wgs), dim3(64 * GRAM_WAVES), smem, c->stream, c->dIndptr,
                        c->dIndices, c->dVals, c->m, np, slabs, use_lds);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, slabs, wgs, (int64_t)E, c->dC);
+    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, slabs, wgs, np, c->dC);
     HIPCHK(c, hipGetLastError());
     PMFCHK(allreduce_sum(c, c->dC, E, true));
     HIPCHK(c, hipStreamSynchronize(c->stream));    // the scratch is freed on return
@@ -2168,6 +2173,23 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2) {
 // everything derived from it -- ||V||^2, (W^T V | W^T W), the cached V H^T.
 int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return PMF_EINVAL;
+  if (std::strcmp(name, "force_tiled") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "force_tiled: 0 or 1");
+    if (value == 1 && c->fused_wgs > 0) {
+      c->fused_wgs_hidden = c->fused_wgs; c->fused8_hidden = c->fused8;
+      c->fused_wgs = 0; c->fused8 = false;
+      c->path_hidden = c->path;
+      c->path = "tiled (forced)";
+    } else if (value == 0 && c->fused_wgs_hidden > 0) {
+      c->fused_wgs = c->fused_wgs_hidden; c->fused8 = c->fused8_hidden;
+      c->fused_wgs_hidden = 0;
+      c->path = c->path_hidden;
+    }
+    c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
+    if (c->g_parts > 0) { c->g_valid = false; c->g_parts = 0; }
+    choose_stat_site(c, false);
+    return PMF_OK;
+  }
   if (std::strcmp(name, "snmf_gram") == 0) {
     if (value < -1 || value > 2) return fail(c, PMF_EINVAL, "snmf_gram: -1 (auto), 0 (off), 1 (on) or 2 (on, W written every iteration)");
     c->opt_snmf_gram = (int)value;

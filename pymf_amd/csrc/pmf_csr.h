@@ -10,48 +10,167 @@
 
 // C = V^T V (np x np, float64) of CSR data, for the Gram-space SNMF loop: a row with c entries adds its
 // c^2 products v_a v_b to C[col_a][col_b] (duplicates included: (a + b)^2 = aa + ab + ba + bb, the semantics
-// of V.toarray()).  One wave per row at a time, lanes <-> pairs of entries; every workgroup accumulates its
-// rows into a private image of C -- in LDS when it fits (np <= 128: float64 LDS atomics), else directly into
-// its slab in global memory (float64 global atomics) -- and k_csr_gram_sum adds the slabs in fixed order.
+// of V.toarray()).  C is symmetric and v_a v_b = v_b v_a exactly, so only the pairs with col_a <= col_b are
+// added (to the upper triangle) and k_csr_gram_sum mirrors.
+//
+// A wave takes 64 ROWS at a time (lane <-> row: two coalesced loads bring the 65 row pointers), stages the
+// block's T entries (column, value) and, per entry, the row it belongs to in a small LDS area of its own, and
+// then works lane <-> ENTRY: entry t of row r is paired with the c_r entries of its row, one per trip, so a
+// trip of the wave issues up to 64 products whatever the row lengths are (1.28 entries per row at cfg5: one
+// wave per row, lanes <-> pairs -- the first form of this kernel -- left 62 lanes idle and spent three
+// dependent memory latencies per row: 1.48 ms for 77 MB).  The loads are software-pipelined: while block i
+// is paired, the entries of block i + 1 and the row pointers of block i + 2 are in flight (a wave owns a
+// CONTIGUOUS range of blocks).  A block with GRAM_CAP or more entries (dense rows) takes the row-by-row
+// form.  Every workgroup accumulates into a private image of C -- in LDS when it fits (np <= 128: float64 LDS
+// atomics), else directly into its slab in global memory -- and k_csr_gram_sum adds the slabs in fixed order.
 // float32 products are exact in float64, so the only run-to-run freedom is the order of float64 additions
 // inside a workgroup (1e-16 relative).
-__global__ __launch_bounds__(256) void k_csr_gram(const int64_t* __restrict__ indptr,
-                                                  const int32_t* __restrict__ indices,
-                                                  const float* __restrict__ vals, int64_t rows, int np,
-                                                  double* __restrict__ slabs, int use_lds) {
+constexpr int GRAM_CAP = 256;       // entries of a 64-row block staged per wave
+constexpr int GRAM_WAVES = 8;       // waves per workgroup
+constexpr size_t gram_stage_bytes() { return (size_t)GRAM_WAVES * (GRAM_CAP * (4 + 4 + 1) + 64 * 4 + 64); }
+
+__global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __restrict__ indptr,
+                                                              const int32_t* __restrict__ indices,
+                                                              const float* __restrict__ vals, int64_t rows, int np,
+                                                              double* __restrict__ slabs, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) double sC[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double* img = use_lds ? sC : slabs + (size_t)blockIdx.x * np * np;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int E = np * np;
+  double* img = use_lds ? sC : slabs + (size_t)blockIdx.x * E;
+  // per-wave staging behind the image: columns, values, row of every entry, first entry and length of every row
+  char* stage = reinterpret_cast<char*>(sC + (use_lds ? E : 0)) + (size_t)wv * (GRAM_CAP * 9 + 64 * 4 + 64);
+  int* sCol = reinterpret_cast<int*>(stage);
+  float* sVal = reinterpret_cast<float*>(stage + GRAM_CAP * 4);
+  int* sRel = reinterpret_cast<int*>(stage + GRAM_CAP * 8);
+  unsigned char* sCnt = reinterpret_cast<unsigned char*>(stage + GRAM_CAP * 8 + 64 * 4);
+  unsigned char* sRow = reinterpret_cast<unsigned char*>(stage + GRAM_CAP * 8 + 64 * 4 + 64);
   if (use_lds) {
-    for (int q = tid; q < np * np; q += 256) sC[q] = 0.0;
+    for (int q = tid; q < E; q += 64 * GRAM_WAVES) sC[q] = 0.0;
     __syncthreads();
   }
-  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * per;
-  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
-  for (int64_t row = r0 + wv; row < r1; row += 4) {
-    const int64_t a = indptr[row], b = indptr[row + 1];
-    const int cnt = (int)(b - a);
-    for (int pq = lane; pq < cnt * cnt; pq += 64) {
-      const int e1 = pq / cnt, e2 = pq % cnt;
-      const double v = (double)vals[a + e1] * (double)vals[a + e2];
-      atomicAdd(&img[(size_t)indices[a + e1] * np + indices[a + e2]], v);
+  // this wave's contiguous range of 64-row blocks
+  const int64_t nblk = (rows + 63) / 64;
+  const int64_t nwaves = (int64_t)gridDim.x * GRAM_WAVES, gw = (int64_t)blockIdx.x * GRAM_WAVES + wv;
+  const int64_t per = nblk / nwaves, extra = nblk % nwaves;
+  const int64_t b0 = gw * per + (gw < extra ? gw : extra), nb = per + (gw < extra ? 1 : 0);
+  const int64_t nnz = indptr[rows];
+
+  auto load_ptrs = [&](int64_t blk, int64_t& ip, int64_t& ipn) {      // row pointers of block blk (lane <-> row)
+    const int64_t r = blk * 64 + lane;
+    ip = indptr[r < rows ? r : rows];
+    ipn = indptr[r + 1 < rows ? r + 1 : rows];
+  };
+  int ecol[GRAM_CAP / 64];
+  float eval_[GRAM_CAP / 64];
+  auto load_entries = [&](int64_t a0, int T) {                          // entries [a0, a0 + min(T, CAP)) -> registers
+#pragma unroll
+    for (int u = 0; u < GRAM_CAP / 64; ++u) {
+      const int t = 64 * u + lane;
+      ecol[u] = 0; eval_[u] = 0.f;
+      if (t < T && a0 + t < nnz) { ecol[u] = indices[a0 + t]; eval_[u] = vals[a0 + t]; }
     }
+  };
+  auto first64 = [&](int64_t v) -> int64_t {                            // lane 0's value, wave-uniform
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+  };
+
+  int64_t ipA = 0, ipnA = 0, ipB = 0, ipnB = 0;
+  if (nb > 0) load_ptrs(b0, ipA, ipnA);
+  if (nb > 1) load_ptrs(b0 + 1, ipB, ipnB);
+  int64_t a0 = 0;
+  int T = 0;
+  if (nb > 0) {
+    a0 = first64(ipA);
+    T = (int)(__builtin_amdgcn_readlane((int)(ipnA - a0), 63));
+    load_entries(a0, T);
+  }
+  for (int64_t bi = 0; bi < nb; ++bi) {
+    const int rel = (int)(ipA - a0), cnt = (int)(ipnA - ipA);
+    const int Tcur = T;
+    const int64_t a0cur = a0;
+    const bool staged = Tcur < GRAM_CAP;          // (row lengths are staged as bytes: < 256 entries in all)
+    if (staged) {
+      // stage block bi (its entries are in registers), then request block bi + 1's entries and bi + 2's pointers
+#pragma unroll
+      for (int u = 0; u < GRAM_CAP / 64; ++u) {
+        const int t = 64 * u + lane;
+        if (t < Tcur) { sCol[t] = ecol[u]; sVal[t] = eval_[u]; }
+      }
+      sRel[lane] = rel;
+      sCnt[lane] = (unsigned char)(cnt < 255 ? cnt : 255);
+      for (int j = 0; j < cnt; ++j) sRow[rel + j] = (unsigned char)lane;
+    }
+    // pipeline: next block's pointers are at hand (ipB), its entries are requested now
+    int64_t ipC = 0, ipnC = 0;
+    if (bi + 2 < nb) load_ptrs(b0 + bi + 2, ipC, ipnC);
+    int64_t a0n = 0;
+    int Tn = 0;
+    if (bi + 1 < nb) {
+      a0n = first64(ipB);
+      Tn = (int)(__builtin_amdgcn_readlane((int)(ipnB - a0n), 63));
+      if (staged) load_entries(a0n, Tn);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the wave's own LDS writes are in place
+    if (staged) {
+      for (int tb = 0; tb < Tcur; tb += 64) {
+        const int t = tb + lane;
+        const bool act = t < Tcur;
+        const int r = act ? sRow[t] : 0;
+        const int ea = sRel[r];
+        const int c = act ? sCnt[r] : 0;
+        const int col1 = act ? sCol[t] : 0;
+        const double v1 = act ? (double)sVal[t] : 0.0;
+        int cm = c;                                                     // longest row among this trip's entries
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cm = max(cm, __shfl_xor(cm, o, 64));
+        for (int j = 0; j < cm; ++j) {
+          if (j < c) {
+            const int col2 = sCol[ea + j];
+            if (col1 <= col2) atomicAdd(&img[(size_t)col1 * np + col2], v1 * (double)sVal[ea + j]);
+          }
+        }
+      }
+    } else {
+      // a block of long rows: row by row, lanes <-> pairs of entries (reads straight from global)
+      for (int rr = 0; rr < 64; ++rr) {
+        const int ra = __builtin_amdgcn_readlane(rel, rr), rc = __builtin_amdgcn_readlane(cnt, rr);
+        const int64_t base = a0cur + ra;
+        for (int64_t pq = lane; pq < (int64_t)rc * rc; pq += 64) {
+          const int e1 = (int)(pq / rc), e2 = (int)(pq % rc);
+          const int col1 = indices[base + e1], col2 = indices[base + e2];
+          if (col1 <= col2) atomicAdd(&img[(size_t)col1 * np + col2], (double)vals[base + e1] * (double)vals[base + e2]);
+        }
+      }
+      if (bi + 1 < nb) load_entries(a0n, Tn);
+    }
+    __builtin_amdgcn_wave_barrier();
+    ipA = ipB; ipnA = ipnB; ipB = ipC; ipnB = ipnC;
+    a0 = a0n; T = Tn;
   }
   if (use_lds) {
     __syncthreads();
-    double* out = slabs + (size_t)blockIdx.x * np * np;
-    for (int q = tid; q < np * np; q += 256) out[q] = sC[q];
+    double* out = slabs + (size_t)blockIdx.x * E;
+    for (int q = tid; q < E; q += 64 * GRAM_WAVES)
+      if (q / np <= q % np) out[q] = sC[q];                             // the upper triangle is all there is
   }
 }
 
-__global__ __launch_bounds__(256) void k_csr_gram_sum(const double* __restrict__ slabs, int nslabs, int64_t E,
+// C = sum of the slabs' upper triangles (fixed order), mirrored.
+__global__ __launch_bounds__(256) void k_csr_gram_sum(const double* __restrict__ slabs, int nslabs, int np,
                                                       double* __restrict__ C) {
+  const int64_t E = (int64_t)np * np;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
+  const int r = (int)(e / np), c = (int)(e % np);
+  if (r > c) return;
   double s = 0.0;
   for (int q = 0; q < nslabs; ++q) s += slabs[(size_t)q * E + e];
   C[e] = s;
+  C[(int64_t)c * np + r] = s;
 }
 
 // W = V M for CSR V, the write-bound form (the Gram-space SNMF loop materialises W with it, once per

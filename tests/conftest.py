@@ -35,11 +35,11 @@ def golden():
 # ---- parity ledger -------------------------------------------------------------------------------
 # Every comparison of a device result with the oracle / a reference golden goes through rel_fro()
 # or close(): both record (test, source line, quantity, achieved error, tolerance) and the session
-# writes them to gpurun_out/parity_r02.json (copied to profiles/ and committed), so the achieved
+# writes them to gpurun_out/parity_r03.json (copied to profiles/ and committed), so the achieved
 # errors -- not only "it passed" -- are on record and the tolerances can be held next to them.
 _LEDGER = []
 _CURRENT = {"test": None}
-LEDGER_PATH = os.environ.get("PMF_PARITY_LEDGER", os.path.join(ROOT, "gpurun_out", "parity_r02.json"))
+LEDGER_PATH = os.environ.get("PMF_PARITY_LEDGER", os.path.join(ROOT, "gpurun_out", "parity_r03.json"))
 
 
 @pytest.fixture(autouse=True)

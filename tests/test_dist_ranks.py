@@ -156,3 +156,15 @@ def test_wrong_key_and_strangers_cannot_join_and_frames_are_capped():
         result["peers"][1].close()
         dist._LISTENER.close()
         dist._LISTENER = None
+
+
+@pytest.mark.gpu
+def test_class_level_multi_rank_path_over_rccl():
+    """One RCCL rank per GPU (needs a box with >= 2 GPUs; the 1-GPU boxes skip it): the class-level worker with the
+    default transport -- every cross-rank sum of the refactored allreduce_sum() helper goes through ncclAllReduce:
+    (P | S) per iteration, ||V||^2, RNMF's error, the float64 V^T V of the Gram-space SNMF loop, NNDSVD's Gram and
+    split norms."""
+    from pymf_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: one RCCL rank per GPU")
+    _spawn_workers("_dist_class_worker.py", 2)
