@@ -70,6 +70,7 @@ struct pmf_ctx {
   double* dGinvD = nullptr;     // SNMF: inv(H H^T) in float64, [KP][KP]
   // Gram-space SNMF loop (snmf_gram_iteration): C = V^T V over all ranks' rows, and the float64 M^T, P
   double *dC = nullptr, *dMTd = nullptr, *dPd = nullptr;
+  double* dCslabs = nullptr;    // k_csr_gram: per-workgroup images of C
   bool c_valid = false;         // dC holds the all-rank V^T V of the current V
   int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible, 2 = 1 + W written in every iteration
   bool w_implicit = false;      // the loop ran in Gram space: dW is stale, W = V M with the M at hand (materialize_w)
@@ -950,12 +951,14 @@ int ensure_vgram(pmf_ctx* c) {
   if (!c->dMTd) PMFCHK(dalloc(c, &c->dMTd, (size_t)c->KP * np));
   if (!c->dPd) PMFCHK(dalloc(c, &c->dPd, (size_t)c->KP * np));
   if (use_csr(c)) {                 // k_csr_gram: per-workgroup images of C, added up in fixed order
-    DevTemps tmp;
     const size_t E = (size_t)np * np;
     const int use_lds = E * sizeof(double) <= 128 * 1024;
     const int wgs = use_lds ? 256 : 32;            // global images are E doubles each: fewer of them
-    double* slabs = nullptr;
-    PMFCHK(talloc(c, tmp, &slabs, (size_t)wgs * E));   // zeroed
+    // per-workgroup images of C: kept with the context (32 MiB at n = 128); zeroed only where the kernel adds
+    // into them directly (LDS images are written out whole)
+    if (!c->dCslabs) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dCslabs), (size_t)wgs * E * sizeof(double)));
+    double* slabs = c->dCslabs;
+    if (!use_lds) HIPCHK(c, hipMemsetAsync(slabs, 0, (size_t)wgs * E * sizeof(double), c->stream));
     const size_t smem = (use_lds ? E * sizeof(double) : 0) + gram_stage_bytes();
     static bool attr_done_dev[PMF_MAX_DEVICES] = {};
     bool& attr_done = attr_done_dev[pmf_current_device()];
@@ -967,10 +970,9 @@ int ensure_vgram(pmf_ctx* c) {
     hipLaunchKernelGGL(k_csr_gram, dim3((unsigned)wgs), dim3(64 * GRAM_WAVES), smem, c->stream, c->dIndptr,
                        c->dIndices, c->dVals, c->m, np, slabs, use_lds);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, slabs, wgs, np, c->dC);
+    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, c->stream, slabs, wgs, np, c->dC);
     HIPCHK(c, hipGetLastError());
     PMFCHK(allreduce_sum(c, c->dC, E, true));
-    HIPCHK(c, hipStreamSynchronize(c->stream));    // the scratch is freed on return
   } else {
     DevTemps tmp;
     const int64_t blocks16 = c->mp / 16;
@@ -1536,7 +1538,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);

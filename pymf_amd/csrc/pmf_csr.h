@@ -159,18 +159,30 @@ __global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __r
   }
 }
 
-// C = sum of the slabs' upper triangles (fixed order), mirrored.
+// C = sum of the slabs' upper triangles (fixed order), mirrored.  Block b owns 64 consecutive elements;
+// thread (g = tid / 64, e = tid % 64) adds slabs g, g + 4, ... (independent loads, eight in flight), the four
+// partial sums are combined in the order of g.
 __global__ __launch_bounds__(256) void k_csr_gram_sum(const double* __restrict__ slabs, int nslabs, int np,
                                                       double* __restrict__ C) {
+  __shared__ double part[4][64];
   const int64_t E = (int64_t)np * np;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
-  const int r = (int)(e / np), c = (int)(e % np);
-  if (r > c) return;
+  const int g = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool live = e < E && (e / np) <= (e % np);
   double s = 0.0;
-  for (int q = 0; q < nslabs; ++q) s += slabs[(size_t)q * E + e];
-  C[e] = s;
-  C[(int64_t)c * np + r] = s;
+  if (live) {
+#pragma unroll 8
+    for (int q = g; q < nslabs; q += 4) s += slabs[(size_t)q * E + e];
+  }
+  part[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && live) {
+    const int l = threadIdx.x & 63;
+    const double t = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+    const int r = (int)(e / np), c = (int)(e % np);
+    C[e] = t;
+    C[(int64_t)c * np + r] = t;
+  }
 }
 
 // W = V M for CSR V, the write-bound form (the Gram-space SNMF loop materialises W with it, once per
