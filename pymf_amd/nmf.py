@@ -119,6 +119,7 @@ class NMF(object):
         self._handed = set()     # factors whose host array was read through .W / .H since it was last synchronised
         self._defer_pull = False
         self._in_loop = False
+        self._loop_data_checked = False
 
     # ---- W / H: plain attributes to the user, lazily refreshed from the device in the hook loop ----
     def _factor_get(self, name):
@@ -256,8 +257,9 @@ class NMF(object):
 
     def _sync_to_device(self, with_data=True):
         ctx = self._context()
-        if with_data and not self._in_loop:
-            # inside factorize()'s loop `data` was checked once, when the loop started
+        if with_data and (not self._in_loop or not self._loop_data_checked):
+            # inside factorize()'s hook loop `data` is checked once, by the first shipped hook that runs
+            self._loop_data_checked = True
             if self._stream_rows():
                 if self._v_src is not self.data or self.check_data:
                     ctx.invalidate_v()            # streamed data is re-read every pass; ||V||^2 with it
@@ -356,6 +358,7 @@ class NMF(object):
         self._pull(ctx, False, True)
 
     def update_w(self):                                        # nmf.py:128-132
+        self._keep_w_on_host_if_the_step_may_fail()
         ctx = self._sync_to_device()
         rows = self._stream_rows()
         try:
@@ -364,10 +367,22 @@ class NMF(object):
             else:
                 ctx.update_w()
         except Exception:                                      # e.g. SNMF: LinAlgError behind a singular H H^T
-            self._w_fp = self._h_fp = None                     # the host arrays go up again with the next call
-            self._host_stale.clear()
+            # the reference raises before it rebinds W (snmf.py:69-70): W is what it was, H is untouched.
+            # Here the device W is gone: the host array (kept current above) goes up again with the next
+            # call; the device H is still good and stays the newer copy if it was.
+            self._w_fp = None
+            self._host_stale.discard("W")
             raise
         self._pull(ctx, True, False)
+
+    #: True for classes whose W step can raise (SNMF: np.linalg.inv on a singular H H^T, snmf.py:69)
+    _W_STEP_MAY_FAIL = False
+
+    def _keep_w_on_host_if_the_step_may_fail(self):
+        """A failing W step leaves garbage in the device W; the reference would still hold the previous W.
+        Where that can happen the host array is brought up to date first."""
+        if self._W_STEP_MAY_FAIL and "W" in self._host_stale:
+            self._refresh_host("W")
 
     def converged(self, i):                                    # nmf.py:134-139
         derr = np.abs(self.ferr[i] - self.ferr[i - 1]) / self._num_samples
@@ -402,10 +417,13 @@ class NMF(object):
         if compute_err:                                        # nmf.py:179-180
             self.ferr = np.zeros(niter)
 
-        ctx = self._sync_to_device()
         rows = self._stream_rows()
         if self._hooks_overridden() or (show_progress and not rows):
+            # the hooks synchronise what THEY need: a subclass that computes on the host never pays for an upload
             return self._factorize_by_hooks(niter, compute_w, compute_h, compute_err)
+        if compute_w:
+            self._keep_w_on_host_if_the_step_may_fail()
+        ctx = self._sync_to_device()
         if rows:                                               # a Python loop already: logs as it runs
             ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
             self._last_iters = done
@@ -421,7 +439,8 @@ class NMF(object):
                                                     conv_eps=self._EPS)
             except Exception:
                 # the device factors are in an unknown state (e.g. behind a singular H H^T): the host arrays
-                # are what the object holds, and they go up again with the next call
+                # -- W kept current above where the step may fail, H as of the last read -- are what the object
+                # holds, and they go up again with the next call
                 self._w_fp = self._h_fp = None
                 self._host_stale.clear()
                 raise
@@ -444,6 +463,7 @@ class NMF(object):
         the user) reads `.W` / `.H`, and in any case before factorize() returns."""
         self._defer_pull = True
         self._in_loop = True
+        self._loop_data_checked = False
         done = 0
         try:
             for i in range(niter):

@@ -18,6 +18,7 @@ class SNMF(NMF):
     _SHIPPED = True
     _ALGO = _lib.ALGO_SNMF
     _REBIND_W = True
+    _W_STEP_MAY_FAIL = True      # np.linalg.inv(H H^T) raises on a singular matrix (snmf.py:69)
 
     def _upload_sparse(self, ctx):
         csr = self.data.tocsr()

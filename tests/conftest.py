@@ -38,21 +38,44 @@ def golden():
 # writes them to gpurun_out/parity_r03.json (copied to profiles/ and committed), so the achieved
 # errors -- not only "it passed" -- are on record and the tolerances can be held next to them.
 _LEDGER = []
-_CURRENT = {"test": None}
+_CURRENT = {"test": None, "seen": {}}
+
+# Per-case tolerances: the literal in a test is the bar of its whole function (often a parametrised one); the
+# table holds, for every single comparison -- (test id, quantity, n-th occurrence) --, ten times the worst error
+# that comparison has shown on the MI355X boxes (never above the literal, never below 1e-9 / 1e-12 for float64
+# quantities): tools/tighten_tolerances.py writes it from the ledger.  A comparison uses the smaller of the two.
+_TOL_TABLE = {}
+try:
+    import json as _json
+    with open(os.path.join(ROOT, "tests", "golden", "tolerances.json")) as _f:
+        _TOL_TABLE = _json.load(_f)["cases"]
+except (OSError, ValueError, KeyError):
+    _TOL_TABLE = {}
+
+
+def _case_tol(what, tol):
+    key0 = "%s|%s" % (_CURRENT["test"], what)
+    n = _CURRENT["seen"].get(key0, 0)
+    _CURRENT["seen"][key0] = n + 1
+    key = "%s|%d" % (key0, n)
+    t = _TOL_TABLE.get(key)
+    return (min(float(tol), float(t)) if t is not None else float(tol)), key
 LEDGER_PATH = os.environ.get("PMF_PARITY_LEDGER", os.path.join(ROOT, "gpurun_out", "parity_r03.json"))
 
 
 @pytest.fixture(autouse=True)
 def _ledger_current_test(request):
     _CURRENT["test"] = request.node.nodeid
+    _CURRENT["seen"] = {}
     yield
     _CURRENT["test"] = None
 
 
-def _record(kind, what, value, tol, depth=2):
+def _record(kind, what, value, tol, depth=2, stated=None, key=None):
     f = sys._getframe(depth)
     _LEDGER.append({"test": _CURRENT["test"], "at": "%s:%d" % (os.path.basename(f.f_code.co_filename), f.f_lineno),
                     "kind": kind, "what": what, "achieved": float(value), "tol": float(tol),
+                    "stated_tol": float(tol if stated is None else stated), "case": key,
                     "ok": bool(value <= tol)})
 
 
@@ -61,12 +84,14 @@ class Measured(float):
     what = ""
 
     def __lt__(self, tol):
-        _record("rel_fro", self.what, float(self), float(tol))
-        return float(self) < float(tol)
+        eff, key = _case_tol(self.what, tol)
+        _record("rel_fro", self.what, float(self), eff, stated=tol, key=key)
+        return float(self) < eff
 
     def __le__(self, tol):
-        _record("rel_fro", self.what, float(self), float(tol))
-        return float(self) <= float(tol)
+        eff, key = _case_tol(self.what, tol)
+        _record("rel_fro", self.what, float(self), eff, stated=tol, key=key)
+        return float(self) <= eff
 
 
 def rel_fro(a, b, what=""):
@@ -82,11 +107,16 @@ def close(actual, desired, rtol=1e-7, atol=0.0, what="", err_msg=""):
     tolerance band: max |a - d| / (atol + rtol |d|) * rtol  (the relative error when atol = 0)."""
     a = np.asarray(actual, dtype=np.float64)
     d = np.asarray(desired, dtype=np.float64)
+    stated = rtol
+    if atol == 0.0:
+        rtol, key = _case_tol(what, rtol)          # (a band with an absolute part keeps its literal)
+    else:
+        key = None
     if a.shape == d.shape and a.size:
-        band = atol + rtol * np.abs(d)
+        band = atol + stated * np.abs(d)
         with np.errstate(divide="ignore", invalid="ignore"):
             r = np.where(band > 0, np.abs(a - d) / band, np.where(a == d, 0.0, np.inf))
-        _record("allclose", what, float(np.nanmax(r)) * rtol, rtol)
+        _record("allclose", what, float(np.nanmax(r)) * stated, rtol, stated=stated, key=key)
     np.testing.assert_allclose(actual, desired, rtol=rtol, atol=atol, err_msg=err_msg)
 
 

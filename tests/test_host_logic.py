@@ -199,3 +199,39 @@ def test_pickling_flushes_the_host_arrays():
     clone = pickle.loads(pickle.dumps(mdl))
     assert clone._ctx is None and clone._host_stale == set()
     np.testing.assert_allclose(clone.__dict__["_W"], mdl._ctx.W, rtol=1e-6)
+
+
+def test_failed_w_step_leaves_the_previous_factors_like_the_reference():
+    """snmf.py:69-70: np.linalg.inv raises BEFORE W is rebound, so after a LinAlgError at iteration i the object
+    holds iteration i-1's W and H.  Here the failing call leaves garbage in the device W: the host W is
+    refreshed before every W step that may fail, and the device H (still good) is pulled afterwards."""
+    import oracle
+
+    class Ctx(_CountingCtx):
+        calls = 0
+
+        def update_w(self):
+            Ctx.calls += 1
+            if Ctx.calls == 3:
+                self.W[:] = np.nan                      # what a singular H H^T leaves behind on the device
+                raise _lib.PmfError("SNMF: H H^T is singular")
+            oracle.nmf_update_w(self.V, self.W, self.H)
+
+        def update_h(self):
+            oracle.nmf_update_h(self.V, self.W, self.H)
+
+    rs = np.random.RandomState(7)
+    V = rs.rand(30, 10).astype(np.float32)
+    mdl = pymf_amd.SNMF(V, num_bases=3)
+    mdl._ctx = Ctx(30, 10, 3)
+    W0, H0 = rs.rand(30, 3), rs.rand(3, 10)
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    with pytest.raises(_lib.PmfError):
+        mdl.factorize(niter=5, show_progress=True, compute_err=False)     # hook loop; the third W step fails
+    Wr, Hr = W0.copy(), H0.copy()
+    for _ in range(2):
+        oracle.nmf_update_w(V.astype(np.float64), Wr, Hr)
+        oracle.nmf_update_h(V.astype(np.float64), Wr, Hr)
+    np.testing.assert_allclose(mdl.W, Wr, rtol=1e-6)
+    np.testing.assert_allclose(mdl.H, Hr, rtol=1e-6)
+    assert np.isfinite(mdl.W).all()
