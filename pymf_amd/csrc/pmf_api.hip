@@ -29,6 +29,7 @@
 #include "pmf_fused.h"
 #include "pmf_coop.h"
 #include "pmf_nnls.h"
+#include "pmf_nnls_quad.h"
 #include "pmf_inv.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
@@ -97,6 +98,8 @@ struct pmf_ctx {
   bool csr_dense = false;       // CSR data with num_bases > 128: a dense image in dV serves the data paths (no CSR kernel at that width)
   int* dSing = nullptr;         // SNMF: raised by the inverse kernels when H H^T has a zero pivot (check_singular)
   double* dQp = nullptr;        // k_nnqp_big (NMFALS, num_bases > 64): per-workgroup inverse images
+  double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
+  int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): 32 < num_bases <= 64 on the four-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
@@ -1158,19 +1161,37 @@ int nnqp_scratch(pmf_ctx* c, double** out) {
   return PMF_OK;
 }
 
+// One half step's problems: F(var, prob) = F[var * f_sk + prob * f_sp], X likewise; HA in dGd.  32 < num_bases <= 64 with a
+// well-conditioned HA (dWarm, k_spd_unique): k_nnqp_quad on B = inv(HA); otherwise (and as the fallback the flag
+// selects on the device, without a host round trip) k_nnqp / k_nnqp_big.
+int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, bool stat) {
+  PMFCHK(nnqp_warm_flag(c));
+  double* qp = nullptr;
+  PMFCHK(nnqp_scratch(c, &qp));
+  // (a few thousand problems do not fill the chip four to a wave: the H half step of a tall matrix stays on k_nnqp)
+  const bool quad = c->opt_nnqp_quad && c->k > 32 && c->k <= 64 && (nprob >= 16384 || c->opt_nnqp_quad == 2);
+  if (quad) {
+    if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
+    double* Hp = c->dBinv + (size_t)c->KP * c->KP;
+    hipLaunchKernelGGL(k_nnqp_patch_dead, dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, Hp);
+    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, c->stream, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (stat) stat_begin(c, SITE_NNQP_W);
+  int rc = PMF_OK;
+  if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm);
+  if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, quad ? 1 : 0);
+  if (stat) stat_end(c, SITE_NNQP_W);
+  if (rc != PMF_OK) return fail(c, rc, "nnqp launch failed");
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
 int als_update_w(pmf_ctx* c) {
   // HA = H H^T (nmfals.py:93), -FA = V H^T (nmfals.py:88), one QP per row (nmfals.py:89-90)
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
-  PMFCHK(nnqp_warm_flag(c));
-  double* qp = nullptr;
-  PMFCHK(nnqp_scratch(c, &qp));
-  stat_begin(c, SITE_NNQP_W);
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, c->dWarm, qp);
-  stat_end(c, SITE_NNQP_W);
-  if (rc != PMF_OK) return fail(c, rc, "nnqp launch (W) failed");
-  HIPCHK(c, hipGetLastError());
-  return PMF_OK;
+  return solve_nnqps(c, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, true);
 }
 
 int als_update_h(pmf_ctx* c) {
@@ -1181,12 +1202,7 @@ int als_update_h(pmf_ctx* c) {
                      c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
   HIPCHK(c, hipGetLastError());
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
-  PMFCHK(nnqp_warm_flag(c));
-  double* qp = nullptr;
-  PMFCHK(nnqp_scratch(c, &qp));
-  int rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, c->dWarm, qp);
-  if (rc != PMF_OK) return fail(c, rc, "nnqp launch (H) failed");
-  HIPCHK(c, hipGetLastError());
+  PMFCHK(solve_nnqps(c, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, false));
   c->g_valid = false; c->num_valid = false;
   c->ps_valid = true;
   c->trace_ready = false;
@@ -1428,6 +1444,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   pmf_ctx* c = new (std::nothrow) pmf_ctx();
   if (!c) return fail(nullptr, PMF_ENOMEM, "host allocation failed");
   c->algo = algo; c->m = m_local; c->n = n; c->k = k; c->device = device; c->rank = rank; c->nranks = nranks;
+  if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
   c->np = (int)round_up(n, 64);
   c->NT = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
@@ -1538,7 +1555,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
@@ -2190,6 +2207,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
     if (c->g_parts > 0) { c->g_valid = false; c->g_parts = 0; }
     choose_stat_site(c, false);
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "nnqp_quad") == 0) {
+    if (value < 0 || value > 2) return fail(c, PMF_EINVAL, "nnqp_quad: 0 (never), 1 (from 16 384 problems per half step on) or 2 (always)");
+    c->opt_nnqp_quad = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "snmf_gram") == 0) {

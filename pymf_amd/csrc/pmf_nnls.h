@@ -91,8 +91,9 @@ template <int KR>   // variable slots per problem: 16, 32 or 64 (k <= KR)
 __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int KP, int k,
                                               const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
                                               float* __restrict__ X, int64_t x_sk, int64_t x_sp,
-                                              int64_t nprob, const int* __restrict__ warm_flag) {
+                                              int64_t nprob, const int* __restrict__ warm_flag, int skip_if_warm) {
   const bool warm = warm_flag != nullptr && *warm_flag != 0;
+  if (skip_if_warm && warm) return;                  // k_nnqp_quad (pmf_nnls_quad.h) has taken the half step
   extern __shared__ __attribute__((aligned(16))) double sH[];   // [KR][KR]
   const int tid = threadIdx.x, t = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,7 +564,7 @@ static inline int64_t nnqp_big_blocks(int k, int64_t nprob) {
 // F(var, prob) = F[var * f_sk + prob * f_sp]; X likewise.  Hd: [KP][KP] float64.
 static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, const float* F, int64_t f_sk,
                               int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm = nullptr,
-                              double* scratch = nullptr) {
+                              double* scratch = nullptr, int skip_if_warm = 0) {
   if (k > 64) {                 // generic kernel; scratch: nnqp_big_blocks(k, nprob) * (64 VPL)^2 doubles
     if (!scratch || k > 1024) return PMF_EINVAL;
     const unsigned blocks = (unsigned)nnqp_big_blocks(k, nprob);
@@ -581,9 +582,9 @@ static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, co
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (blocks < 1) blocks = 1;
   switch (KR) {
-    case 16: hipLaunchKernelGGL((k_nnqp<16>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm); break;
-    case 32: hipLaunchKernelGGL((k_nnqp<32>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm); break;
-    default: hipLaunchKernelGGL((k_nnqp<64>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm); break;
+    case 16: hipLaunchKernelGGL((k_nnqp<16>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, skip_if_warm); break;
+    case 32: hipLaunchKernelGGL((k_nnqp<32>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, skip_if_warm); break;
+    default: hipLaunchKernelGGL((k_nnqp<64>), dim3((unsigned)blocks), dim3(256), smem, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, skip_if_warm); break;
   }
   return PMF_OK;
 }

@@ -1,0 +1,402 @@
+// pmf_nnls_quad.h -- the NMFALS sub-problems (pymf/nmfals.py:70-97) with SIXTEEN LANES PER PROBLEM.
+//
+//     minimise 1/2 x' HA x - f' x   subject to x >= 0      (HA = H H^T or W^T W, 32 < k <= 64 variables)
+//
+// HA is positive definite here, so the minimiser is unique and characterised by its KKT conditions
+// (x >= 0, w = f - HA x <= 0, x w = 0): any exact active-set method ends at the point k_nnqp (pmf_nnls.h) and the
+// float64 oracle end at.  k_nnqp walks there one variable at a time and keeps the explicit inverse of HA[P,P] in
+// the registers of a whole wave (lane = variable), paying two v_readlane per broadcast operand: 16.6 k VALU
+// instructions per problem, two thirds of them broadcasts, the warm start alone 38 rank-one borders.  Here:
+//
+//  * HA is SHARED by all problems of a half step, so B = inv(HA) is formed ONCE (k_inverse_spd_mfma) and a
+//    problem only factorises the smaller of the two complementary blocks -- with P the passive set and
+//    N the rest, |P| + |N| = k:
+//       |P| <= |N|  (primal):      HA[P,P] x_P = f_P,                     w_N = f_N - HA[N,P] x_P
+//       |N| <  |P|  (complement):  x = B (f_P (+) mu),  B[N,N] mu = -(B f_P)_N,   w_N = f_N - mu
+//    (the second is the first written for the dual problem: x_N = 0 fixes mu, and HA x = f_P (+) mu makes the
+//    multipliers of the zero variables come out of the same solve).  Either way the system has at most 32
+//    unknowns, whatever the support of the warm start, and NO border-by-border build-up: a warm start is one
+//    factorisation.
+//  * that system lives in the registers of a ROW of 16 lanes (4 problems per wave): row i of its LDL^T factor
+//    in lane i % 16 (48 doubles per lane), every index a constant of the program text, so the factorisation is
+//    straight-line code whose only cross-lane traffic is ONE v_mov_b64_dpp row_newbcast per broadcast operand
+//    (register to register: no SGPR round trip, no LDS).
+//  * products with HA / B read the shared matrices from LDS (rows padded to 66 doubles and permuted so that a
+//    lane's 4 entries of a row are contiguous); operands that are problem-specific come from a small per-problem
+//    LDS vector.
+//  * the passive set moves by BLOCK principal pivoting (Kim & Park's rule with Murty's single-variable exchange as
+//    the safeguard): one solve on the current P gives s_P and w_N; every passive variable with s < 0 leaves and
+//    every zero variable with w > tol enters AT ONCE -- from the warm start of an ALS iteration that is two or
+//    three solves per problem instead of one per entering / leaving variable.
+// Every pass of the wave's loop is ONE solve for each of its 4 problems followed by the exchange; a problem that
+// has finished idles until the wave's 4 are done.
+//
+// Preconditions (the host checks them, k_nnqp serves the rest): 32 < k <= 64, and *warm_flag != 0, i.e.
+// k_spd_unique found HA positive definite and well conditioned -- then B exists and every principal block of
+// HA and of B is positive definite too.
+#pragma once
+#include <type_traits>
+#include "pmf_dev.h"
+#include "pmf_nnls.h"
+
+constexpr int QLD = 66;            // LDS row stride of the shared matrices in doubles (528 B: rows start on different banks)
+constexpr int QNS = 32;            // largest system a problem factorises
+constexpr int QPW = 4;             // problems per wave
+constexpr size_t nnqp_quad_smem_bytes() {
+  return (size_t)2 * 64 * QLD * sizeof(double)                    // HA, B
+         + (size_t)4 * QPW * (64 + QNS) * sizeof(double)          // per wave and problem: a 64-vector and a 32-vector
+         + (size_t)4 * QPW * 128;                                 // ... and the P and N lists (bytes)
+}
+
+template <int R>
+__device__ __forceinline__ double row_bcast(double v) {          // lane R of this 16-lane row, in all 16 lanes
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + R, 0xF, 0xF, false);
+}
+// reductions over the 16 lanes of a row, result in all of them (DPP butterfly: quad_perm, row_half_mirror, row_mirror)
+__device__ __forceinline__ double row_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);
+  v += dpp_mov_f64<0x4E>(v);
+  v += dpp_mov_f64<0x141>(v);
+  v += dpp_mov_f64<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double row_min(double v) {
+  v = fmin(v, dpp_mov_f64<0xB1>(v));
+  v = fmin(v, dpp_mov_f64<0x4E>(v));
+  v = fmin(v, dpp_mov_f64<0x141>(v));
+  return fmin(v, dpp_mov_f64<0x140>(v));
+}
+__device__ __forceinline__ double row_max(double v) {
+  v = fmax(v, dpp_mov_f64<0xB1>(v));
+  v = fmax(v, dpp_mov_f64<0x4E>(v));
+  v = fmax(v, dpp_mov_f64<0x141>(v));
+  return fmax(v, dpp_mov_f64<0x140>(v));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int row_or(int v) {
+  v |= dpp_mov_i32<0xB1>(v);
+  v |= dpp_mov_i32<0x4E>(v);
+  v |= dpp_mov_i32<0x141>(v);
+  v |= dpp_mov_i32<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ int row_min_i(int v) {
+  v = min(v, dpp_mov_i32<0xB1>(v));
+  v = min(v, dpp_mov_i32<0x4E>(v));
+  v = min(v, dpp_mov_i32<0x141>(v));
+  return min(v, dpp_mov_i32<0x140>(v));
+}
+
+// row block m of a lane (rows 16 m + r, r = lane % 16) holds columns 0 .. 16 m + 15: 16 + 32 = 48 doubles
+__host__ __device__ constexpr int qoff(int m) { return 16 * m; }
+
+// for (I = A; I < B; ++I) f(integral_constant<I>) -- the factor's indices must be constants of the program
+// text (the array lives in registers), and #pragma unroll gives up on the nested triangular loops
+template <int A, int B, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {
+  if constexpr (A < B) {
+    fn(std::integral_constant<int, A>{});
+    static_for<A + 1, B>(fn);
+  }
+}
+
+// Hp = HA with every DEAD variable (zero row and column: a basis that has died out) replaced by the identity, so
+// that B = inv(Hp) exists; such variables never become passive (k_nnqp rejects them when it borders).
+__global__ __launch_bounds__(256) void k_nnqp_patch_dead(const double* __restrict__ Hd, int KP, int k, double* __restrict__ Hp) {
+  __shared__ double dmax_s;
+  if (threadIdx.x == 0) {
+    double dm = 0.0;
+    for (int t = 0; t < k; ++t) dm = fmax(dm, Hd[(int64_t)t * KP + t]);
+    dmax_s = dm;
+  }
+  __syncthreads();
+  const double dead_below = 1e-12 * dmax_s;
+  for (int e = threadIdx.x; e < KP * KP; e += 256) {
+    const int c = e / KP, t = e % KP;
+    const bool dc = c >= k || !(Hd[(int64_t)c * KP + c] > dead_below), dt = t >= k || !(Hd[(int64_t)t * KP + t] > dead_below);
+    Hp[e] = (dc || dt) ? (c == t ? 1.0 : 0.0) : Hd[e];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__ Horig, const double* __restrict__ Hd,
+                                                      const double* __restrict__ Bd,
+                                                      int KP, int k, const float* __restrict__ F, int64_t f_sk,
+                                                      int64_t f_sp, float* __restrict__ X, int64_t x_sk, int64_t x_sp,
+                                                      int64_t nprob, const int* __restrict__ warm_flag) {
+  if (*warm_flag == 0) return;                       // HA not safely positive definite: k_nnqp takes the half step
+  extern __shared__ __attribute__((aligned(16))) double qsm[];
+  double* sM = qsm;                                  // [2][64][QLD]: 0 = HA, 1 = B; entry (c, t) at c * QLD + (t % 16) * 4 + t / 16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  double* vecV = qsm + 2 * 64 * QLD + (size_t)(wv * QPW + q) * (64 + QNS);   // this problem's 64-vector
+  double* vecC = vecV + 64;                                                   // ... and 32-vector
+  unsigned char* lst = reinterpret_cast<unsigned char*>(qsm + 2 * 64 * QLD + 4 * QPW * (64 + QNS)) +
+                       (size_t)(wv * QPW + q) * 128;                          // [2][64]: P list, N list
+  for (int e = tid; e < 2 * 64 * 64; e += 256) {
+    const int which = e >> 12, c = (e >> 6) & 63, t = e & 63;
+    const double* src = which ? Bd : Hd;
+    const double v = (c < k && t < k) ? src[(int64_t)c * KP + t] : (c == t ? 1.0 : 0.0);
+    sM[which * (64 * QLD) + c * QLD + (t & 15) * 4 + (t >> 4)] = v;
+  }
+  __syncthreads();
+  double hmax = 0.0;
+  for (int t = 0; t < k; ++t) hmax = fmax(hmax, Horig[(int64_t)t * KP + t]);
+  const double tol = 2.220446049250313e-15 * (double)k * hmax;       // as k_nnqp and the oracle
+  unsigned long long kmask = 0ull;                   // the live variables: real (< k) and not dead
+  for (int t = 0; t < k; ++t)
+    if (Horig[(int64_t)t * KP + t] > 1e-12 * hmax) kmask |= 1ull << t;
+  const unsigned long long live = kmask;
+  const int klive = __popcll(kmask);
+
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * QPW; base < nprob; base += nwaves * QPW) {
+    const int64_t prob = base + q;
+    const bool valid = prob < nprob;
+    // ---- this problem's right-hand side and warm start: variable 16 s + r in slot s of lane r ----
+    double f[4], x[4];
+    unsigned long long pm = 0ull;
+    {
+      int lo = 0, hi = 0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int v = 16 * s + r;
+        const bool act = valid && v < k;
+        f[s] = act ? (double)F[(int64_t)v * f_sk + prob * f_sp] : 0.0;
+        const float x0 = act ? X[(int64_t)v * x_sk + prob * x_sp] : 0.f;
+        x[s] = x0 > 0.f ? (double)x0 : 0.0;
+        if (x0 > 0.f) { if (v < 32) lo |= 1 << v; else hi |= 1 << (v - 32); }
+      }
+      lo = row_or(lo); hi = row_or(hi);
+      pm = (((unsigned long long)(unsigned)hi << 32) | (unsigned)lo) & kmask;
+    }
+    bool done = !valid;
+    int npass = 0, ninf_best = k + 1, backup = 3;
+
+    for (int pass = 0; pass < 8 * 64 + 16; ++pass) {
+      if (__ballot(!done) == 0ull) break;
+      // ---- lists of P and N (ascending), the form of the solve ----
+      // The system's unknowns sit at positions shift .. 31 of a 32-slot frame (shift = 32 - ns, identity in front):
+      // the factorisation can then START at the first position any of the wave's problems uses.
+      const int np_ = __popcll(pm), nn = klive - np_;
+      const bool comp = nn < np_;                    // complement form: factorise B[N,N]
+      const int ns = comp ? nn : np_;                // <= k / 2 <= 32
+      const int shift = QNS - ns;
+      int nsmax = ns, ntmax = comp ? np_ : 0;
+#pragma unroll
+      for (int o = 32; o >= 16; o >>= 1) {
+        nsmax = max(nsmax, __shfl_xor(nsmax, o, 64));
+        ntmax = max(ntmax, __shfl_xor(ntmax, o, 64));
+      }
+      const int jstart = __builtin_amdgcn_readfirstlane(QNS - nsmax);
+      ntmax = __builtin_amdgcn_readfirstlane(ntmax);
+      {
+        const int offP = comp ? 0 : shift, offN = comp ? shift : 0;   // the S list right-aligned at byte 32, the other at 0
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int v = 16 * s + r;
+          const unsigned long long below = (1ull << v) - 1ull;
+          if ((kmask >> v) & 1ull) {
+            if ((pm >> v) & 1ull) lst[offP + __popcll(pm & below)] = (unsigned char)v;
+            else lst[64 + offN + __popcll(~pm & kmask & below)] = (unsigned char)v;
+          }
+        }
+      }
+      // f into the problem's LDS vector (the complement form reads f on P from it, the primal form its right-hand side)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) vecV[16 * s + r] = f[s];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned char* lS = lst + (comp ? 64 : 0);      // entry of position p at lS[p], p >= shift
+      const unsigned char* lT = lst + (comp ? 0 : 64);      // entry i at lT[i]
+      const double* Msel = sM + (comp ? 64 * QLD : 0);
+      unsigned pcl[8];                               // permuted column offsets of the S frame, packed bytes
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const unsigned sld = reinterpret_cast<const unsigned*>(lS)[d];
+        pcl[d] = ((sld & 0x0f0f0f0fu) << 2) | ((sld >> 4) & 0x03030303u);     // (t % 16) * 4 + t / 16 per byte
+      }
+
+      // ---- complement form: y = B (f on P), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
+      double y[4] = {0.0, 0.0, 0.0, 0.0};
+      {
+        const int nt = comp ? np_ : 0;
+        for (int i = 0; i < ntmax; ++i) {
+          const bool live = i < nt;
+          const int c = live ? lT[i] : 0;
+          const double fc = live ? vecV[c] : 0.0;
+          const double* row = sM + 64 * QLD + c * QLD + r * 4;        // B, row c, this lane's 4 entries
+#pragma unroll
+          for (int s = 0; s < 4; ++s) y[s] = fma(row[s], fc, y[s]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (comp) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vecV[16 * s + r] = y[s];
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+      // ---- gather M[S,S] into positions shift .. 31 (identity in front) and the right-hand side ----
+      double Lr[48], dv[2], bv[2];
+      static_for<0, 2>([&](auto mc_) {
+        constexpr int m = decltype(mc_)::value;
+        const int i = 16 * m + r;
+        const bool live_i = i >= shift;
+        const int si = live_i ? lS[i] : 0;
+        const double* rowp = Msel + si * QLD;
+        const double vi = live_i ? vecV[si] : 0.0;
+        bv[m] = comp ? -vi : vi;
+        dv[m] = 1.0;
+        static_for<0, 16 * m + 16>([&](auto cc_) {
+          constexpr int c = decltype(cc_)::value;
+          const int pc = (int)((pcl[c >> 2] >> (8 * (c & 3))) & 0xffu);
+          const double val = rowp[c >= shift ? pc : 0];
+          Lr[qoff(m) + c] = (live_i && c >= shift) ? val : (c == i ? 1.0 : 0.0);
+        });
+      });
+      // ---- LDL^T, right-looking; row i in lane i % 16, every index a constant of the program text ----
+      static_for<0, QNS>([&](auto jc_) {
+        constexpr int j = decltype(jc_)::value;
+        constexpr int mj = j >> 4, rj = j & 15;
+        if (j >= jstart) {                           // (below: identity in every problem of this wave)
+          const double dj = row_bcast<rj>(Lr[qoff(mj) + j]);
+          const double inv = pmf_rcp_f64(dj);
+          if (r == rj) dv[mj] = dj;
+          double lij[2];
+          static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; lij[m] = Lr[qoff(m) + j] * inv; });
+          static_for<j + 1, QNS>([&](auto cc_) {
+            constexpr int c = decltype(cc_)::value;
+            constexpr int mc = c >> 4, rc = c & 15;
+            const double acj = row_bcast<rc>(Lr[qoff(mc) + j]);
+            static_for<mc, 2>([&](auto mm_) {
+              constexpr int m = decltype(mm_)::value;
+              Lr[qoff(m) + c] = fma(-lij[m], acj, Lr[qoff(m) + c]);
+            });
+          });
+          // (rows <= j of block mj: padding, never read again)
+          static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; Lr[qoff(m) + j] = lij[m]; });
+        }
+      });
+      // ---- forward: L z = b ----
+      static_for<0, QNS>([&](auto jc_) {
+        constexpr int j = decltype(jc_)::value;
+        constexpr int mj = j >> 4, rj = j & 15;
+        if (j >= jstart) {
+          const double zj = row_bcast<rj>(bv[mj]);
+          if (rj < 15) bv[mj] = fma(-(r > rj ? Lr[qoff(mj) + j] : 0.0), zj, bv[mj]);
+          static_for<mj + 1, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; bv[m] = fma(-Lr[qoff(m) + j], zj, bv[m]); });
+        }
+      });
+      static_for<0, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; bv[m] = bv[m] * pmf_rcp_f64(dv[m]); });
+      // ---- backward: L^T mu = z ----
+      static_for<0, QNS>([&](auto jr_) {
+        constexpr int j = QNS - 1 - decltype(jr_)::value;
+        constexpr int mj = j >> 4, rj = j & 15;
+        if (j >= jstart) {
+          double part = 0.0;
+          if (rj < 15) part = (r > rj ? Lr[qoff(mj) + j] : 0.0) * bv[mj];
+          static_for<mj + 1, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; part = fma(Lr[qoff(m) + j], bv[m], part); });
+          const double tot = row_sum(part);
+          if (r == rj) bv[mj] -= tot;
+        }
+      });
+      // mu (by position) -> vecC
+#pragma unroll
+      for (int m = 0; m < 2; ++m) vecC[16 * m + r] = bv[m];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+      // ---- z = M[:, S] mu over this lane's 4 variables ----
+      double z[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int p = jstart; p < QNS; ++p) {
+        const bool live = p >= shift;
+        const int c = live ? lS[p] : 0;
+        const double mu = live ? vecC[p] : 0.0;
+        const double* row = Msel + c * QLD + r * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) z[s] = fma(row[s], mu, z[s]);
+      }
+      // ---- candidate solution s and dual w per variable ----
+      //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)
+      //   primal:     P: s = mu(t), w = 0;   N: s = 0, w = f - z
+      double sv[4], w[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int v = 16 * s + r;
+        const bool inP = (pm >> v) & 1ull;
+        const bool real = (kmask >> v) & 1ull;
+        const unsigned long long below = (1ull << v) - 1ull;
+        const unsigned long long smask = comp ? (~pm & kmask) : pm;
+        const bool inS = (smask >> v) & 1ull;
+        const double muv = inS ? vecC[(shift + __popcll(smask & below)) & (QNS - 1)] : 0.0;
+        if (comp) { sv[s] = inP ? y[s] + z[s] : 0.0; w[s] = (real && !inP) ? f[s] - muv : 0.0; }
+        else { sv[s] = inP ? muv : 0.0; w[s] = (real && !inP) ? f[s] - z[s] : 0.0; }
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // ---- block principal pivoting: all infeasible variables change sides at once ----
+      if (!done) {
+        int outlo = 0, outhi = 0, inlo = 0, inhi = 0, ninf_l = 0, top = -1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int v = 16 * s + r;
+          const bool inP = (pm >> v) & 1ull;
+          const bool leave = inP && sv[s] < 0.0;
+          const bool enter = ((live >> v) & 1ull) && !inP && w[s] > tol;
+          if (leave) { if (v < 32) outlo |= 1 << v; else outhi |= 1 << (v - 32); }
+          if (enter) { if (v < 32) inlo |= 1 << v; else inhi |= 1 << (v - 32); }
+          if (leave || enter) { ++ninf_l; top = v; }           // (v ascends with s: the lane's largest)
+          x[s] = inP ? fmax(sv[s], 0.0) : 0.0;
+        }
+        outlo = row_or(outlo); outhi = row_or(outhi); inlo = row_or(inlo); inhi = row_or(inhi);
+        const unsigned long long out_m = ((unsigned long long)(unsigned)outhi << 32) | (unsigned)outlo;
+        const unsigned long long in_m = ((unsigned long long)(unsigned)inhi << 32) | (unsigned)inlo;
+        const int ninf = __popcll(out_m) + __popcll(in_m);
+        ++npass;
+        if (ninf == 0 || npass > 6 * k + 16) {
+          done = true;                               // KKT holds: x = s on P, zero elsewhere
+        } else {
+          bool full = true;
+          if (ninf < ninf_best) { ninf_best = ninf; backup = 3; }
+          else if (backup > 0) --backup;
+          else full = false;
+          if (full) {
+            pm = (pm & ~out_m) | in_m;
+          } else {                                   // Murty: only the infeasible variable with the largest index
+            const int vtop = 63 - __builtin_clzll(out_m | in_m);
+            pm ^= 1ull << vtop;
+          }
+        }
+        (void)ninf_l; (void)top;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (valid) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int v = 16 * s + r;
+        if (v < k) X[(int64_t)v * x_sk + prob * x_sp] = (float)(((pm >> v) & 1ull) ? x[s] : 0.0);
+      }
+    }
+  }
+}
+
+static inline int launch_nnqp_quad(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
+                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm) {
+  static bool attr_done_dev[PMF_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[pmf_current_device()];
+  const size_t smem = nnqp_quad_smem_bytes();
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nnqp_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return PMF_EHIP;
+    attr_done = true;
+  }
+  int64_t blocks = (nprob + 4 * QPW - 1) / (4 * QPW);
+  if (blocks > 512) blocks = 512;                      // two workgroups per CU
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_nnqp_quad, dim3((unsigned)blocks), dim3(256), smem, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm);
+  return PMF_OK;
+}
