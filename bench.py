@@ -440,24 +440,36 @@ def main():
                          "kernel_share_of_timed_region": stats["launches"] * mean_s / dt if dt > 0 else 0.0},
         }
         if algo_name == "NMFALS":
-            # k_nnqp is bound by VALU issue (float64 active-set updates, lane = variable): neither HBM nor MFMA.
-            # Recorded constants (rocprofv3 SQ_INSTS_VALU per W-step launch, profiles/r02_pmc_summary.csv, and the
-            # DFMA count of DESIGN.md 3.4) against the live launch time: float64 flop/s vs the 78.6 TFLOP/s vector
-            # peak, and wave instructions/s vs one per 4 cycles per SIMD.
+            # The QP kernel runs float64 VALU code: neither HBM nor MFMA bounds it.  Against the 78.6 TFLOP/s float64
+            # vector peak: flop of ONE solve per problem (k_nnqp_quad: LDL^T of the smaller of HA[P,P] / inv(HA)[N,N],
+            # order ns ~ 26 of 64 at cfg3, two triangular solves, the two products with the shared matrices) times the
+            # solves per problem, the latter from the recorded VALU instruction count of a W-step launch in this bench's
+            # state (rocprofv3 SQ_INSTS_VALU, profiles/r03_pmc_cfg3_nnqp_quad.txt: 1.18e8 per launch = 450 per problem
+            # = one solve: after the pre-roll the active sets of most rows no longer change).
             qps = float(hi - lo)
-            fma_flop = 2.0 * 2.24e5 * qps * (k / 64.0) ** 3          # ~|P|^3-sized work, measured at k = 64
-            valu_instr = 16.6e3 * qps * (k / 64.0) ** 2
+            quad = "quad" in stats["name"]
+            if quad and k == 64:
+                ns, npas = 26.0, 38.0
+                flop_per_solve = 2.0 * (ns ** 3 / 3.0 + 2.0 * ns * ns + 64.0 * (ns + npas))
+                valu_instr = 1.18e8 * qps / 262144.0
+                solves = valu_instr / (450.0 * qps)
+                fma_flop = flop_per_solve * solves * qps
+                src = "profiles/r03_pmc_cfg3_nnqp_quad.txt (SQ_INSTS_VALU of k_nnqp_quad in this bench's state)"
+            else:                                 # lane-per-variable kernel: DESIGN.md 3.4, profiles/r02_pmc_summary.csv
+                fma_flop = 2.0 * 2.24e5 * qps * (k / 64.0) ** 3
+                valu_instr = 16.6e3 * qps * (k / 64.0) ** 2
+                src = "profiles/r02_pmc_summary.csv (16.6 k VALU instructions per QP at k = 64, k_nnqp)"
             if mean_s > 0:
                 out["roofline"].update(bound="valu_f64", achieved=fma_flop / mean_s / 1e12, peak=78.6, unit="TFLOP/s",
                                        frac=fma_flop / mean_s / 1e12 / 78.6)
                 out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": valu_instr,
                                                  "achieved_Ginstr_per_s": valu_instr / mean_s / 1e9,
-                                                 "peak_Ginstr_per_s": 1024 * 2.4 / 4.0 * 1e0 * 1e0,
+                                                 "peak_Ginstr_per_s": 1024 * 2.4 / 4.0,
                                                  "frac": valu_instr / mean_s / 1e9 / (1024 * 2.4 / 4.0),
-                                                 "source": "SQ_INSTS_VALU per QP recorded in profiles/r02_pmc_summary.csv (16.6 k at k = 64)"}
-            out["roofline"]["note"] = ("float64 flop = 2 x DFMA count of the active-set updates (2.24e5 FMA per 64-variable QP, "
-                                       "DESIGN.md 3.4); the kernel sits at the VALU ISSUE limit (valu_issue.frac), two thirds of the "
-                                       "slots being v_readlane broadcasts of the lane = variable layout")
+                                                 "source": src}
+            out["roofline"]["note"] = ("float64 VALU kernel: `achieved` counts the FMA flop of the solves (recorded instruction counts, "
+                                       "live launch time); at two waves per SIMD the kernel is bound by the dependent chains of its "
+                                       "factorisations and triangular solves, not by issue slots (valu_issue.frac)")
         if args.config == "cfg5":
             out["config"]["nnz_local"] = nnz_local
             out["config"]["gram_space_loop_w_once_per_factorize"] = gram_loop

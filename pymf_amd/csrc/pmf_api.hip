@@ -1395,7 +1395,8 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
     }
   } else if (c->algo == PMF_ALGO_NMFALS) {
     st.site = SITE_NNQP_W;
-    if (c->k <= 64) snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
+    if (c->opt_nnqp_quad && c->k > 32 && c->k <= 64 && (c->m >= 16384 || c->opt_nnqp_quad == 2)) snprintf(buf, sizeof(buf), "k_nnqp_quad(update_w)");
+    else if (c->k <= 64) snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
     else snprintf(buf, sizeof(buf), "k_nnqp_big<%d>(update_w)", nnqp_big_vpl(c->k));
     st.name = buf;
     st.bytes = 4.0 * (3.0 * m * k);               // right-hand sides read, warm start read, solution written
