@@ -221,14 +221,24 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       // ---- complement form: y = B (f on P), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
       double y[4] = {0.0, 0.0, 0.0, 0.0};
       {
+        // four terms at a time: one dword of the list, then the four operands and eight row pieces are requested
+        // TOGETHER (term by term the loop was a chain of dependent LDS round trips: list byte -> operand -> row)
         const int nt = comp ? np_ : 0;
-        for (int i = 0; i < ntmax; ++i) {
-          const bool live = i < nt;
-          const int c = live ? lT[i] : 0;
-          const double fc = live ? vecV[c] : 0.0;
-          const double* row = sM + 64 * QLD + c * QLD + r * 4;        // B, row c, this lane's 4 entries
+        for (int i0 = 0; i0 < ntmax; i0 += 4) {
+          const unsigned u = reinterpret_cast<const unsigned*>(lT)[i0 >> 2];
+          double fc[4];
+          const double* row[4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) y[s] = fma(row[s], fc, y[s]);
+          for (int e = 0; e < 4; ++e) {
+            const bool live = i0 + e < nt;
+            const int c = live ? (int)((u >> (8 * e)) & 0xffu) : 0;
+            fc[e] = live ? vecV[c] : 0.0;
+            row[e] = sM + 64 * QLD + c * QLD + r * 4;                 // B, row c, this lane's 4 entries
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) y[s] = fma(row[e][s], fc[e], y[s]);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -258,12 +268,18 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
         });
       });
       // ---- LDL^T, right-looking; row i in lane i % 16, every index a constant of the program text ----
+      // The reciprocal of step j + 1's pivot is started as soon as column j + 1 has its step-j update (first in
+      // the loop over c): its latency -- v_rcp_f64 and two Newton steps -- runs under the rest of step j's updates.
+      double dnext = 1.0, invnext = 1.0;
       static_for<0, QNS>([&](auto jc_) {
         constexpr int j = decltype(jc_)::value;
         constexpr int mj = j >> 4, rj = j & 15;
         if (j >= jstart) {                           // (below: identity in every problem of this wave)
-          const double dj = row_bcast<rj>(Lr[qoff(mj) + j]);
-          const double inv = pmf_rcp_f64(dj);
+          double dj = dnext, inv = invnext;
+          if (j == jstart) {
+            dj = row_bcast<rj>(Lr[qoff(mj) + j]);
+            inv = pmf_rcp_f64(dj);
+          }
           if (r == rj) dv[mj] = dj;
           double lij[2];
           static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; lij[m] = Lr[qoff(m) + j] * inv; });
@@ -275,6 +291,10 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
               constexpr int m = decltype(mm_)::value;
               Lr[qoff(m) + c] = fma(-lij[m], acj, Lr[qoff(m) + c]);
             });
+            if (c == j + 1) {                        // the next pivot is final now
+              dnext = row_bcast<rc>(Lr[qoff(mc) + c]);
+              invnext = pmf_rcp_f64(dnext);
+            }
           });
           // (rows <= j of block mj: padding, never read again)
           static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; Lr[qoff(m) + j] = lij[m]; });
@@ -311,13 +331,21 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
 
       // ---- z = M[:, S] mu over this lane's 4 variables ----
       double z[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int p = jstart; p < QNS; ++p) {
-        const bool live = p >= shift;
-        const int c = live ? lS[p] : 0;
-        const double mu = live ? vecC[p] : 0.0;
-        const double* row = Msel + c * QLD + r * 4;
+      for (int p0 = jstart & ~3; p0 < QNS; p0 += 4) {     // four positions at a time, as above
+        const unsigned u = reinterpret_cast<const unsigned*>(lS)[p0 >> 2];
+        double mu[4];
+        const double* row[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) z[s] = fma(row[s], mu, z[s]);
+        for (int e = 0; e < 4; ++e) {
+          const bool live = p0 + e >= shift;
+          const int c = live ? (int)((u >> (8 * e)) & 0xffu) : 0;
+          mu[e] = live ? vecC[p0 + e] : 0.0;
+          row[e] = Msel + c * QLD + r * 4;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) z[s] = fma(row[e][s], mu[e], z[s]);
       }
       // ---- candidate solution s and dual w per variable ----
       //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)
