@@ -265,6 +265,8 @@ def main():
         ctx.set_h(H0)
         if want_class and "V" in host:
             host["W"], host["H"] = W0, H0
+        if algo_name == "NMFALS":
+            host["W0"], host["H0"] = W0, H0      # for the from-the-random-start rate (below)
         del W0, H0
 
     # ---- disclosed pre-conditioning (untimed, reported as "preroll_ms" / "preroll_iters") ----
@@ -314,6 +316,23 @@ def main():
         dt_e = time.perf_counter() - t1
         dist.barrier()
         rate_err = done_e / dist.allreduce_max(dt_e)
+
+    # NMFALS: `value` is the rate once the pre-roll has run (the active sets of most rows have settled: one solve per
+    # row QP).  Beside it: the first iterations from the random start, where every row QP still changes its set.
+    rate_from_start = None
+    if algo_name == "NMFALS" and "W0" in host:
+        ctx.set_w(host.pop("W0"))
+        ctx.set_h(host.pop("H0"))
+        ns0 = max(2, min(args.steps, 10))
+        ctx.synchronize()
+        dist.barrier()
+        t4 = time.perf_counter()
+        _, done_s, _ = ctx.factorize(ns0, compute_err=False)
+        ctx.synchronize()
+        d4 = time.perf_counter() - t4
+        dist.barrier()
+        rate_from_start = {"iters_per_sec": done_s / dist.allreduce_max(d4), "steps": ns0,
+                           "note": "iterations 1 .. %d from the BASELINE random W0 / H0, no pre-roll" % ns0}
 
     # cfg5: `value` is the loop that writes W = V M in EVERY iteration (what the reference's update_w does,
     # snmf.py:67-70).  Beside it: the Gram-space loop that materialises W once per factorize() -- as an
@@ -419,7 +438,8 @@ def main():
                        "m": m, "n": n, "k": k, "algo": algo_name, "path": ctx.path_name,
                        "collective": collective,
                        "compute_err_true_iters_per_sec": rate_err,
-                       "class_factorize": class_rate},
+                       "class_factorize": class_rate,
+                       "from_random_start": rate_from_start},
             "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                          "traffic": traffic,
                          "traffic_source": ("profiles/traffic.json: rocprofv3 PMC passes of this kernel on this shape "

@@ -175,7 +175,7 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *                over V per iteration: -1 automatic (default: CSR data always, dense data from about
  *                n / 2k iterations on), 0 never, 1 whenever the shape allows (n <= 1024), 2 as 1 but W = V M is
  *                written in EVERY iteration (what the reference's update_w does; same results).
- *   "nnqp_quad"  NMFALS / NMFNNLS with 32 < num_bases <= 64 and a well-conditioned Hessian: the half step's QPs on the
+ *   "nnqp_quad"  NMFALS / NMFNNLS with num_bases <= 64 and a well-conditioned Hessian: the half step's QPs on the
  *                sixteen-lanes-per-problem kernel (block principal pivoting on the smaller of HA[P,P] / inv(HA)[N,N]):
  *                1 (default) from 16 384 problems per half step on, 2 always, 0 never (the lane-per-variable kernel).
  *                Same minimisers (they are unique).

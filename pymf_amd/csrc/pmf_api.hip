@@ -99,7 +99,7 @@ struct pmf_ctx {
   int* dSing = nullptr;         // SNMF: raised by the inverse kernels when H H^T has a zero pivot (check_singular)
   double* dQp = nullptr;        // k_nnqp_big (NMFALS, num_bases > 64): per-workgroup inverse images
   double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
-  int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): 32 < num_bases <= 64 on the four-lanes-per-problem kernel
+  int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): num_bases <= 64 on the sixteen-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
   int fused_wgs = 0;            // >0: fused one-pass kernel available for this shape
@@ -1169,7 +1169,7 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
   double* qp = nullptr;
   PMFCHK(nnqp_scratch(c, &qp));
   // (a few thousand problems do not fill the chip four to a wave: the H half step of a tall matrix stays on k_nnqp)
-  const bool quad = c->opt_nnqp_quad && c->k > 32 && c->k <= 64 && (nprob >= 16384 || c->opt_nnqp_quad == 2);
+  const bool quad = c->opt_nnqp_quad && c->k <= 64 && (nprob >= 16384 || c->opt_nnqp_quad == 2);
   if (quad) {
     if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
     double* Hp = c->dBinv + (size_t)c->KP * c->KP;
@@ -1395,7 +1395,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
     }
   } else if (c->algo == PMF_ALGO_NMFALS) {
     st.site = SITE_NNQP_W;
-    if (c->opt_nnqp_quad && c->k > 32 && c->k <= 64 && (c->m >= 16384 || c->opt_nnqp_quad == 2)) snprintf(buf, sizeof(buf), "k_nnqp_quad(update_w)");
+    if (c->opt_nnqp_quad && c->k <= 64 && (c->m >= 16384 || c->opt_nnqp_quad == 2)) snprintf(buf, sizeof(buf), "k_nnqp_quad(update_w)");
     else if (c->k <= 64) snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
     else snprintf(buf, sizeof(buf), "k_nnqp_big<%d>(update_w)", nnqp_big_vpl(c->k));
     st.name = buf;

@@ -1,6 +1,6 @@
 // pmf_nnls_quad.h -- the NMFALS sub-problems (pymf/nmfals.py:70-97) with SIXTEEN LANES PER PROBLEM.
 //
-//     minimise 1/2 x' HA x - f' x   subject to x >= 0      (HA = H H^T or W^T W, 32 < k <= 64 variables)
+//     minimise 1/2 x' HA x - f' x   subject to x >= 0      (HA = H H^T or W^T W, k <= 64 variables)
 //
 // HA is positive definite here, so the minimiser is unique and characterised by its KKT conditions
 // (x >= 0, w = f - HA x <= 0, x w = 0): any exact active-set method ends at the point k_nnqp (pmf_nnls.h) and the
@@ -31,7 +31,7 @@
 // Every pass of the wave's loop is ONE solve for each of its 4 problems followed by the exchange; a problem that
 // has finished idles until the wave's 4 are done.
 //
-// Preconditions (the host checks them, k_nnqp serves the rest): 32 < k <= 64, and *warm_flag != 0, i.e.
+// Preconditions (the host checks them, k_nnqp serves the rest): k <= 64, and *warm_flag != 0, i.e.
 // k_spd_unique found HA positive definite and well conditioned -- then B exists and every principal block of
 // HA and of B is positive definite too.
 #pragma once
