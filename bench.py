@@ -376,6 +376,9 @@ def main():
         mdl = cls(host["V"], num_bases=k)
         mdl.W, mdl.H = host.pop("W"), host.pop("H")
         class_rate = {"steps": kc}
+        if algo_name == "SNMF":
+            class_rate["note"] = ("the class runs the library's default SNMF loop: Gram-space iterations, W = V M written ONCE per "
+                                  "factorize() -- compare with config.gram_space_loop_w_once_per_factorize, not with `value`")
         try:
             mdl.factorize(niter=2, compute_err=False)
             for key, chk in (("iters_per_sec", True), ("iters_per_sec_check_data_off", False)):

@@ -197,6 +197,13 @@ int pmf_set_host_allreduce(pmf_ctx* ctx, pmf_host_allreduce_fn fn, void* user);
  * rebound or edited between calls. */
 int pmf_invalidate_v(pmf_ctx* ctx);
 
+/* A W step that can fail -- SNMF: np.linalg.inv raises on a singular H H^T BEFORE W is rebound (snmf.py:69-70) --
+ * must leave the previous W behind.  The host class keeps W on the device between calls, so before such a step it
+ * asks for a device-side copy (pmf_snapshot_w: one device-to-device copy, W materialised first if it was implicit) and
+ * puts it back when the step raised (pmf_restore_w).  No host traffic either way. */
+int pmf_snapshot_w(pmf_ctx* ctx);
+int pmf_restore_w(pmf_ctx* ctx);
+
 /* The flops one launch of that kernel really executes (pmf_kernel_stats reports SURVEY's algorithmic
  * count): W^T W is symmetric (upper triangle only) and SNMF's W step is reassociated. */
 int pmf_kernel_exec_flops(pmf_ctx* ctx, double* executed_flops_per_launch);

@@ -65,6 +65,8 @@ SYMBOLS = [
     ("pmf_set_option", _c.c_int, [_ctx, _c.c_char_p, _c.c_int64]),
     ("pmf_set_host_allreduce", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p]),
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
+    ("pmf_snapshot_w", _c.c_int, [_ctx]),
+    ("pmf_restore_w", _c.c_int, [_ctx]),
     ("pmf_kernel_exec_flops", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
@@ -322,6 +324,13 @@ class Context(object):
 
     def invalidate_v(self):
         self._chk(self._lib.pmf_invalidate_v(self._h))
+
+    def snapshot_w(self):
+        """Device-side copy of W before a step that may fail (pmf_snapshot_w)."""
+        self._chk(self._lib.pmf_snapshot_w(self._h))
+
+    def restore_w(self):
+        self._chk(self._lib.pmf_restore_w(self._h))
 
     def kernel_launch_ms(self, cap=65536):
         """Durations (ms) of the dominant kernel's launches since profile_enable(), in launch order."""

@@ -99,6 +99,8 @@ struct pmf_ctx {
   int* dSing = nullptr;         // SNMF: raised by the inverse kernels when H H^T has a zero pivot (check_singular)
   double* dQp = nullptr;        // k_nnqp_big (NMFALS, num_bases > 64): per-workgroup inverse images
   double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
+  float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
+  bool wsnap_valid = false;
   int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): num_bases <= 64 on the sixteen-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
@@ -1556,7 +1558,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dWsnap})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
@@ -2236,6 +2238,27 @@ int pmf_invalidate_v(pmf_ctx* c) {
   if (!c) return PMF_EINVAL;
   c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
   c->c_valid = false;
+  return PMF_OK;
+}
+
+int pmf_snapshot_w(pmf_ctx* c) {
+  PMFCHK(need(c, false, true, false));
+  PMFCHK(materialize_w(c));
+  if (!c->dWsnap) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dWsnap), (size_t)c->mp * c->KP * sizeof(float)));
+  HIPCHK(c, hipMemcpyAsync(c->dWsnap, c->dW, (size_t)c->mp * c->KP * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->wsnap_valid = true;
+  return PMF_OK;
+}
+
+int pmf_restore_w(pmf_ctx* c) {
+  if (!c) return PMF_EINVAL;
+  if (!c->wsnap_valid) return fail(c, PMF_EINVAL, "pmf_restore_w: no snapshot (pmf_snapshot_w)");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->dW, c->dWsnap, (size_t)c->mp * c->KP * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->w_implicit = false;
+  c->ps_valid = false; c->trace_ready = false; c->num_valid = false;
+  if (c->dSing) HIPCHK(c, hipMemsetAsync(c->dSing, 0, sizeof(int), c->stream));
   return PMF_OK;
 }
 

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
                                                       int64_t nprob, const int* __restrict__ warm_flag) {
   if (*warm_flag == 0) return;                       // HA not safely positive definite: k_nnqp takes the half step
   extern __shared__ __attribute__((aligned(16))) double qsm[];
-  double* sM = qsm;                                  // [2][64][QLD]: 0 = HA, 1 = B; entry (c, t) at c * QLD + (t % 16) * 4 + t / 16
+  // [2][64][QLD]: 0 = HA, 1 = B.  Entry (c, t), t = 16 s + r, at c * QLD + (s / 2) * 32 + 2 r + s % 2: lane r's four
+  // entries of a row are two 16-byte pieces, and the 16 lanes of a problem read 256 contiguous bytes per piece --
+  // all 64 banks once (4 entries side by side per lane made lanes r and r + 8 collide on every read)
+  double* sM = qsm;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, r = lane & 15;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
     const int which = e >> 12, c = (e >> 6) & 63, t = e & 63;
     const double* src = which ? Bd : Hd;
     const double v = (c < k && t < k) ? src[(int64_t)c * KP + t] : (c == t ? 1.0 : 0.0);
-    sM[which * (64 * QLD) + c * QLD + (t & 15) * 4 + (t >> 4)] = v;
+    sM[which * (64 * QLD) + c * QLD + ((t >> 5) & 1) * 32 + (t & 15) * 2 + ((t >> 4) & 1)] = v;
   }
   __syncthreads();
   double hmax = 0.0;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
         const unsigned sld = reinterpret_cast<const unsigned*>(lS)[d];
-        pcl[d] = ((sld & 0x0f0f0f0fu) << 2) | ((sld >> 4) & 0x03030303u);     // (t % 16) * 4 + t / 16 per byte
+        pcl[d] = (sld & 0x20202020u) | ((sld & 0x0f0f0f0fu) << 1) | ((sld >> 4) & 0x01010101u);   // the offset above, per byte
       }
 
       // ---- complement form: y = B (f on P), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
@@ -233,12 +236,13 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
             const bool live = i0 + e < nt;
             const int c = live ? (int)((u >> (8 * e)) & 0xffu) : 0;
             fc[e] = live ? vecV[c] : 0.0;
-            row[e] = sM + 64 * QLD + c * QLD + r * 4;                 // B, row c, this lane's 4 entries
+            row[e] = sM + 64 * QLD + c * QLD + r * 2;                 // B, row c, this lane's two 16-byte pieces
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) y[s] = fma(row[e][s], fc[e], y[s]);
+          for (int e = 0; e < 4; ++e) {
+            y[0] = fma(row[e][0], fc[e], y[0]); y[1] = fma(row[e][1], fc[e], y[1]);
+            y[2] = fma(row[e][32], fc[e], y[2]); y[3] = fma(row[e][33], fc[e], y[3]);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -340,12 +344,13 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
           const bool live = p0 + e >= shift;
           const int c = live ? (int)((u >> (8 * e)) & 0xffu) : 0;
           mu[e] = live ? vecC[p0 + e] : 0.0;
-          row[e] = Msel + c * QLD + r * 4;
+          row[e] = Msel + c * QLD + r * 2;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) z[s] = fma(row[e][s], mu[e], z[s]);
+        for (int e = 0; e < 4; ++e) {
+          z[0] = fma(row[e][0], mu[e], z[0]); z[1] = fma(row[e][1], mu[e], z[1]);
+          z[2] = fma(row[e][32], mu[e], z[2]); z[3] = fma(row[e][33], mu[e], z[3]);
+        }
       }
       // ---- candidate solution s and dual w per variable ----
       //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)

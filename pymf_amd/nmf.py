@@ -358,8 +358,8 @@ class NMF(object):
         self._pull(ctx, False, True)
 
     def update_w(self):                                        # nmf.py:128-132
-        self._keep_w_on_host_if_the_step_may_fail()
         ctx = self._sync_to_device()
+        snap = self._snapshot_w_if_the_step_may_fail(ctx)
         rows = self._stream_rows()
         try:
             if rows:
@@ -367,22 +367,28 @@ class NMF(object):
             else:
                 ctx.update_w()
         except Exception:                                      # e.g. SNMF: LinAlgError behind a singular H H^T
-            # the reference raises before it rebinds W (snmf.py:69-70): W is what it was, H is untouched.
-            # Here the device W is gone: the host array (kept current above) goes up again with the next
-            # call; the device H is still good and stays the newer copy if it was.
-            self._w_fp = None
-            self._host_stale.discard("W")
+            self._after_failed_w_step(ctx, snap)
             raise
         self._pull(ctx, True, False)
 
     #: True for classes whose W step can raise (SNMF: np.linalg.inv on a singular H H^T, snmf.py:69)
     _W_STEP_MAY_FAIL = False
 
-    def _keep_w_on_host_if_the_step_may_fail(self):
-        """A failing W step leaves garbage in the device W; the reference would still hold the previous W.
-        Where that can happen the host array is brought up to date first."""
-        if self._W_STEP_MAY_FAIL and "W" in self._host_stale:
-            self._refresh_host("W")
+    def _snapshot_w_if_the_step_may_fail(self, ctx):
+        """The reference raises before it rebinds W (snmf.py:69-70): W is what it was, H is untouched.  A failing
+        step here leaves garbage in the device W, so where that can happen and the device copy is the only
+        current one (the host array was not refreshed since), W is copied device to device first."""
+        if self._W_STEP_MAY_FAIL and "W" in self._host_stale and hasattr(ctx, "snapshot_w"):
+            ctx.snapshot_w()
+            return True
+        return False
+
+    def _after_failed_w_step(self, ctx, snap):
+        if snap:
+            ctx.restore_w()                                    # device W = the previous W again; still the newer copy
+        else:
+            self._w_fp = None                                  # the (current) host array goes up again with the next call
+            self._host_stale.discard("W")
 
     def converged(self, i):                                    # nmf.py:134-139
         derr = np.abs(self.ferr[i] - self.ferr[i - 1]) / self._num_samples
@@ -421,9 +427,8 @@ class NMF(object):
         if self._hooks_overridden() or (show_progress and not rows):
             # the hooks synchronise what THEY need: a subclass that computes on the host never pays for an upload
             return self._factorize_by_hooks(niter, compute_w, compute_h, compute_err)
-        if compute_w:
-            self._keep_w_on_host_if_the_step_may_fail()
         ctx = self._sync_to_device()
+        snap = compute_w and self._snapshot_w_if_the_step_may_fail(ctx)
         if rows:                                               # a Python loop already: logs as it runs
             ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
             self._last_iters = done
@@ -438,11 +443,11 @@ class NMF(object):
                 ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
                                                     conv_eps=self._EPS)
             except Exception:
-                # the device factors are in an unknown state (e.g. behind a singular H H^T): the host arrays
-                # -- W kept current above where the step may fail, H as of the last read -- are what the object
-                # holds, and they go up again with the next call
-                self._w_fp = self._h_fp = None
-                self._host_stale.clear()
+                # the device factors are in an unknown state (e.g. behind a singular H H^T): W goes back to the
+                # snapshot (or to the host array, which then is the current one), H to the host array
+                self._after_failed_w_step(ctx, snap)
+                self._h_fp = None
+                self._host_stale.discard("H")
                 raise
         self._last_iters = done
         self._pull(ctx, compute_w and done > 0, compute_h and done > 0)

@@ -203,12 +203,19 @@ def test_pickling_flushes_the_host_arrays():
 
 def test_failed_w_step_leaves_the_previous_factors_like_the_reference():
     """snmf.py:69-70: np.linalg.inv raises BEFORE W is rebound, so after a LinAlgError at iteration i the object
-    holds iteration i-1's W and H.  Here the failing call leaves garbage in the device W: the host W is
-    refreshed before every W step that may fail, and the device H (still good) is pulled afterwards."""
+    holds iteration i-1's W and H.  Here the failing call leaves garbage in the device W: before every W step
+    that may fail the device W is snapshot (device to device) and put back when the step raised; the factors,
+    still device-resident, reach the host when they are read."""
     import oracle
 
     class Ctx(_CountingCtx):
         calls = 0
+
+        def snapshot_w(self):                           # pmf_snapshot_w: a device-to-device copy
+            self.Wsnap = self.W.copy()
+
+        def restore_w(self):
+            self.W = self.Wsnap.copy()
 
         def update_w(self):
             Ctx.calls += 1

@@ -2,7 +2,7 @@
 # usage: tools/pmc_configs.sh <out tag> [cfg ...]  -- rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in passes of their
 # own, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over bench.py for each BASELINE config; summary by tools/pmc_summary.py
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 cfgs=${@:-cfg4 cfg2 cfg3 cfg5}
 O=$R/gpurun_out/pmc_$tag
 mkdir -p $O

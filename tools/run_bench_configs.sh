@@ -2,7 +2,7 @@
 # usage: tools/run_bench_configs.sh <out tag>   -- every BASELINE config through bench.py, then the same
 # commands under rocprofv3 --kernel-trace --stats (summaries for profiles/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r02}
+tag=${1:-r03}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
