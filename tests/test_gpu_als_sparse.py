@@ -139,3 +139,57 @@ def test_nmf_rejects_sparse(pm):
     mdl = pm.NMF(sp.csr_matrix(np.eye(8, dtype=np.float32)), num_bases=2)
     with pytest.raises(TypeError):
         mdl.factorize(niter=1, compute_err=False)
+
+
+# ---- k_nnqp_quad (pmf_nnls_quad.h): sixteen lanes per problem, block principal pivoting ----------------------------
+@pytest.mark.parametrize("shape,k", [((20000, 300), 50), ((17000, 130), 64), ((18000, 90), 20), ((16500, 64), 7), ((3000, 200), 40)])
+def test_nnqp_quad_gives_the_minimisers_of_the_lane_per_variable_kernel(pm, shape, k):
+    """The QPs are strictly convex: the minimiser is unique whatever path an exact active-set method takes.  Forced on
+    (`nnqp_quad` = 2: every half step, small ones too) against off (k_nnqp), three ALS iterations from the same start;
+    then against the float64 oracle."""
+    import oracle
+    from pymf_amd import _lib
+    m, n = shape
+    rs = np.random.RandomState(m + k)
+    V = rs.random_sample((m, n)).astype(np.float32)
+    V[rs.random_sample((m, n)) < 0.3] = 0.0
+    W0, H0 = rs.random_sample((m, k)).astype(np.float32), rs.random_sample((k, n)).astype(np.float32)
+    out = {}
+    for quad in (2, 0):
+        c = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+        c.set_option("nnqp_quad", quad)
+        c.set_v_dense(V); c.set_w(W0); c.set_h(H0)
+        ferr, done, _ = c.factorize(3, compute_err=True)
+        out[quad] = (c.get_w(), c.get_h(), ferr)
+        c.close()
+    assert rel_fro(out[2][0], out[0][0], what="W: k_nnqp_quad vs k_nnqp") < 2e-5
+    assert rel_fro(out[2][1], out[0][1], what="H: k_nnqp_quad vs k_nnqp") < 2e-5
+    close(out[2][2], out[0][2], rtol=1e-6, what="ferr: k_nnqp_quad vs k_nnqp")
+    assert float(out[2][0].min()) >= 0.0 and float(out[2][1].min()) >= 0.0
+    if m <= 3000:
+        o = oracle.NMFALSOracle(V, num_bases=k)
+        o.W, o.H = W0.astype(np.float64), H0.astype(np.float64)
+        o.factorize(niter=3)
+        assert rel_fro(out[2][0], o.W, what="W: k_nnqp_quad vs the float64 oracle") < 1e-4
+        assert rel_fro(out[2][1], o.H, what="H: k_nnqp_quad vs the float64 oracle") < 1e-4
+
+
+def test_nnqp_quad_leaves_dead_bases_at_zero(pm):
+    """A basis that has died out (zero row of H: zero row and column of HA = H H^T) never becomes passive; the kernel
+    patches it to the identity before inverting HA (k_nnqp_patch_dead) and k_spd_unique still lets the warm start through."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(5)
+    m, n, k = 17000, 120, 48
+    V = rs.random_sample((m, n)).astype(np.float32)
+    W0, H0 = rs.random_sample((m, k)).astype(np.float32), rs.random_sample((k, n)).astype(np.float32)
+    H0[11] = 0.0
+    res = {}
+    for quad in (2, 0):
+        c = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+        c.set_option("nnqp_quad", quad)
+        c.set_v_dense(V); c.set_w(W0); c.set_h(H0)
+        c.update_w()
+        res[quad] = c.get_w()
+        c.close()
+    assert np.all(res[2][:, 11] == 0.0) and np.isfinite(res[2]).all()
+    assert rel_fro(res[2], res[0], what="W with a dead basis: k_nnqp_quad vs k_nnqp") < 2e-5

@@ -1123,3 +1123,26 @@ def test_snmf_singular_gram_raises_linalgerror(pm):
         mdl.H = rs.random_sample((k, n))                        # the object stays usable
         mdl.factorize(niter=2)
         assert np.isfinite(mdl.W).all() and np.isfinite(mdl.ferr).all()
+
+
+def test_snmf_failed_w_step_keeps_the_device_resident_factors(pm):
+    """snmf.py:69-70 raises before W is rebound.  With the factors living on the device between calls (nobody holds the
+    host arrays), a failing W step must not lose the W of the previous, successful call: pmf_snapshot_w / pmf_restore_w."""
+    import oracle
+    rs = np.random.RandomState(8)
+    V = (rs.random_sample((500, 60)) - 0.3).astype(np.float32)
+    mdl = pm.SNMF(V, num_bases=6)
+    W0, H0 = rs.random_sample((500, 6)), rs.random_sample((6, 60))
+    mdl.W, mdl.H = W0.copy(), H0.copy()
+    mdl.factorize(niter=3, compute_err=False)
+    assert mdl._host_stale == {"W", "H"}                        # nothing was pulled: nobody holds the arrays
+    ref = oracle.SNMFOracle(V, num_bases=6)
+    ref.W, ref.H = W0.copy(), H0.copy()
+    ref.factorize(niter=3, compute_err=False)
+    Hbad = np.asarray(ref.H).copy()
+    Hbad[2] = 0.0
+    mdl.H = Hbad                                                # singular H H^T from here on
+    with pytest.raises(np.linalg.LinAlgError):
+        mdl.update_w()
+    assert rel_fro(mdl.W, ref.W, what="W after a failed W step = W of the last successful call") < 5e-6
+    np.testing.assert_array_equal(mdl.H, Hbad)
