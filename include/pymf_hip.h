@@ -179,6 +179,9 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *                sixteen-lanes-per-problem kernel (block principal pivoting on the smaller of HA[P,P] / inv(HA)[N,N]):
  *                1 (default) from 16 384 problems per half step on, 2 always, 0 never (the lane-per-variable kernel).
  *                Same minimisers (they are unique).
+ *   "rowgemm_stream" 1 (default): plain products with a long contraction (V H^T of NMFALS / SNMF, W = V M^T) on
+ *                k_rowgemm_stream (A fragments straight into registers, requests interleaved with the MFMAs);
+ *                0: on k_rowgemm.  Bit-identical results (same order of summation).
  *   "force_tiled" 1: every path of this context takes the any-shape two-pass kernels (k_rowgemm / k_colgemm)
  *                even where a one-pass kernel covers the shape; 0 gives the one-pass kernels back.  For tests
  *                and measurements of the any-shape kernels on the bench shapes. */

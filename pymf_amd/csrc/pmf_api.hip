@@ -101,6 +101,7 @@ struct pmf_ctx {
   double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
   bool wsnap_valid = false;
+  int opt_rowgemm_stream = 1;   // pmf_set_option("rowgemm_stream"): plain products with a long contraction on k_rowgemm_stream
   int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): num_bases <= 64 on the sixteen-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
   int nchunks = 0, rows_per_chunk = 0;
@@ -223,6 +224,15 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
   if (rows_p < 0) { rows_p = c->mp; mvalid = c->m; }
   if (ldc == 0) ldc = 16 * NT;
   const float lamb = (float)c->lamb_w;
+  if (EPI == EPI_STORE && c->opt_rowgemm_stream && kdimA % 128 == 0) {
+    // long contraction, no epilogue: A straight into registers, requests interleaved with the MFMAs (pmf_tiled.h)
+    constexpr int RB = NT <= 4 ? 4 : 2;
+    const int ntiles = (int)(rows_p / (16 * RB));
+    hipLaunchKernelGGL((k_rowgemm_stream<NT, RB>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), (size_t)2 * 16 * NT * 64 * sizeof(float),
+                       c->stream, A, lda, kdimA, B, ldb, C, ldc, ntiles);
+    HIPCHK(c, hipGetLastError());
+    return PMF_OK;
+  }
   const size_t smem = rowgemm_smem_bytes<NT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[pmf_current_device()];
@@ -1447,6 +1457,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   pmf_ctx* c = new (std::nothrow) pmf_ctx();
   if (!c) return fail(nullptr, PMF_ENOMEM, "host allocation failed");
   c->algo = algo; c->m = m_local; c->n = n; c->k = k; c->device = device; c->rank = rank; c->nranks = nranks;
+  if (const char* e = std::getenv("PMF_ROWGEMM_STREAM")) c->opt_rowgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("rowgemm_stream")
   if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
   c->np = (int)round_up(n, 64);
@@ -2215,6 +2226,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (std::strcmp(name, "nnqp_quad") == 0) {
     if (value < 0 || value > 2) return fail(c, PMF_EINVAL, "nnqp_quad: 0 (never), 1 (from 16 384 problems per half step on) or 2 (always)");
     c->opt_nnqp_quad = (int)value;
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "rowgemm_stream") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "rowgemm_stream: 0 or 1");
+    c->opt_rowgemm_stream = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "snmf_gram") == 0) {

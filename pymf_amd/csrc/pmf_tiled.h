@@ -213,6 +213,98 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
   }
 }
 
+// Plain product C[rows][KP] = A[rows][kdim] B[KP][kdim]^T for long contractions (kdim % 64 == 0): NMFALS' and SNMF's
+// V H^T, SNMF's W = V M^T.  The wave keeps 16*RB rows: their A fragments come straight from global memory into two
+// register stages (the lane layout of the 16x16x4 MFMA's A operand IS a 16-byte global read per lane), one 64-column
+// panel ahead; only B travels through LDS (one [KP][64] panel per barrier, double buffered, shared by the 4 waves).
+// The requests are INTERLEAVED with the MFMAs, one b128 request per 4*NT MFMAs: a burst of 20 requests at the top of the
+// panel blocks the wave at issue for about as long as the panel's MFMAs take (in-kernel stamps, tools/rowgemm_lab.hip:
+// 0.37 ms burst vs 0.31 ms interleaved at 262 144 x 1 024, k = 64; requests only 0.26 ms, MFMAs only 0.27-0.30 ms).
+// The B panel for the next barrier is stored at the END of a panel so that its wait sits in straight-line code with an
+// exact count of younger requests (at a loop head the compiler falls back to vmcnt(0), draining the prefetch).
+// Same k order per accumulator as k_rowgemm: the results are bit-identical.  kdim % 128 == 0 (an even number of
+// panels: a tail panel after the loop costs the register allocation of the loop 540 bytes of scratch).
+template <int NT, int RB>
+__global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restrict__ A, int64_t lda, int kdim,
+                                                           const float* __restrict__ B, int64_t ldb,
+                                                           float* __restrict__ C, int64_t ldc, int ntiles) {
+  constexpr int KP = 16 * NT;
+  constexpr int WR = 16 * RB;                          // rows per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int npan = kdim >> 6;
+  const int tile = blockIdx.x * 4 + wv;                // tiles of WR rows
+  const bool act = tile < ntiles;
+  const float* Arow = A + ((int64_t)(act ? tile : 0) * WR + i) * lda + 4 * kq;
+  f32x4 acc[RB][NT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 fa0[RB][4], fa1[RB][4];
+  constexpr int BCH = KP * 16 / 256;                   // 16-byte pieces of a B panel per thread
+  f32x4 pbr[BCH];
+  auto load_b = [&](int p) {                           // unconditional: a guard is a branch the waitcnt pass trips over
+    const int pp = p < npan ? p : npan - 1;
+#pragma unroll
+    for (int q = 0; q < BCH; ++q) {
+      const int id = tid + 256 * q;
+      pbr[q] = *reinterpret_cast<const f32x4*>(B + (int64_t)(id >> 4) * ldb + 64 * pp + 4 * (id & 15));
+    }
+  };
+  auto store_b = [&](float* cb) {
+#pragma unroll
+    for (int q = 0; q < BCH; ++q) {
+      const int id = tid + 256 * q;
+      lds_write4(cb, id >> 4, id & 15, pbr[q]);
+    }
+  };
+  auto panel = [&](int p, f32x4 (&fa)[RB][4], f32x4 (&fan)[RB][4]) {
+    const float* cb = smem + (p & 1) * (KP * 64);
+    const float* An = Arow + 64 * (p + 1 < npan ? p + 1 : p);   // (the last panel re-requests itself: straight-line code)
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 b4[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(cb, 16 * nt + i, 4 * t + kq);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        fan[rb][t] = *reinterpret_cast<const f32x4*>(An + (int64_t)(16 * rb) * lda + 16 * t);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = mfma16(fa[rb][t][e], b4[nt][e], acc[rb][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    store_b(smem + ((p + 1) & 1) * (KP * 64));         // B panel p + 1: its buffer was last read in panel p - 1
+    load_b(p + 2);
+  };
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa0[rb][t] = *reinterpret_cast<const f32x4*>(Arow + (int64_t)(16 * rb) * lda + 16 * t);
+  load_b(0);
+  store_b(smem);
+  load_b(1);
+  for (int p = 0; p < npan; p += 2) {                  // no branch INSIDE the pair: LLVM sinks the prefetch into it
+    panel(p, fa0, fa1);
+    panel(p + 1, fa1, fa0);
+  }
+  if (act) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) C[((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + 16 * nt + i] = acc[rb][nt][j];
+  }
+}
+
 // Partials of P = W^T V and S = W^T W over one chunk of rows.
 // grid = (nchunks, ceil(np/256)); wave w of a block owns columns [256*by + 64*w, +64).
 // slab[chunk][KP][np + KP]: P in columns [0,np), S in [np, np+KP) (written by by == 0).
