@@ -224,14 +224,17 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
   if (rows_p < 0) { rows_p = c->mp; mvalid = c->m; }
   if (ldc == 0) ldc = 16 * NT;
   const float lamb = (float)c->lamb_w;
-  if (EPI == EPI_STORE && c->opt_rowgemm_stream && kdimA % 128 == 0) {
-    // long contraction, no epilogue: A straight into registers, requests interleaved with the MFMAs (pmf_tiled.h)
-    constexpr int RB = NT <= 4 ? 4 : 2;
-    const int ntiles = (int)(rows_p / (16 * RB));
-    hipLaunchKernelGGL((k_rowgemm_stream<NT, RB>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), (size_t)2 * 16 * NT * 64 * sizeof(float),
-                       c->stream, A, lda, kdimA, B, ldb, C, ldc, ntiles);
-    HIPCHK(c, hipGetLastError());
-    return PMF_OK;
+  if constexpr (EPI == EPI_STORE || EPI == EPI_NMF_W || EPI == EPI_BNMF_W || EPI == EPI_RNMF_W) {
+    if (c->opt_rowgemm_stream && kdimA % 128 == 0) {
+      // long contraction: A straight into registers, requests interleaved with the MFMAs (pmf_tiled.h)
+      constexpr int RB = NT <= 4 ? 4 : 2;
+      const int ntiles = (int)(rows_p / (16 * RB));
+      hipLaunchKernelGGL((k_rowgemm_stream<NT, RB, EPI>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256),
+                         (size_t)2 * 16 * NT * 64 * sizeof(float), c->stream, A, lda, kdimA, B, ldb, W, G, C, ldc, lamb, mvalid,
+                         c->k, ntiles);
+      HIPCHK(c, hipGetLastError());
+      return PMF_OK;
+    }
   }
   const size_t smem = rowgemm_smem_bytes<NT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device

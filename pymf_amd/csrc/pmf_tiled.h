@@ -224,10 +224,17 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 // exact count of younger requests (at a loop head the compiler falls back to vmcnt(0), draining the prefetch).
 // Same k order per accumulator as k_rowgemm: the results are bit-identical.  kdim % 128 == 0 (an even number of
 // panels: a tail panel after the loop costs the register allocation of the loop 540 bytes of scratch).
-template <int NT, int RB>
+//
+// EPI_NMF_W / EPI_BNMF_W / EPI_RNMF_W: Den = W_tile G follows on the same registers (the A stages are dead by then; G
+// takes the B buffers' place in LDS, the W fragments come straight from global memory as A did), then the epilogue of
+// k_rowgemm, expression for expression.
+template <int NT, int RB, int EPI>
 __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restrict__ A, int64_t lda, int kdim,
                                                            const float* __restrict__ B, int64_t ldb,
-                                                           float* __restrict__ C, int64_t ldc, int ntiles) {
+                                                           float* __restrict__ W, const float* __restrict__ G,
+                                                           float* __restrict__ C, int64_t ldc, float lamb,
+                                                           int64_t mvalid, int kvalid, int ntiles) {
+  static_assert(EPI == EPI_STORE || EPI == EPI_NMF_W || EPI == EPI_BNMF_W || EPI == EPI_RNMF_W, "k_rowgemm_stream: epilogue");
   constexpr int KP = 16 * NT;
   constexpr int WR = 16 * RB;                          // rows per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -295,14 +302,70 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
     panel(p, fa0, fa1);
     panel(p + 1, fa1, fa0);
   }
-  if (act) {
+  if (EPI == EPI_STORE) {
+    if (act) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) C[((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + 16 * nt + i] = acc[rb][nt][j];
+          for (int j = 0; j < 4; ++j) C[((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + 16 * nt + i] = acc[rb][nt][j];
+    }
+    return;
   }
+  // ---- Den = W_tile G: contraction over the KP bases, G as [ceil(KP / 64)][KP][64] panel images in LDS ----
+  constexpr int GPAN = (KP + 63) / 64;                 // 64-column panels of G
+  constexpr int GCH = KP < 64 ? KP / 4 : 16;           // 16-byte chunks per row of a panel
+  __syncthreads();                                     // every wave is through with the B panels
+  for (int id = tid; id < GPAN * KP * GCH; id += 256) {
+    const int pg = id / (KP * GCH), rem = id % (KP * GCH), row = rem / GCH, ch = rem % GCH;
+    lds_write4(smem + pg * (KP * 64), row, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
+  }
+  const float* Wrow = W + ((int64_t)(act ? tile : 0) * WR + i) * KP + 4 * kq;
+  f32x4 den[RB][NT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) den[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int pg = 0; pg < GPAN; ++pg)
+#pragma unroll
+    for (int t = 0; t < GCH / 4; ++t) {
+      f32x4 b4[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(smem + pg * (KP * 64), 16 * nt + i, 4 * t + kq);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wrow + (int64_t)(16 * rb) * KP + 64 * pg + 16 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) den[rb][nt] = mfma16(a4[e], b4[nt][e], den[rb][nt]);
+      }
+    }
+  if (!act) return;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t row = (int64_t)tile * WR + 16 * rb + 4 * kq + j;
+        float* p = W + row * KP + 16 * nt + i;
+        const float w = *p;
+        const float num = acc[rb][nt][j], dn = den[rb][nt][j];
+        if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
+          const float r = w * ((fabsf(num) - num) / (2.0f * dn));
+          *p = (row < mvalid && (16 * nt + i) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
+        } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
+          const float w1 = num + (3.0f * lamb) * (w * w);
+          const float w2 = ((dn + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
+          *p = w * (w1 / w2);
+        } else {
+          *p = (w * num) / (dn + PMF_EPS_DEN);                // multiply, then divide (nmf.py:131-132)
+        }
+      }
 }
 
 // Partials of P = W^T V and S = W^T W over one chunk of rows.

@@ -63,16 +63,25 @@ def test_two_rank_bench_line_on_one_gpu():
     import socket
     import subprocess
     import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
-           "--rows", "131072", "--fill", "device", "--debug-share-gpu", "--no-cpu-baseline", "--preroll-ms", "20"]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
-                       env=dict(os.environ, OMP_NUM_THREADS="4"))
-    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    errs = []
+    for attempt in range(3):        # the rendezvous port is picked, released and re-bound by the launcher: a rare race
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+               "--rows", "131072", "--fill", "device", "--debug-share-gpu", "--no-cpu-baseline", "--preroll-ms", "20"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                           env=dict(os.environ, OMP_NUM_THREADS="4"))
+        if p.returncode == 0:
+            break
+        errs.append(p.stderr.decode()[-1500:])
+        print("attempt %d of the two-rank launch failed:\n%s" % (attempt, errs[-1]))
+    assert p.returncode == 0, "\n----\n".join(errs)
     lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()
     j = lines[0]

@@ -374,6 +374,43 @@ def test_bitwise_reproducible(pm):
         np.testing.assert_array_equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("algo_name,m,n,k", [
+    ("NMF", 4096, 128, 16), ("NMF", 4160, 256, 30), ("NMF", 8192, 1024, 64), ("NMF", 2048, 384, 128),
+    ("BNMF", 4096, 256, 64), ("RNMF", 4100, 128, 100), ("NMFALS", 4096, 256, 48), ("NMF", 2048, 256, 200),
+])
+def test_rowgemm_stream_and_rowgemm_are_bit_identical(pm, algo_name, m, n, k):
+    """`k_rowgemm_stream` (A straight into registers, requests interleaved with the MFMAs; contractions that are a
+    multiple of 128 wide) forms every accumulator in the same order as `k_rowgemm`: the W step (nmf.py:128-132,
+    bnmf.py:87-90, rnmf.py:109-115; the plain product of nmfals.py:88 and of base blocks beyond 128) must come out
+    bit for bit the same whichever of the two runs, ragged row counts and partly filled base tiles included."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(m + n + k)
+    V = rs.random_sample((m, n)).astype(np.float32)
+    if algo_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    outs = []
+    for stream in (1, 0):
+        c = _lib.Context(getattr(_lib, "ALGO_" + algo_name), m, n, k)
+        c.set_option("force_tiled", 1)
+        c.set_option("rowgemm_stream", stream)
+        if algo_name == "BNMF":
+            c.set_lambda(0.3, 0.2)
+        if algo_name == "RNMF":
+            c.set_lambda(0.7, 0.7)
+        c.set_v_dense(V); c.set_w(W0); c.set_h(H0)
+        if algo_name == "RNMF":
+            c.rnmf_update_s()                          # rnmf.py:96-98: the W step reads S - data
+        for _ in range(2):
+            c.update_w()
+            c.update_h()
+        outs.append((c.get_w(), c.get_h()))
+    assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[0][1]).all()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_fused_vs_tiled_random_shapes(pm):
     """Randomised sweep of (m, n, k) over the fused-kernel shape space, including row counts where
     waves get 0, 1 or uneven numbers of 16-row blocks: fused factorize == tiled hooks."""
