@@ -231,7 +231,7 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
       const int ntiles = (int)(rows_p / (16 * RB));
       hipLaunchKernelGGL((k_rowgemm_stream<NT, RB, EPI>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256),
                          (size_t)2 * 16 * NT * 64 * sizeof(float), c->stream, A, lda, kdimA, B, ldb, W, G, C, ldc, lamb, mvalid,
-                         c->k, ntiles);
+                         c->k, ntiles, (int64_t)(16 * NT));
       HIPCHK(c, hipGetLastError());
       return PMF_OK;
     }
@@ -438,10 +438,10 @@ int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
     const int wdt = (np - c0 >= 128) ? 128 : 64;
     dim3 grid((unsigned)gchunks, (unsigned)((np + 255) / 256));
     if (wdt == 128)
-      hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
+      hipLaunchKernelGGL((k_colgemm<8, false>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
                          (int64_t)np, c->mp, rpc, slab);
     else
-      hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
+      hipLaunchKernelGGL((k_colgemm<4, false>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
                          (int64_t)np, c->mp, rpc, slab);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((wdt * np + 255) / 256)), dim3(256), 0, c->stream, slab,
@@ -608,12 +608,36 @@ int bigk_update_w(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 0.0));
   const bool rn = c->algo == PMF_ALGO_RNMF;      // rnmf.py:109-115: the contraction runs on D = S - data
   if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
-  for (int b = 0; b < c->nb; ++b)
-    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, rn ? c->dD : c->dV, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
-                                         c->dW1 + b * 128, -1, -1, c->KP)));
-  for (int b = 0; b < c->nb; ++b)
+  const float* X = rn ? c->dD : c->dV;
+  for (int b = 0; b < c->nb; ++b)                            // Den = W G^T, every block from the OLD W
     PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dW, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
                                          c->dW2 + b * 128, -1, -1, c->KP)));
+  if (c->opt_rowgemm_stream && c->np % 128 == 0) {
+    // Num = V H_b^T with the update rule as its epilogue: block b of W is rewritten in place (V H^T does not read W)
+    const int ntiles = (int)(c->mp / 32);
+    const dim3 grid((unsigned)((ntiles + 3) / 4));
+    const size_t smem = (size_t)2 * 128 * 64 * sizeof(float);
+    for (int b = 0; b < c->nb; ++b) {
+      const float* Hb = c->dH + (size_t)b * 128 * c->np;
+      float* Wb = c->dW + b * 128;
+      const float* Db = c->dW2 + b * 128;
+      const int kv = std::max(0, std::min(128, c->k - 128 * b));
+      if (rn)
+        hipLaunchKernelGGL((k_rowgemm_stream<8, 2, EPI_RNMF_W, true>), grid, dim3(256), smem, c->stream, X, (int64_t)c->np, c->np, Hb,
+                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, 0.f, c->m, kv, ntiles, (int64_t)c->KP);
+      else if (c->algo == PMF_ALGO_BNMF)
+        hipLaunchKernelGGL((k_rowgemm_stream<8, 2, EPI_BNMF_W, true>), grid, dim3(256), smem, c->stream, X, (int64_t)c->np, c->np, Hb,
+                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, (float)c->lamb_w, c->m, kv, ntiles, (int64_t)c->KP);
+      else
+        hipLaunchKernelGGL((k_rowgemm_stream<8, 2, EPI_NMF_W, true>), grid, dim3(256), smem, c->stream, X, (int64_t)c->np, c->np, Hb,
+                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, 0.f, c->m, kv, ntiles, (int64_t)c->KP);
+      HIPCHK(c, hipGetLastError());
+    }
+    return PMF_OK;
+  }
+  for (int b = 0; b < c->nb; ++b)
+    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, X, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
+                                         c->dW1 + b * 128, -1, -1, c->KP)));
   const int64_t count = c->mp * c->KP;
   hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dW1, c->dW2, count,
                      c->algo == PMF_ALGO_BNMF ? 1 : rn ? 2 : 0, (float)c->lamb_w, c->KP, c->m, c->k);
@@ -628,11 +652,11 @@ int bigk_ps(pmf_ctx* c) {
       const float* X = pass == 0 ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : c->dW;
       const int xn = pass == 0 ? c->np : c->KP;
       dim3 grid((unsigned)c->nchunks, (unsigned)((xn + 255) / 256));
-      hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, c->dW + b * 128, (int64_t)c->KP,
+      hipLaunchKernelGGL((k_colgemm<8, false>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, c->dW + b * 128, (int64_t)c->KP,
                          c->mp, c->rows_per_chunk, c->dSlab);
       HIPCHK(c, hipGetLastError());
-      const int64_t cnt = (int64_t)128 * xn;
-      hipLaunchKernelGGL(k_reduce_slabs_block, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->dSlab,
+      const int64_t cnt4 = (int64_t)128 * xn / 4;
+      hipLaunchKernelGGL(k_reduce_slabs_block, dim3((unsigned)((cnt4 + 63) / 64)), dim3(1024), 0, c->stream, c->dSlab,
                          c->nchunks, 128, xn + 128, xn, c->dPS + (size_t)b * 128 * ldp + (pass == 0 ? 0 : c->np), ldp);
       HIPCHK(c, hipGetLastError());
     }

@@ -227,13 +227,14 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
 //
 // EPI_NMF_W / EPI_BNMF_W / EPI_RNMF_W: Den = W_tile G follows on the same registers (the A stages are dead by then; G
 // takes the B buffers' place in LDS, the W fragments come straight from global memory as A did), then the epilogue of
-// k_rowgemm, expression for expression.
-template <int NT, int RB, int EPI>
+// k_rowgemm, expression for expression.  DENBUF (base blocks beyond 128: W has ldw > KP columns and Den = W G^T was
+// formed for all blocks BEFORE the first block of W changes): Den is read from the buffer G points at, [.][ldw] as W.
+template <int NT, int RB, int EPI, bool DENBUF = false>
 __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restrict__ A, int64_t lda, int kdim,
                                                            const float* __restrict__ B, int64_t ldb,
                                                            float* __restrict__ W, const float* __restrict__ G,
                                                            float* __restrict__ C, int64_t ldc, float lamb,
-                                                           int64_t mvalid, int kvalid, int ntiles) {
+                                                           int64_t mvalid, int kvalid, int ntiles, int64_t ldw) {
   static_assert(EPI == EPI_STORE || EPI == EPI_NMF_W || EPI == EPI_BNMF_W || EPI == EPI_RNMF_W, "k_rowgemm_stream: epilogue");
   constexpr int KP = 16 * NT;
   constexpr int WR = 16 * RB;                          // rows per wave
@@ -313,37 +314,39 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
     }
     return;
   }
-  // ---- Den = W_tile G: contraction over the KP bases, G as [ceil(KP / 64)][KP][64] panel images in LDS ----
-  constexpr int GPAN = (KP + 63) / 64;                 // 64-column panels of G
-  constexpr int GCH = KP < 64 ? KP / 4 : 16;           // 16-byte chunks per row of a panel
-  __syncthreads();                                     // every wave is through with the B panels
-  for (int id = tid; id < GPAN * KP * GCH; id += 256) {
-    const int pg = id / (KP * GCH), rem = id % (KP * GCH), row = rem / GCH, ch = rem % GCH;
-    lds_write4(smem + pg * (KP * 64), row, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
-  }
-  const float* Wrow = W + ((int64_t)(act ? tile : 0) * WR + i) * KP + 4 * kq;
   f32x4 den[RB][NT];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) den[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-#pragma unroll
-  for (int pg = 0; pg < GPAN; ++pg)
-#pragma unroll
-    for (int t = 0; t < GCH / 4; ++t) {
-      f32x4 b4[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(smem + pg * (KP * 64), 16 * nt + i, 4 * t + kq);
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wrow + (int64_t)(16 * rb) * KP + 64 * pg + 16 * t);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) den[rb][nt] = mfma16(a4[e], b4[nt][e], den[rb][nt]);
-      }
+  if (!DENBUF) {
+    // ---- Den = W_tile G: contraction over the KP bases, G as [ceil(KP / 64)][KP][64] panel images in LDS ----
+    constexpr int GPAN = (KP + 63) / 64;                 // 64-column panels of G
+    constexpr int GCH = KP < 64 ? KP / 4 : 16;           // 16-byte chunks per row of a panel
+    __syncthreads();                                     // every wave is through with the B panels
+    for (int id = tid; id < GPAN * KP * GCH; id += 256) {
+      const int pg = id / (KP * GCH), rem = id % (KP * GCH), row = rem / GCH, ch = rem % GCH;
+      lds_write4(smem + pg * (KP * 64), row, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
     }
+    const float* Wrow = W + ((int64_t)(act ? tile : 0) * WR + i) * ldw + 4 * kq;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) den[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int pg = 0; pg < GPAN; ++pg)
+#pragma unroll
+      for (int t = 0; t < GCH / 4; ++t) {
+        f32x4 b4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(smem + pg * (KP * 64), 16 * nt + i, 4 * t + kq);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wrow + (int64_t)(16 * rb) * ldw + 64 * pg + 16 * t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) den[rb][nt] = mfma16(a4[e], b4[nt][e], den[rb][nt]);
+        }
+      }
+  }
   if (!act) return;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -352,9 +355,9 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t row = (int64_t)tile * WR + 16 * rb + 4 * kq + j;
-        float* p = W + row * KP + 16 * nt + i;
+        float* p = W + row * ldw + 16 * nt + i;
         const float w = *p;
-        const float num = acc[rb][nt][j], dn = den[rb][nt][j];
+        const float num = acc[rb][nt][j], dn = DENBUF ? G[row * ldw + 16 * nt + i] : den[rb][nt][j];
         if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
           const float r = w * ((fabsf(num) - num) / (2.0f * dn));
           *p = (row < mvalid && (16 * nt + i) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
@@ -376,7 +379,9 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
 // consecutive columns of V; tile e then holds bases {NT*i + e} resp. columns {4*i + e}, and the
 // permutation is undone in the slab store.  4 + 4 vector loads feed the 4*NT*(4 + ...) MFMAs of a
 // 16-row step (was 16 + 4*NT dword loads).
-template <int NT>
+// WITH_S = false (base blocks beyond 128: S is formed by a pass of its own with W in V's place): no W^T W tiles --
+// at NT = 8 they are a third of the MFMAs and 64 of the accumulator registers.
+template <int NT, bool WITH_S = true>
 __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, int64_t ldv, int np,
                                                  const float* __restrict__ W, int64_t ldw, int64_t mp,
                                                  int rows_per_chunk, float* __restrict__ slab) {
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
   if (r_end > mp) r_end = mp;
   const int c0 = blockIdx.y * 256 + 64 * wv;
   const bool pact = (V != nullptr) && c0 < np;   // V == nullptr: S only (CSR path)
-  const bool sact = blockIdx.y == 0;
+  const bool sact = WITH_S && blockIdx.y == 0;
 
   f32x4 P[NT][4];
   f32x4 S[NT][ST];
@@ -651,15 +656,41 @@ __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int6
 
 // ---- num_bases > 128 (NMF): the bases are handled in blocks of 128 by the NT = 8 kernels above ----
 // out[r * out_ld + c] = sum over slabs of slab[s][r][c]  (r < rows, c < ncols; slab rows have src_ld floats)
-__global__ __launch_bounds__(256) void k_reduce_slabs_block(const float* __restrict__ slab, int nslabs, int rows,
-                                                            int src_ld, int ncols, float* __restrict__ out,
-                                                            int64_t out_ld) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)rows * ncols) return;
-  const int r = (int)(idx / ncols), c = (int)(idx % ncols);
-  double s = 0.0;
-  for (int sl = 0; sl < nslabs; ++sl) s += (double)slab[((int64_t)sl * rows + r) * src_ld + c];
-  out[(int64_t)r * out_ld + c] = (float)s;
+// One block (1024 threads) = 64 float4 of the [rows][ncols] result; wave w sums slabs w, w + 16, ... in float64 (coalesced
+// reads), the 16 partials are combined in wave order (as k_reduce_slabs).  ncols % 4 == 0.
+// (One thread per element walking the 1 024 slabs one dword at a time took 364 us for 201 MB: 0.55 TB/s.)
+__global__ __launch_bounds__(1024) void k_reduce_slabs_block(const float* __restrict__ slab, int nslabs, int rows,
+                                                             int src_ld, int ncols, float* __restrict__ out,
+                                                             int64_t out_ld) {
+  __shared__ double part[16][64][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nc4 = ncols >> 2;
+  const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;
+  const bool ok = e4 < (int64_t)rows * nc4;
+  const int r = ok ? (int)(e4 / nc4) : 0, c = ok ? 4 * (int)(e4 % nc4) : 0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (ok) {
+    const float* p = slab + (int64_t)r * src_ld + c;
+    const int64_t slab_stride = (int64_t)rows * src_ld;
+#pragma unroll 4
+    for (int sl = wv; sl < nslabs; sl += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + sl * slab_stride);
+      s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+    }
+  }
+  part[wv][lane][0] = s0; part[wv][lane][1] = s1; part[wv][lane][2] = s2; part[wv][lane][3] = s3;
+  __syncthreads();
+  if (wv == 0 && ok) {
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double t = part[0][lane][q];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) t += part[w][lane][q];
+      o[q] = (float)t;
+    }
+    *reinterpret_cast<f32x4*>(out + (int64_t)r * out_ld + c) = o;
+  }
 }
 
 // W <- (W * Num) / (Den + 1e-9), elementwise over [rows][ld] (pymf/nmf.py:128-132); the zero padding stays 0

@@ -346,7 +346,7 @@ int main(int argc, char** argv) {
   }
   for (int it = 0; it < 6; ++it) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_rowgemm_stream<NT, 4, EPI_STORE>), dim3((ntiles64 + 3) / 4), dim3(256), smem, 0, A, (int64_t)K, K, B, (int64_t)K, (float*)nullptr, (const float*)nullptr, C2, (int64_t)KP, 0.f, m, KP, ntiles64);
+    hipLaunchKernelGGL((k_rowgemm_stream<NT, 4, EPI_STORE>), dim3((ntiles64 + 3) / 4), dim3(256), smem, 0, A, (int64_t)K, K, B, (int64_t)K, (float*)nullptr, (const float*)nullptr, C2, (int64_t)KP, 0.f, m, KP, ntiles64, (int64_t)KP);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (it >= 3) printf("k_rowgemm_stream<4,4>: %.3f ms  %.1f TFLOP/s\n", ms, flop / ms / 1e9);
@@ -364,6 +364,7 @@ int main(int argc, char** argv) {
   printf("max rel diff (last 64 rows) %.2e\n", md);
   return 0;
 }
-#define INST(NT_, RB_, EPI_) template __global__ void k_rowgemm_stream<NT_, RB_, EPI_>(const float*, int64_t, int, const float*, int64_t, float*, const float*, float*, int64_t, float, int64_t, int, int);
+#define INST(NT_, RB_, EPI_) template __global__ void k_rowgemm_stream<NT_, RB_, EPI_>(const float*, int64_t, int, const float*, int64_t, float*, const float*, float*, int64_t, float, int64_t, int, int, int64_t);
 INST(1, 4, EPI_STORE) INST(2, 4, EPI_STORE) INST(8, 2, EPI_STORE)
 INST(1, 4, EPI_NMF_W) INST(2, 4, EPI_NMF_W) INST(4, 4, EPI_NMF_W) INST(8, 2, EPI_NMF_W) INST(4, 4, EPI_BNMF_W) INST(8, 2, EPI_RNMF_W)
+template __global__ void k_rowgemm_stream<8, 2, EPI_NMF_W, true>(const float*, int64_t, int, const float*, int64_t, float*, const float*, float*, int64_t, float, int64_t, int, int, int64_t);
