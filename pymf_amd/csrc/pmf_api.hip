@@ -1176,15 +1176,34 @@ int snmf_update_h(pmf_ctx* c) {
 }
 
 // ---- NMFALS ---------------------------------------------------------------------------------
-int nnqp_warm_flag(pmf_ctx* c) {   // dWarm[0] = 1 iff the QPs over the current dGd have unique minimisers
+int nnqp_warm_flag(pmf_ctx* c, hipStream_t s) {   // dWarm[0] = 1 iff the QPs over the current dGd have unique minimisers
   if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
   if (c->k <= 64) {
-    hipLaunchKernelGGL(k_spd_unique, dim3(1), dim3(64), 0, c->stream, c->dGd, c->KP, c->k, c->dWarm);
+    hipLaunchKernelGGL(k_spd_unique, dim3(1), dim3(64), 0, s, c->dGd, c->KP, c->k, c->dWarm);
   } else {
     if (!c->dInvA) PMFCHK(dalloc(c, &c->dInvA, (size_t)c->KP * c->KP));
-    hipLaunchKernelGGL(k_spd_unique_big, dim3(1), dim3(1024), 0, c->stream, c->dGd, c->KP, c->k, c->dInvA, c->dWarm);
+    hipLaunchKernelGGL(k_spd_unique_big, dim3(1), dim3(1024), 0, s, c->dGd, c->KP, c->k, c->dInvA, c->dWarm);
   }
   HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+// (a few thousand problems do not fill the chip four to a wave: the H half step of a tall matrix stays on k_nnqp)
+bool nnqp_use_quad(const pmf_ctx* c, int64_t nprob) {
+  return c->opt_nnqp_quad && c->k <= 64 && (nprob >= 16384 || c->opt_nnqp_quad == 2);
+}
+
+// What a half step's QPs need from HA = dGd alone, on stream s: the uniqueness flag and, for k_nnqp_quad,
+// B = inv(HA with its dead variables patched out).  k x k sized kernels, 36 + 2 + 18 us at k = 64.
+int nnqp_prepare(pmf_ctx* c, hipStream_t s, bool quad) {
+  PMFCHK(nnqp_warm_flag(c, s));
+  if (quad) {
+    if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
+    double* Hp = c->dBinv + (size_t)c->KP * c->KP;
+    hipLaunchKernelGGL(k_nnqp_patch_dead, dim3(1), dim3(256), 0, s, c->dGd, c->KP, c->k, Hp);
+    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr);
+    HIPCHK(c, hipGetLastError());
+  }
   return PMF_OK;
 }
 
@@ -1203,19 +1222,12 @@ int nnqp_scratch(pmf_ctx* c, double** out) {
 // One half step's problems: F(var, prob) = F[var * f_sk + prob * f_sp], X likewise; HA in dGd.  32 < num_bases <= 64 with a
 // well-conditioned HA (dWarm, k_spd_unique): k_nnqp_quad on B = inv(HA); otherwise (and as the fallback the flag
 // selects on the device, without a host round trip) k_nnqp / k_nnqp_big.
-int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, bool stat) {
-  PMFCHK(nnqp_warm_flag(c));
+int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, bool stat,
+                bool prepared = false) {
+  const bool quad = nnqp_use_quad(c, nprob);
+  if (!prepared) PMFCHK(nnqp_prepare(c, c->stream, quad));
   double* qp = nullptr;
   PMFCHK(nnqp_scratch(c, &qp));
-  // (a few thousand problems do not fill the chip four to a wave: the H half step of a tall matrix stays on k_nnqp)
-  const bool quad = c->opt_nnqp_quad && c->k <= 64 && (nprob >= 16384 || c->opt_nnqp_quad == 2);
-  if (quad) {
-    if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
-    double* Hp = c->dBinv + (size_t)c->KP * c->KP;
-    hipLaunchKernelGGL(k_nnqp_patch_dead, dim3(1), dim3(256), 0, c->stream, c->dGd, c->KP, c->k, Hp);
-    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, c->stream, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr);
-    HIPCHK(c, hipGetLastError());
-  }
   if (stat) stat_begin(c, SITE_NNQP_W);
   int rc = PMF_OK;
   if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm);
@@ -1229,6 +1241,8 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
 int als_update_w(pmf_ctx* c) {
   // HA = H H^T (nmfals.py:93), -FA = V H^T (nmfals.py:88), one QP per row (nmfals.py:89-90)
   PMFCHK(ensure_gram(c, 1.0));
+  // (The QPs' preparation -- 56 us of single-workgroup k x k kernels that read HA only -- on a second stream beside
+  // V H^T was tried: the iteration got 4 % SLOWER, profiles/r03_experiments.md.)
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
   return solve_nnqps(c, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, true);
 }
@@ -1983,7 +1997,7 @@ int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
     // what the W step of every tile needs from H: G = H H^T (NMF, BNMF); M^T = inv(H H^T) H (SNMF, snmf.py:67-70);
     // the Hessian H H^T in float64 + the warm-start verdict (NMFALS, nmfals.py:85-97)
     if (c->algo == PMF_ALGO_SNMF) PMFCHK(snmf_inverse(c));
-    else if (c->algo == PMF_ALGO_NMFALS) { PMFCHK(ensure_gram(c, 1.0)); PMFCHK(nnqp_warm_flag(c)); }
+    else if (c->algo == PMF_ALGO_NMFALS) { PMFCHK(ensure_gram(c, 1.0)); PMFCHK(nnqp_warm_flag(c, c->stream)); }
     else PMFCHK(ensure_gram(c, 0.0));
   }
   return PMF_OK;
