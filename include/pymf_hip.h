@@ -126,7 +126,7 @@ int pmf_rnmf_update_s(pmf_ctx* ctx);
 int pmf_rnmf_get_s_f32(pmf_ctx* ctx, float* S);
 
 /* Streamed V (the `data[:, :]` idiom of nmf.py:123,129 for data that does not fit
- * in HBM: an h5py dataset, a memmap, a matrix beyond 288 GB).  NMF, BNMF, SNMF and NMFALS contexts (num_bases <= 128); pmf_set_v_* is not
+ * in HBM: an h5py dataset, a memmap, a matrix beyond 288 GB).  NMF, BNMF, SNMF and NMFALS contexts (not RNMF: the reference's RNMF keeps S, an in-memory array of data's shape, rnmf.py:94-98); pmf_set_v_* is not
  * called.  One pass = one iteration of the reference loop (nmf.py:183-202):
  *   pmf_stream_begin(ctx, flags, max_tile_rows)   flags as pmf_factorize (PMF_COMPUTE_W/H/ERR)
  *   pmf_stream_tile(ctx, row0, rows, tile, ld)    row tiles in order; row0 and rows multiples of 64

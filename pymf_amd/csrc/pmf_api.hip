@@ -604,64 +604,79 @@ int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2)
 // W step (nmf.py:128-132): Num = V H^T and Den = W (H H^T) block by block into [mp][KP] buffers, then
 // one elementwise pass.  (P | S) (nmf.py:122-124 operands): per base block W_b^T V, and W_b^T W by the
 // same kernel with W in the place of V.
-int bigk_update_w(pmf_ctx* c) {
-  PMFCHK(ensure_gram(c, 0.0));
-  const bool rn = c->algo == PMF_ALGO_RNMF;      // rnmf.py:109-115: the contraction runs on D = S - data
-  if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
-  const float* X = rn ? c->dD : c->dV;
+// X [rows_p][np] (V, D = S - data, or a streamed tile), Wr / W1r / W2r the same rows of W and of the two [.][KP] temporaries
+int bigk_update_w_rows(pmf_ctx* c, const float* X, float* Wr, float* W1r, float* W2r, int64_t rows_p, int64_t mvalid) {
+  const bool rn = c->algo == PMF_ALGO_RNMF;
   for (int b = 0; b < c->nb; ++b)                            // Den = W G^T, every block from the OLD W
-    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, c->dW, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
-                                         c->dW2 + b * 128, -1, -1, c->KP)));
+    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, Wr, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
+                                         W2r + b * 128, rows_p, mvalid, c->KP)));
   if (c->opt_rowgemm_stream && c->np % 128 == 0) {
     // Num = V H_b^T with the update rule as its epilogue: block b of W is rewritten in place (V H^T does not read W)
-    const int ntiles = (int)(c->mp / 32);
+    const int ntiles = (int)(rows_p / 32);
     const dim3 grid((unsigned)((ntiles + 3) / 4));
     const size_t smem = (size_t)2 * 128 * 64 * sizeof(float);
     for (int b = 0; b < c->nb; ++b) {
       const float* Hb = c->dH + (size_t)b * 128 * c->np;
-      float* Wb = c->dW + b * 128;
-      const float* Db = c->dW2 + b * 128;
+      float* Wb = Wr + b * 128;
+      const float* Db = W2r + b * 128;
       const int kv = std::max(0, std::min(128, c->k - 128 * b));
       if (rn)
         hipLaunchKernelGGL((k_rowgemm_stream<8, 2, EPI_RNMF_W, true>), grid, dim3(256), smem, c->stream, X, (int64_t)c->np, c->np, Hb,
-                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, 0.f, c->m, kv, ntiles, (int64_t)c->KP);
+                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, 0.f, mvalid, kv, ntiles, (int64_t)c->KP);
       else if (c->algo == PMF_ALGO_BNMF)
         hipLaunchKernelGGL((k_rowgemm_stream<8, 2, EPI_BNMF_W, true>), grid, dim3(256), smem, c->stream, X, (int64_t)c->np, c->np, Hb,
-                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, (float)c->lamb_w, c->m, kv, ntiles, (int64_t)c->KP);
+                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, (float)c->lamb_w, mvalid, kv, ntiles, (int64_t)c->KP);
       else
         hipLaunchKernelGGL((k_rowgemm_stream<8, 2, EPI_NMF_W, true>), grid, dim3(256), smem, c->stream, X, (int64_t)c->np, c->np, Hb,
-                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, 0.f, c->m, kv, ntiles, (int64_t)c->KP);
+                           (int64_t)c->np, Wb, Db, (float*)nullptr, (int64_t)0, 0.f, mvalid, kv, ntiles, (int64_t)c->KP);
       HIPCHK(c, hipGetLastError());
     }
     return PMF_OK;
   }
   for (int b = 0; b < c->nb; ++b)
     PMFCHK((launch_rowgemm<8, EPI_STORE>(c, X, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
-                                         c->dW1 + b * 128, -1, -1, c->KP)));
-  const int64_t count = c->mp * c->KP;
-  hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dW1, c->dW2, count,
-                     c->algo == PMF_ALGO_BNMF ? 1 : rn ? 2 : 0, (float)c->lamb_w, c->KP, c->m, c->k);
+                                         W1r + b * 128, rows_p, mvalid, c->KP)));
+  const int64_t count = rows_p * c->KP;
+  hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, Wr, W1r, W2r, count,
+                     c->algo == PMF_ALGO_BNMF ? 1 : rn ? 2 : 0, (float)c->lamb_w, c->KP, mvalid, c->k);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
 
-int bigk_ps(pmf_ctx* c) {
+int bigk_update_w(pmf_ctx* c) {
+  PMFCHK(ensure_gram(c, 0.0));
+  const bool rn = c->algo == PMF_ALGO_RNMF;      // rnmf.py:109-115: the contraction runs on D = S - data
+  if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+  return bigk_update_w_rows(c, rn ? c->dD : c->dV, c->dW, c->dW1, c->dW2, c->mp, c->m);
+}
+
+// acc == nullptr: (P | S) of rows [0, rows_p) of X / Wr into dPS; else added (first: stored) to the float64 image acc
+int bigk_ps_rows(pmf_ctx* c, const float* Xv, const float* Wr, int64_t rows_p, int rpc, int nch, double* acc, int first) {
   const int64_t ldp = (int64_t)c->np + c->KP;
   for (int b = 0; b < c->nb; ++b) {
     for (int pass = 0; pass < 2; ++pass) {                 // 0: W_b^T V -> P rows,  1: W_b^T W -> S rows
-      const float* X = pass == 0 ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : c->dW;
+      const float* X = pass == 0 ? Xv : Wr;
       const int xn = pass == 0 ? c->np : c->KP;
-      dim3 grid((unsigned)c->nchunks, (unsigned)((xn + 255) / 256));
-      hipLaunchKernelGGL((k_colgemm<8, false>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, c->dW + b * 128, (int64_t)c->KP,
-                         c->mp, c->rows_per_chunk, c->dSlab);
+      dim3 grid((unsigned)nch, (unsigned)((xn + 255) / 256));
+      hipLaunchKernelGGL((k_colgemm<8, false>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, Wr + b * 128, (int64_t)c->KP,
+                         rows_p, rpc, c->dSlab);
       HIPCHK(c, hipGetLastError());
       const int64_t cnt4 = (int64_t)128 * xn / 4;
-      hipLaunchKernelGGL(k_reduce_slabs_block, dim3((unsigned)((cnt4 + 63) / 64)), dim3(1024), 0, c->stream, c->dSlab,
-                         c->nchunks, 128, xn + 128, xn, c->dPS + (size_t)b * 128 * ldp + (pass == 0 ? 0 : c->np), ldp);
+      const size_t off = (size_t)b * 128 * ldp + (pass == 0 ? 0 : c->np);
+      if (acc)
+        hipLaunchKernelGGL((k_reduce_slabs_block<double>), dim3((unsigned)((cnt4 + 63) / 64)), dim3(1024), 0, c->stream, c->dSlab,
+                           nch, 128, xn + 128, xn, acc + off, ldp, first ? 0 : 1);
+      else
+        hipLaunchKernelGGL((k_reduce_slabs_block<float>), dim3((unsigned)((cnt4 + 63) / 64)), dim3(1024), 0, c->stream, c->dSlab,
+                           nch, 128, xn + 128, xn, c->dPS + off, ldp, 0);
       HIPCHK(c, hipGetLastError());
     }
   }
   return PMF_OK;
+}
+
+int bigk_ps(pmf_ctx* c) {
+  return bigk_ps_rows(c, c->algo == PMF_ALGO_RNMF ? c->dD : c->dV, c->dW, c->mp, c->rows_per_chunk, c->nchunks, nullptr, 0);
 }
 
 int nmf_fused_pass(pmf_ctx* c);
@@ -1555,7 +1570,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
       PMFCHK(dalloc(c, &c->dSlab, (size_t)nslabs * ps_elems(c)));
     } else {                    // one 128-base block at a time: [chunk][128][max(np, KP) + 128]
       PMFCHK(dalloc(c, &c->dSlab, (size_t)c->nchunks * 128 * (std::max(c->np, c->KP) + 128)));
-      PMFCHK(dalloc(c, &c->dW1, (size_t)c->mp * c->KP));
+      PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dW2, (size_t)c->mp * c->KP));
     }
     PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
@@ -1567,8 +1582,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->ferr_cap = 4096;
     PMFCHK(dalloc(c, &c->dFerr, (size_t)c->ferr_cap));
     if (algo == PMF_ALGO_RNMF) PMFCHK(dalloc(c, &c->dD, (size_t)c->mp * c->np));
-    if (algo != PMF_ALGO_NMF && !c->dW1) {
-      PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
+    if (algo != PMF_ALGO_NMF) {
+      if (!c->dW1) PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dGinvT, (size_t)c->KP * c->KP));
     }
     if (algo == PMF_ALGO_SNMF) {
@@ -1963,8 +1978,8 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
 // stream into two device tiles, so the copy of tile t+1 overlaps the kernels of tile t.
 int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
   if (!c) return PMF_EINVAL;
-  if (c->algo == PMF_ALGO_RNMF || c->nb > 1)
-    return fail(c, PMF_EINVAL, "pmf_stream_*: NMF, BNMF, SNMF and NMFALS contexts with num_bases <= 128");
+  if (c->algo == PMF_ALGO_RNMF)   // (the reference's RNMF keeps S, an in-memory array of data's shape: rnmf.py:94-98)
+    return fail(c, PMF_EINVAL, "pmf_stream_*: NMF, BNMF, SNMF and NMFALS contexts");
   if (!c->have_w || !c->have_h) return fail(c, PMF_EINVAL, "pmf_stream_begin: W and H must be set");
   if (max_tile_rows < 1) return fail(c, PMF_EINVAL, "pmf_stream_begin: max_tile_rows must be >= 1");
   HIPCHK(c, hipSetDevice(c->device));
@@ -2040,7 +2055,9 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       HIPCHK(c, hipGetLastError());
     }
     if (c->st_flags & PMF_COMPUTE_W) {
-      if (c->algo == PMF_ALGO_BNMF) {   // bnmf.py:87-90: the penalised W rule, same contractions
+      if (c->nb > 1 && (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF)) {   // blocks of 128 bases (bigk_update_w)
+        PMFCHK(bigk_update_w_rows(c, T, Wt, c->dW1 + row0 * c->KP, c->dW2 + row0 * c->KP, rows_p, rows));
+      } else if (c->algo == PMF_ALGO_BNMF) {   // bnmf.py:87-90: the penalised W rule, same contractions
         PMFCHK(rowgemm<EPI_BNMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
       } else if (c->algo == PMF_ALGO_SNMF) {   // snmf.py:67-70: the tile's rows of W = V M^T
         PMFCHK(rowgemm<EPI_STORE>(c, T, c->np, c->np, c->dMT, c->np, nullptr, nullptr, Wt, rows_p, rows));
@@ -2063,6 +2080,9 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       const int rpc = (int)((blocks16 + tch - 1) / tch) * 16;
       tch = (int)((rows_p + rpc - 1) / rpc);
       dim3 grid((unsigned)tch, (unsigned)((c->np + 255) / 256));
+      if (c->nb > 1) {
+        PMFCHK(bigk_ps_rows(c, T, Wt, rows_p, rpc, tch, c->dPSacc, first));
+      } else {
       switch (c->NT) {
         case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
         case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
@@ -2074,6 +2094,7 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       hipLaunchKernelGGL(k_reduce_slabs_acc, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dSlab, tch,
                          E, c->dPSacc, first);
       HIPCHK(c, hipGetLastError());
+      }
     }
   }
   HIPCHK(c, hipEventRecord(c->ev_consumed[b], c->stream));

@@ -659,9 +659,11 @@ __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int6
 // One block (1024 threads) = 64 float4 of the [rows][ncols] result; wave w sums slabs w, w + 16, ... in float64 (coalesced
 // reads), the 16 partials are combined in wave order (as k_reduce_slabs).  ncols % 4 == 0.
 // (One thread per element walking the 1 024 slabs one dword at a time took 364 us for 201 MB: 0.55 TB/s.)
+// OutT = double with accumulate != 0: out += the sum (the float64 image of a streamed pass, tile after tile).
+template <typename OutT>
 __global__ __launch_bounds__(1024) void k_reduce_slabs_block(const float* __restrict__ slab, int nslabs, int rows,
-                                                             int src_ld, int ncols, float* __restrict__ out,
-                                                             int64_t out_ld) {
+                                                             int src_ld, int ncols, OutT* __restrict__ out,
+                                                             int64_t out_ld, int accumulate) {
   __shared__ double part[16][64][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nc4 = ncols >> 2;
@@ -681,15 +683,14 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_block(const float* __rest
   part[wv][lane][0] = s0; part[wv][lane][1] = s1; part[wv][lane][2] = s2; part[wv][lane][3] = s3;
   __syncthreads();
   if (wv == 0 && ok) {
-    f32x4 o;
+    OutT* o = out + (int64_t)r * out_ld + c;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       double t = part[0][lane][q];
 #pragma unroll
       for (int w = 1; w < 16; ++w) t += part[w][lane][q];
-      o[q] = (float)t;
+      o[q] = accumulate ? (OutT)((double)o[q] + t) : (OutT)t;
     }
-    *reinterpret_cast<f32x4*>(out + (int64_t)r * out_ld + c) = o;
   }
 }
 

@@ -236,7 +236,7 @@ class NMF(object):
     def _stream_rows(self):
         """Tile height of the streamed mode (rounded to 64 rows), or 0 when `data` is kept resident."""
         r = self.stream_rows or int(os.environ.get("PYMF_STREAM_ROWS", "0") or 0)
-        if not r or self._ALGO == _lib.ALGO_RNMF or self._num_bases > 128 or _is_sparse(self.data):
+        if not r or self._ALGO == _lib.ALGO_RNMF or _is_sparse(self.data):
             return 0
         return max(64, (int(r) + 63) // 64 * 64)
 

@@ -69,6 +69,35 @@ def test_streamed_equals_resident(pm, shape, k, rows, tmp_path):
     assert abs(st.frobenius_norm() - res.frobenius_norm()) <= 2e-6 * res.frobenius_norm()
 
 
+@pytest.mark.parametrize("cls_name,shape,k,rows", [("NMF", (3000, 256), 200, 1024), ("NMF", (2000, 192), 130, 512),
+                                                  ("BNMF", (2048, 128), 140, 640), ("SNMF", (3000, 320), 150, 1024),
+                                                  ("NMFALS", (700, 160), 130, 256)])
+def test_streamed_equals_resident_beyond_128_bases(pm, cls_name, shape, k, rows, tmp_path):
+    """num_bases > 128 (the products in blocks of 128 bases) through the row-tile passes: the same
+    iteration as on resident data (per tile the W rule, W_b^T V and W_b^T W partials accumulated in float64)."""
+    rs = np.random.RandomState(shape[0] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    if cls_name == "BNMF":
+        V = (V < 0.3).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    path = str(tmp_path / "v.f32")
+    V.tofile(path)
+    Vmm = np.memmap(path, dtype=np.float32, mode="r", shape=shape)
+    cls = getattr(pm, cls_name)
+    niter = 3 if cls_name == "NMFALS" else 5
+    res = cls(V, num_bases=k)
+    res.W, res.H = W0.copy(), H0.copy()
+    res.factorize(niter=niter)
+    st = cls(Vmm, num_bases=k)
+    st.stream_rows = rows
+    st.W, st.H = W0.copy(), H0.copy()
+    st.factorize(niter=niter)
+    assert st._ctx.path_name and len(st.ferr) == len(res.ferr)
+    tol = 2e-5 if cls_name in ("SNMF", "NMFALS") else 2e-6
+    close(st.ferr, res.ferr, rtol=tol, what="st.ferr")
+    assert rel_fro(st.W, res.W, what="st.W") < tol and rel_fro(st.H, res.H, what="st.H") < tol
+
+
 def test_streamed_flags_and_hooks(pm):
     from oracle import NMFOracle
     rs = np.random.RandomState(9)
