@@ -142,8 +142,9 @@ int pmf_stream_tile(pmf_ctx* ctx, int64_t row0, int64_t rows, const float* tile,
 int pmf_stream_end(pmf_ctx* ctx, double* ferr, int32_t* needs_direct);
 
 /* NNDSVD initialisation (pymf/nndsvd.py:79-108 = NNDSVD.update_w, with the SVD of pymf/svd.py:125-148):
- * fills the context's W and H from the dense V already set.  Needs n <= 4096 (the Gram matrix
- * data^T data is n x n; a wide matrix is handled by the caller on the transposed problem, as the
+ * fills the context's W and H from the dense V already set.  Needs n <= 16384 (the Gram matrix
+ * data^T data is n x n: all its eigenpairs by a float64 Jacobi iteration up to 1024 columns, the num_bases largest
+ * by a Chebyshev-filtered subspace iteration on the float64 MFMA beyond -- option "nndsvd_topk"; a wide matrix is handled by the caller on the transposed problem, as the
  * reference's SVD switches between its left and right forms, svd.py:237-246) and num_bases <= n.
  * rank_found (may be NULL) receives how many of the leading num_bases eigenvalues exceed the
  * reference's 1e-8 cut (svd.py:130-131); fewer than num_bases is PMF_EINVAL (the reference raises
@@ -179,6 +180,9 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *                sixteen-lanes-per-problem kernel (block principal pivoting on the smaller of HA[P,P] / inv(HA)[N,N]):
  *                1 (default) from 16 384 problems per half step on, 2 always, 0 never (the lane-per-variable kernel).
  *                Same minimisers (they are unique).
+ *   "nndsvd_topk" pmf_nndsvd_init's eigen-solver: -1 (default) full Jacobi up to 1024 columns and the top-k subspace
+ *                iteration beyond, 1 / 0 force one of them where both apply (top-k needs num_bases + 16 <= n, Jacobi
+ *                n <= 4096).  Same W, H to ~1e-8 (well inside the float32 accuracy of the Gram matrix).
  *   "rowgemm_stream" 1 (default): plain products with a long contraction (V H^T of NMFALS / SNMF, W = V M^T) on
  *                k_rowgemm_stream (A fragments straight into registers, requests interleaved with the MFMAs);
  *                0: on k_rowgemm.  Bit-identical results (same order of summation).

@@ -33,6 +33,7 @@
 #include "pmf_inv.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
+#include "pmf_topk.h"
 
 namespace {
 
@@ -101,6 +102,8 @@ struct pmf_ctx {
   double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
   bool wsnap_valid = false;
+  int opt_nndsvd_topk = -1;     // pmf_set_option("nndsvd_topk"): -1 by size, 1 the filtered subspace iteration, 0 full Jacobi
+  int nndsvd_products = 0;      // products with the Gram matrix the last top-k solve took
   int opt_rowgemm_stream = 1;   // pmf_set_option("rowgemm_stream"): plain products with a long contraction on k_rowgemm_stream
   int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): num_bases <= 64 on the sixteen-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
@@ -452,14 +455,237 @@ int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
   return allreduce_sum(c, Ad, (size_t)np * np, true);
 }
 
+// ---- top-k eigenpairs of the Gram matrix (pmf_topk.h) ----------------------------------------------
+// C[M x N] = A[M x K] B, B stored [K][N] (or [N][K]: transb); M, N, K multiples of 16; float64 MFMA.
+int dgemm64(pmf_ctx* c, const double* A, int64_t lda, const double* B, int64_t ldb, int K, double* C, int64_t ldc, int M, int N,
+            bool transb) {
+  const dim3 grid((unsigned)(N / 16), (unsigned)(M / 16));
+  if (transb) hipLaunchKernelGGL((k_dgemm_mfma<true>), grid, dim3(64), 0, c->stream, A, lda, B, ldb, K, C, ldc, (float*)nullptr, (int64_t)0, (const int*)nullptr);
+  else hipLaunchKernelGGL((k_dgemm_mfma<false>), grid, dim3(64), 0, c->stream, A, lda, B, ldb, K, C, ldc, (float*)nullptr, (int64_t)0, (const int*)nullptr);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
+// eigen-decomposition of the nj x nj (nj even) symmetric A (leading dimension ld, as A2 and QT) on the device: evals
+// (unsorted), rows of QT
+int jacobi_eigh_dev(pmf_ctx* c, double* A, double* A2, double* QT, int ld, int nj, double* evals, int* sweeps_done) {
+  const int64_t items = (int64_t)(nj / 2) * (nj / 2) + (int64_t)(nj / 2) * nj;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  const int64_t max_wgs = nj > 1024 ? cus : 64;      // one 1024-thread workgroup per CU at most (cooperative launch)
+  const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(max_wgs, items / 4096));
+  int ld_ = ld, nj_ = nj, sweeps_ = 40;
+  void* args[] = {&A, &A2, &QT, &ld_, &nj_, &sweeps_, &evals, &sweeps_done};
+  HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_jacobi_eigh), dim3(wgs), dim3(1024), args,
+                                       (unsigned)jacobi_smem_bytes(nj), c->stream));
+  return PMF_OK;
+}
+
+// The k largest eigenpairs of G [np][np] (symmetric positive semi-definite, rows / columns >= n zero): rows 0 .. nl-1 of L
+// ([round_up(k, 16)][np], zeroed by the caller) and ev[0 .. nl-1], descending as locked; nl <= k.  pmf_topk.h has the method.
+int eigh_topk(pmf_ctx* c, DevTemps& tmp, double* G, int n, int np, int k, double* L, double* ev_dev, int* nl_out, int* products_out) {
+  const int ld = np;
+  const int kp16 = (int)round_up(k, 16);
+  const int pblk = std::max(16, std::min(64, k / 2));
+  const int s = (int)std::min<int64_t>(round_up(k + pblk, 16), (n / 16) * 16);
+  if (s < 16 || s < k) return fail(c, PMF_EINVAL, "eigh_topk: the block does not fit the matrix");
+  const int64_t cnt = (int64_t)s * ld;
+  double *Ya, *Yb, *Yc, *Z, *D, *GQ, *T1, *S, *S2, *QTs, *Ug, *C1, *dth, *dev_ev, *dsc, *dres;
+  int *dperm, *dinfo;
+  for (double** q : {&Ya, &Yb, &Yc, &Z, &D, &GQ, &T1}) PMFCHK(talloc(c, tmp, q, (size_t)cnt));
+  for (double** q : {&S, &S2, &QTs, &Ug}) PMFCHK(talloc(c, tmp, q, (size_t)s * s));
+  PMFCHK(talloc(c, tmp, &C1, (size_t)s * kp16));
+  PMFCHK(talloc(c, tmp, &dth, (size_t)kp16));
+  PMFCHK(talloc(c, tmp, &dev_ev, (size_t)s));
+  PMFCHK(talloc(c, tmp, &dsc, (size_t)s));
+  PMFCHK(talloc(c, tmp, &dres, (size_t)s));
+  PMFCHK(talloc(c, tmp, &dperm, (size_t)s));
+  PMFCHK(talloc(c, tmp, &dinfo, 2));
+  std::vector<double> th(s), hev(s), hsc(s), hres(s), thl;
+  std::vector<int> perm(s);
+  int nl = 0, products = 0;
+  uint64_t seed = 0x9e3779b97f4a7c15ull;
+  auto blocks = [](int64_t count) { return dim3((unsigned)((count + 255) / 256)); };
+  auto fill_random = [&](double* Y, int r0, int r1) -> int {
+    hipLaunchKernelGGL(k_topk_fill_random, blocks((int64_t)(r1 - r0) * ld), dim3(256), 0, c->stream, Y, r0, r1, ld, n, seed++);
+    HIPCHK(c, hipGetLastError());
+    return PMF_OK;
+  };
+  // D = (Y L^T) diag(theta or 1) L : the locked directions' part of Y (scaled: of A Y)
+  auto locked_part = [&](const double* Y, bool scaled) -> int {
+    PMFCHK(dgemm64(c, Y, ld, L, ld, np, C1, kp16, s, kp16, true));
+    if (scaled) {
+      hipLaunchKernelGGL(k_topk_scale_cols, blocks((int64_t)s * kp16), dim3(256), 0, c->stream, C1, s, kp16, kp16, dth);
+      HIPCHK(c, hipGetLastError());
+    }
+    return dgemm64(c, C1, kp16, L, ld, kp16, D, ld, s, np, false);
+  };
+  // Zout = Y A'  (A' = A with the locked pairs deflated); returns with D = the deflation term when with_d
+  auto apply = [&](const double* Y, double* Zout) -> int {
+    ++products;
+    PMFCHK(dgemm64(c, Y, ld, G, ld, np, Zout, ld, s, np, false));
+    if (nl > 0) PMFCHK(locked_part(Y, true));
+    return PMF_OK;
+  };
+  auto eigh_small = [&](double* A) -> int {                     // A (s x s) -> QTs rows, hev (host, unsorted)
+    PMFCHK(jacobi_eigh_dev(c, A, S2, QTs, s, s, dev_ev, dinfo));
+    HIPCHK(c, hipMemcpyAsync(hev.data(), dev_ev, (size_t)s * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  };
+  auto ortho = [&](double*& Y) -> int {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      if (nl > 0)
+        for (int rep = 0; rep < 2; ++rep) {
+          PMFCHK(locked_part(Y, false));
+          hipLaunchKernelGGL(k_topk_sub, blocks(cnt), dim3(256), 0, c->stream, Y, D, cnt);
+          HIPCHK(c, hipGetLastError());
+        }
+      bool deficient = false;
+      for (int rep = 0; rep < 2 && !deficient; ++rep) {
+        PMFCHK(dgemm64(c, Y, ld, Y, ld, np, S, s, s, s, true));
+        PMFCHK(eigh_small(S));
+        double lmax = 0.0;
+        for (int j = 0; j < s; ++j) lmax = std::max(lmax, hev[j]);
+        if (!(lmax > 0.0) || !std::isfinite(lmax)) return fail(c, PMF_EHIP, "eigh_topk: the block collapsed");
+        for (int j = 0; j < s; ++j) {
+          if (!(hev[j] > 1e-24 * lmax)) { deficient = true; hsc[j] = 0.0; }
+          else hsc[j] = 1.0 / std::sqrt(hev[j]);
+        }
+        HIPCHK(c, hipMemcpyAsync(dsc, hsc.data(), (size_t)s * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PMFCHK(dgemm64(c, QTs, s, Y, ld, s, T1, ld, s, np, false));
+        hipLaunchKernelGGL(k_topk_scale_rows, blocks(cnt), dim3(256), 0, c->stream, T1, s, ld, dsc);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));               // hsc is reused
+        std::swap(Y, T1);
+        if (deficient)                                            // dependent rows came out as zeros: new random ones, again
+          for (int j = 0; j < s; ++j)
+            if (hsc[j] == 0.0) PMFCHK(fill_random(Y, j, j + 1));
+      }
+      if (!deficient) return PMF_OK;
+    }
+    return fail(c, PMF_EHIP, "eigh_topk: could not orthonormalise the block");
+  };
+  // Rayleigh-Ritz on the orthonormal rows Y: GQ = Y A', T = Y GQ^T, rows rotated to the Ritz vectors, th descending
+  auto rayleigh_ritz = [&](double*& Y) -> int {
+    PMFCHK(apply(Y, GQ));
+    if (nl > 0) {
+      hipLaunchKernelGGL(k_topk_sub, blocks(cnt), dim3(256), 0, c->stream, GQ, D, cnt);
+      HIPCHK(c, hipGetLastError());
+    }
+    PMFCHK(dgemm64(c, Y, ld, GQ, ld, np, S, s, s, s, true));
+    PMFCHK(eigh_small(S));
+    for (int j = 0; j < s; ++j) perm[j] = j;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return hev[a] > hev[b]; });
+    for (int j = 0; j < s; ++j) th[j] = hev[perm[j]];
+    HIPCHK(c, hipMemcpyAsync(dperm, perm.data(), (size_t)s * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dev_ev, th.data(), (size_t)s * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_topk_gather_rows, blocks((int64_t)s * s), dim3(256), 0, c->stream, QTs, (int64_t)s, dperm, Ug, (int64_t)s, s, s);
+    HIPCHK(c, hipGetLastError());
+    PMFCHK(dgemm64(c, Ug, s, Y, ld, s, T1, ld, s, np, false));
+    std::swap(Y, T1);
+    PMFCHK(dgemm64(c, Ug, s, GQ, ld, s, T1, ld, s, np, false));
+    std::swap(GQ, T1);
+    hipLaunchKernelGGL(k_topk_resid, dim3((unsigned)s), dim3(256), 0, c->stream, GQ, Y, ld, np, dev_ev, dres);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hres.data(), dres, (size_t)s * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  };
+
+  hipLaunchKernelGGL(k_topk_symmetrise, blocks((int64_t)n * n), dim3(256), 0, c->stream, G, ld, n);
+  HIPCHK(c, hipGetLastError());
+  PMFCHK(fill_random(Ya, 0, s));
+  PMFCHK(ortho(Ya));
+  PMFCHK(rayleigh_ritz(Ya));
+  const double scale = std::max(th[0], 1e-300);
+  // A pair is locked when its residual is below 1e-11 of ITS OWN eigenvalue: the error of the vector is residual / gap, and
+  // a tolerance relative to lambda_1 cannot be met by the dominant pair itself (its rounding floor is ~1e-12 lambda_1 at
+  // n = 4608) while being too loose for the pairs of the bulk (1e-13 lambda_1 = 6e-7 against gaps of 0.05 there).
+  double tol = 1e-11;
+  int stagnant = 0;
+  constexpr int kMaxIter = 300, kMaxDeg = 40;
+  for (int it = 0; it < kMaxIter && nl < k; ++it) {
+    // ---- lock the leading converged pairs, in order ----
+    const int need = k - nl;
+    if (std::getenv("PMF_TOPK_DEBUG")) fprintf(stderr, "topk it %d: locked %d products %d th[0] %.6e th[need-1] %.6e th[s-1] %.6e res[0]/th %.2e res[need-1]/th %.2e\n", it, nl, products, th[0], th[std::min(need, s) - 1], th[s - 1], hres[0] / std::max(th[0], 1e-300), hres[std::min(need, s) - 1] / std::max(th[std::min(need, s) - 1], 1e-300));
+    int nlock = 0;
+    while (nlock < std::min(need, s) && (hres[nlock] <= tol * th[nlock] || th[nlock] <= 1e-14 * scale)) ++nlock;
+    if (nlock == 0 && ++stagnant >= 10) {            // ten filters without a lock: the leading pair sits on its rounding floor
+      if (tol >= 1e-8) return fail(c, PMF_EHIP, "pmf_nndsvd_init: the top-k eigen-solver stalled (residual " + std::to_string(hres[0] / std::max(th[0], 1e-300)) + " of the eigenvalue)");
+      tol *= 30.0;
+      stagnant = 0;
+      continue;
+    }
+    if (nlock > 0) stagnant = 0;
+    if (nlock > 0) {
+      HIPCHK(c, hipMemcpyAsync(L + (size_t)nl * ld, Ya, (size_t)nlock * ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      for (int j = 0; j < nlock; ++j) thl.push_back(th[j]);
+      nl += nlock;
+      HIPCHK(c, hipMemcpyAsync(dth, thl.data(), (size_t)nl * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (nl >= k) break;
+      // the rest of the block moves up, fresh random rows behind it
+      HIPCHK(c, hipMemcpyAsync(T1, Ya + (size_t)nlock * ld, (size_t)(s - nlock) * ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      std::swap(Ya, T1);
+      PMFCHK(fill_random(Ya, s - nlock, s));
+      PMFCHK(ortho(Ya));
+      PMFCHK(rayleigh_ritz(Ya));
+      continue;
+    }
+    // ---- Chebyshev filter: damp [0, cut], degree bounded by the dynamic range inside the block ----
+    const double cut = std::max(th[s - 1], 1e-10 * scale), top = std::max(th[0], cut * (1.0 + 1e-12));
+    const double e = 0.5 * cut, cc = 0.5 * cut;
+    const double x_top = (top - cc) / e, x_k = (std::max(th[std::min(need, s) - 1], cut) - cc) / e;
+    int deg = kMaxDeg;
+    {
+      const double g_top = std::acosh(std::max(x_top, 1.0)), g_k = std::acosh(std::max(x_k, 1.0));
+      if (g_top - g_k > 0.0) deg = (int)std::max(2.0, std::min((double)kMaxDeg, std::floor(std::log(1e9) / (g_top - g_k))));
+    }
+    double sigma = e / (top - cc);
+    const double sigma1 = sigma;
+    PMFCHK(apply(Ya, Z));
+    hipLaunchKernelGGL(k_topk_cheb, blocks(cnt), dim3(256), 0, c->stream, Z, nl > 0 ? D : nullptr, Ya, (const double*)nullptr, Yb, cnt, cc,
+                       sigma1 / e, 0.0);
+    HIPCHK(c, hipGetLastError());
+    for (int d = 2; d <= deg; ++d) {
+      const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+      PMFCHK(apply(Yb, Z));
+      hipLaunchKernelGGL(k_topk_cheb, blocks(cnt), dim3(256), 0, c->stream, Z, nl > 0 ? D : nullptr, Yb, Ya, Yc, cnt, cc, 2.0 * sigma2 / e,
+                         sigma * sigma2);
+      HIPCHK(c, hipGetLastError());
+      double* t = Ya; Ya = Yb; Yb = Yc; Yc = t;
+      sigma = sigma2;
+    }
+    std::swap(Ya, Yb);
+    PMFCHK(ortho(Ya));
+    PMFCHK(rayleigh_ritz(Ya));
+  }
+  std::vector<double> out(kp16, -1.0);
+  for (int j = 0; j < nl && j < kp16; ++j) out[j] = thl[j];
+  HIPCHK(c, hipMemcpyAsync(ev_dev, out.data(), (size_t)kp16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *nl_out = nl;
+  if (products_out) *products_out = products;
+  return PMF_OK;
+}
+
 int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: dense V only");
-  if (c->n > PMF_NNDSVD_MAX_N)
-    return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= " + std::to_string(PMF_NNDSVD_MAX_N) +
-                " (the Gram matrix is n x n and its eigen-decomposition O(n^3); pass the transposed problem for wide data)");
+  if (c->n > PMF_TOPK_MAX_N)
+    return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_samples <= " + std::to_string(PMF_TOPK_MAX_N) +
+                " (the Gram matrix is n x n; pass the transposed problem for wide data)");
   if (c->k > c->n) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases exceeds the number of columns");
   const int n = (int)c->n, np = c->np, KP = c->KP, ld = np;
-  const int nj = n + (n & 1);
+  // all n eigenpairs by Jacobi (pmf_nndsvd.h: exact and quick up to ~1000 columns, 13 s at 4096), or the k largest by
+  // filtered subspace iteration (pmf_topk.h: 0.06 s instead of 1.2 s at 1500 columns, the only form beyond 4096).
+  // pmf_set_option("nndsvd_topk", 1 / 0) forces one of them where both apply; a top-k solve that stalls falls back
+  // to Jacobi where that exists.
+  const bool topk_fits = c->k + 16 <= (n / 16) * 16;
+  bool topk = (n > PMF_NNDSVD_MAX_N) || (topk_fits && (c->opt_nndsvd_topk == 1 || (c->opt_nndsvd_topk < 0 && n > 1024)));
+  if (topk && !topk_fits) return fail(c, PMF_EINVAL, "pmf_nndsvd_init: num_bases too close to the number of columns for this size");
+  int nj = n + (n & 1);
   DevTemps tmp;
   double *Ad = nullptr, *Ad2 = nullptr, *evals = nullptr, *QT = nullptr, *sv = nullptr, *part = nullptr, *norms = nullptr;
   float *slab = nullptr, *B = nullptr, *wscale = nullptr;
@@ -468,10 +694,10 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   int gchunks = (int)std::min<int64_t>(512, blocks16);
   const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;
   gchunks = (int)((c->mp + rpc - 1) / rpc);
+  const int kp16 = (int)round_up(c->k, 16);
+  const bool can_jacobi = n <= PMF_NNDSVD_MAX_N;
   PMFCHK(talloc(c, tmp, &Ad, (size_t)np * np));
-  PMFCHK(talloc(c, tmp, &QT, (size_t)np * np));
-  PMFCHK(talloc(c, tmp, &Ad2, (size_t)np * np));
-  PMFCHK(talloc(c, tmp, &evals, (size_t)np));
+  PMFCHK(talloc(c, tmp, &evals, (size_t)std::max(np, kp16)));
   PMFCHK(talloc(c, tmp, &slab, (size_t)gchunks * 128 * (np + 128)));
   PMFCHK(talloc(c, tmp, &B, (size_t)KP * np));
   PMFCHK(talloc(c, tmp, &sv, (size_t)KP));
@@ -487,20 +713,23 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   // 1. A = V^T V over all ranks' rows
   PMFCHK(gram_vtv(c, Ad, slab, gchunks, rpc));
   // 2./3. eigen-decomposition, top-k selection
-  {
-    const int64_t items = (int64_t)(nj / 2) * (nj / 2) + (int64_t)(nj / 2) * nj;
-    // one 1024-thread workgroup per CU at most (cooperative launch: all must be co-resident)
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    const int64_t max_wgs = nj > 1024 ? cus : 64;
-    const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(max_wgs, items / 4096));
-    double *a_ = Ad, *b_ = Ad2, *q_ = QT, *e_ = evals;
-    int ld_ = ld, nj_ = nj, sweeps_ = 40;
-    int* done_ = info + 1;
-    void* args[] = {&a_, &b_, &q_, &ld_, &nj_, &sweeps_, &e_, &done_};
-    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_jacobi_eigh), dim3(wgs), dim3(1024), args,
-                                         (unsigned)jacobi_smem_bytes(nj), c->stream));
+  if (topk) {
+    int nl = 0;
+    PMFCHK(talloc(c, tmp, &QT, (size_t)kp16 * np));
+    DevTemps work;                                   // the solver's block buffers: freed before the rest of the pipeline
+    const int trc = eigh_topk(c, work, Ad, n, np, c->k, QT, evals, &nl, &c->nndsvd_products);
+    if (trc == PMF_OK) {
+      nj = kp16;                                     // evals[nl ..] = -1: below the reference's 1e-8 cut
+    } else if (can_jacobi) {
+      topk = false;                                  // (the message of the failed solve is replaced by whatever follows)
+    } else {
+      return trc;
+    }
+  }
+  if (!topk) {
+    PMFCHK(talloc(c, tmp, &QT, (size_t)np * np));
+    PMFCHK(talloc(c, tmp, &Ad2, (size_t)np * np));
+    PMFCHK(jacobi_eigh_dev(c, Ad, Ad2, QT, ld, nj, evals, info + 1));
   }
   hipLaunchKernelGGL(k_nndsvd_select, dim3(1), dim3(1024), 0, c->stream, evals, QT, ld, nj, n, c->k, KP, np, B, sv,
                      order, info);
@@ -2288,6 +2517,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (std::strcmp(name, "nnqp_quad") == 0) {
     if (value < 0 || value > 2) return fail(c, PMF_EINVAL, "nnqp_quad: 0 (never), 1 (from 16 384 problems per half step on) or 2 (always)");
     c->opt_nnqp_quad = (int)value;
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "nndsvd_topk") == 0) {
+    if (value < -1 || value > 1) return fail(c, PMF_EINVAL, "nndsvd_topk: -1 (by size), 0 or 1");
+    c->opt_nndsvd_topk = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "rowgemm_stream") == 0) {

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ s
 // A ping-pongs between two buffers (step t reads A0/A1, writes the other), so a workgroup still
 // deriving its rotations never sees a block another workgroup has already rotated.
 // On return evals[j] holds the eigenvalues and row j of QT the eigenvector of evals[j].
-#define PMF_NNDSVD_MAX_N 4096
+#define PMF_NNDSVD_MAX_N 4096          // the full Jacobi decomposition up to here ...
+#define PMF_TOPK_MAX_N 16384           // ... the k largest pairs by filtered subspace iteration (pmf_topk.h) up to here
 static inline size_t jacobi_smem_bytes(int nj) { return (size_t)(nj / 2) * 24; }
 
 __global__ __launch_bounds__(1024) void k_jacobi_eigh(double* A0, double* A1, double* QT,

@@ -4,12 +4,13 @@ Non-negative double SVD (Boutsidis & Gallopoulos 2008): the deterministic initia
 offers for NMF -- factorize() fills W and H once, and the user copies them into an NMF model
 (nndsvd.py:56-64).  The whole computation is one C call, pmf_nndsvd_init (Gram matrix and
 U = data V S^-1 on fp32 MFMA, a float64 Jacobi eigensolver on the device, and the closed form of
-the reference's per-basis second SVD; pymf_amd/csrc/pmf_nndsvd.h).
+the reference's per-basis second SVD; pymf_amd/csrc/pmf_nndsvd.h; beyond 1024 columns the k largest
+eigenpairs by a Chebyshev-filtered subspace iteration on the float64 MFMA, pymf_amd/csrc/pmf_topk.h).
 
 The reference's SVD works on data^T data when rows > cols and on data data^T otherwise
 (svd.py:237-246).  The device routine takes the first form, so a wide matrix is passed transposed
 (W and H swap roles and are transposed back) -- the same switch, made on the host.  Limit of this
-build: min(rows, cols) <= 4096.
+build: min(rows, cols) <= 16384.
 """
 import logging
 

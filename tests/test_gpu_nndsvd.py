@@ -72,11 +72,69 @@ def test_nndsvd_vs_float64_oracle(pm, shape, k):
     assert abs(mdl.ferr[0] - ref_err) <= 1e-4 * max(ref_err, 1e-3)
 
 
+@pytest.mark.parametrize("kind,shape,k", [("uniform", (3000, 1500), 12), ("uniform", (4096, 2048), 200), ("binary", (5000, 2048), 48),
+                                          ("dupcols", (3000, 1024), 20), ("lowrank_exact", (2500, 1280), 30)])
+def test_nndsvd_topk_solver_equals_full_jacobi(pm, kind, shape, k):
+    """pmf_nndsvd_init's two eigen-solvers -- all n pairs of data^T data by Jacobi (svd.py:125-131 takes them all from
+    eigh and keeps the leading ones), or the k largest by the filtered subspace iteration of pmf_topk.h -- give the same
+    W and H: dominant eigenvalue 4 000 x the bulk (uniform), sparse binary data, every eigenvalue double (duplicated
+    columns), an exactly rank-30 matrix asked for 30 bases."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(sum(shape) + k)
+    m, n = shape
+    if kind == "uniform":
+        V = rs.random_sample(shape)
+    elif kind == "binary":
+        V = (rs.random_sample(shape) < 0.05).astype(np.float64)
+    elif kind == "dupcols":
+        a = rs.random_sample((m, n // 2)); V = np.concatenate([a, a], axis=1)
+    else:
+        V = rs.random_sample((m, 30)) @ rs.random_sample((30, n))
+    V = V.astype(np.float32)
+    out = {}
+    for topk in (1, 0):
+        ctx = _lib.Context(_lib.ALGO_NMF, m, n, k)
+        ctx.set_v_dense(V)
+        ctx.set_option("nndsvd_topk", topk)
+        assert ctx.nndsvd_init() == k
+        out[topk] = (ctx.get_w(), ctx.get_h())
+        ctx.close()
+    # (a double eigenvalue leaves the basis of its eigenspace open: compare what NNDSVD makes of it, W H)
+    if kind == "dupcols":
+        a, b = out[1][0].astype(np.float64) @ out[1][1], out[0][0].astype(np.float64) @ out[0][1]
+        assert rel_fro(a, b, what="W H, top-k vs Jacobi") < 1e-5
+    else:
+        tol = 2e-4 if kind == "lowrank_exact" else 1e-6     # rank 30 exactly: the 30th direction sits on float32 noise
+        assert rel_fro(out[1][0], out[0][0], what="W, top-k vs Jacobi") < tol
+        assert rel_fro(out[1][1], out[0][1], what="H, top-k vs Jacobi") < tol
+
+
+def test_nndsvd_beyond_4096_columns_vs_float64_oracle(pm):
+    """min(m, n) > 4096 (svd.py:125-148 has no size limit): only the top-k solver exists there."""
+    from oracle import nndsvd_closed_form
+    shape, k = (5000, 4608), 32
+    V = np.random.RandomState(7).random_sample(shape).astype(np.float32)
+    mdl = pm.NNDSVD(V, num_bases=k)
+    mdl.factorize()
+    W, H = nndsvd_closed_form(V, k)
+    assert rel_fro(mdl.W, W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, H, what="mdl.H") < 2e-5
+    wide = pm.NNDSVD(np.ascontiguousarray(V.T[:, :4700]), num_bases=8)      # 4608 x 4700: the transposed problem, still > 4096
+    wide.factorize()
+    W2, H2 = nndsvd_closed_form(np.ascontiguousarray(V.T[:, :4700]), 8)
+    assert rel_fro(wide.W, W2, what="wide.W") < 2e-5 and rel_fro(wide.H, H2, what="wide.H") < 2e-5
+
+
 def test_nndsvd_rank_deficient_raises(pm):
     from pymf_amd._lib import PmfError
     V = np.outer(np.arange(1, 41, dtype=np.float32), np.arange(1, 9, dtype=np.float32))   # rank 1
     mdl = pm.NNDSVD(V, num_bases=3)
     with pytest.raises(PmfError):                        # reference: IndexError at nndsvd.py:94
+        mdl.factorize()
+    # ... and through the top-k solver (n > 1024): rank 3, 40 bases asked for (0/1 factors: the float32 Gram matrix is exact)
+    rs = np.random.RandomState(3)
+    V = ((rs.random_sample((2000, 3)) < 0.5).astype(np.float32) @ (rs.random_sample((3, 1100)) < 0.5).astype(np.float32))
+    mdl = pm.NNDSVD(V, num_bases=40)
+    with pytest.raises(PmfError):
         mdl.factorize()
 
 
