@@ -603,7 +603,7 @@ int eigh_topk(pmf_ctx* c, DevTemps& tmp, double* G, int n, int np, int k, double
   // A pair is locked when its residual is below 1e-11 of ITS OWN eigenvalue: the error of the vector is residual / gap, and
   // a tolerance relative to lambda_1 cannot be met by the dominant pair itself (its rounding floor is ~1e-12 lambda_1 at
   // n = 4608) while being too loose for the pairs of the bulk (1e-13 lambda_1 = 6e-7 against gaps of 0.05 there).
-  double tol = 1e-11;
+  double tol = 1e-11, prev_lead = 1e300;
   int stagnant = 0;
   constexpr int kMaxIter = 300, kMaxDeg = 40;
   for (int it = 0; it < kMaxIter && nl < k; ++it) {
@@ -612,12 +612,21 @@ int eigh_topk(pmf_ctx* c, DevTemps& tmp, double* G, int n, int np, int k, double
     if (std::getenv("PMF_TOPK_DEBUG")) fprintf(stderr, "topk it %d: locked %d products %d th[0] %.6e th[need-1] %.6e th[s-1] %.6e res[0]/th %.2e res[need-1]/th %.2e\n", it, nl, products, th[0], th[std::min(need, s) - 1], th[s - 1], hres[0] / std::max(th[0], 1e-300), hres[std::min(need, s) - 1] / std::max(th[std::min(need, s) - 1], 1e-300));
     int nlock = 0;
     while (nlock < std::min(need, s) && (hres[nlock] <= tol * th[nlock] || th[nlock] <= 1e-14 * scale)) ++nlock;
-    if (nlock == 0 && ++stagnant >= 10) {            // ten filters without a lock: the leading pair sits on its rounding floor
-      if (tol >= 1e-8) return fail(c, PMF_EHIP, "pmf_nndsvd_init: the top-k eigen-solver stalled (residual " + std::to_string(hres[0] / std::max(th[0], 1e-300)) + " of the eigenvalue)");
-      tol *= 30.0;
-      stagnant = 0;
-      continue;
+    // the leading pair sits on its rounding floor (its residual no longer halves from one filter to the next; at
+    // n = 16 384 the floor of the bulk pairs is 3e-10 of their eigenvalue: the deflated lambda_1 leaves eps lambda_1 behind):
+    // take the floor as the tolerance
+    const double lead = hres[0] / std::max(th[0], 1e-300);
+    if (nlock == 0) {
+      stagnant = (lead > 0.5 * prev_lead) ? stagnant + 1 : 0;
+      if (stagnant >= 2 || it > kMaxIter - 3) {
+        if (lead > 1e-8) return fail(c, PMF_EHIP, "pmf_nndsvd_init: the top-k eigen-solver stalled (residual " + std::to_string(lead) + " of the eigenvalue)");
+        tol = std::max(tol, 2.0 * lead);
+        stagnant = 0;
+        prev_lead = 1e300;
+        continue;
+      }
     }
+    prev_lead = nlock > 0 ? 1e300 : lead;
     if (nlock > 0) stagnant = 0;
     if (nlock > 0) {
       HIPCHK(c, hipMemcpyAsync(L + (size_t)nl * ld, Ya, (size_t)nlock * ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

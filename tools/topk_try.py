@@ -24,7 +24,7 @@ def make(kind, m, n, rs):
 
 cases = [("uniform", 3000, 1500, 12), ("uniform", 6000, 2048, 100), ("lowrank", 4000, 1536, 64), ("binary", 5000, 2048, 48),
          ("dupcols", 3000, 1024, 20), ("diagish", 4096, 1024, 32), ("uniform", 5000, 4608, 32), ("uniform", 9000, 8192, 64),
-         ("uniform", 4096, 2048, 256), ("uniform", 17000, 16384, 64), ("uniform", 12000, 8192, 512)]
+         ("uniform", 4096, 2048, 256), ("uniform", 17000, 16384, 64), ("uniform", 12000, 8000, 512)]
 if len(sys.argv) > 1:
     cases = [c for c in cases if c[0] in sys.argv[1:] or str(c[2]) in sys.argv[1:]]
 for (kind, m, n, k) in cases:
