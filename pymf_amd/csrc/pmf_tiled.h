@@ -213,6 +213,34 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, in
   }
 }
 
+// N consecutive floats (N = 1, 2, 4, 8; the address is a multiple of 4 N bytes): one or two vector accesses
+template <int N>
+__device__ __forceinline__ void vec_load(const float* __restrict__ p, float (&v)[N]) {
+  if constexpr (N >= 4) {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+  } else if constexpr (N == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = p[0];
+  }
+}
+template <int N>
+__device__ __forceinline__ void vec_store(float* __restrict__ p, const float (&v)[N]) {
+  if constexpr (N >= 4) {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  } else if constexpr (N == 2) {
+    *reinterpret_cast<float2*>(p) = float2{v[0], v[1]};
+  } else {
+    p[0] = v[0];
+  }
+}
+
 // Plain product C[rows][KP] = A[rows][kdim] B[KP][kdim]^T for long contractions (kdim % 64 == 0): NMFALS' and SNMF's
 // V H^T, SNMF's W = V M^T.  The wave keeps 16*RB rows: their A fragments come straight from global memory into two
 // register stages (the lane layout of the 16x16x4 MFMA's A operand IS a 16-byte global read per lane), one 64-column
@@ -262,11 +290,14 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
       pbr[q] = *reinterpret_cast<const f32x4*>(B + (int64_t)(id >> 4) * ldb + 64 * pp + 4 * (id & 15));
     }
   };
+  // The MFMA N index of a lane is free: B row (basis) NT i + nt goes to LDS row 16 nt + i, so column i of tile nt IS basis
+  // NT i + nt and the NT tiles of a lane hold NT CONSECUTIVE bases -- the epilogue reads and writes them as vectors
+  // (at 128 bases: 512 contiguous bytes per row instead of eight 64-byte pieces).  Same sums, same order: same bits.
   auto store_b = [&](float* cb) {
 #pragma unroll
     for (int q = 0; q < BCH; ++q) {
-      const int id = tid + 256 * q;
-      lds_write4(cb, id >> 4, id & 15, pbr[q]);
+      const int id = tid + 256 * q, brow = id >> 4;
+      lds_write4(cb, 16 * (brow % NT) + brow / NT, id & 15, pbr[q]);
     }
   };
   auto panel = [&](int p, f32x4 (&fa)[RB][4], f32x4 (&fan)[RB][4]) {
@@ -308,9 +339,12 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int j = 0; j < 4; ++j) {
+          float v[NT];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) C[((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + 16 * nt + i] = acc[rb][nt][j];
+          for (int nt = 0; nt < NT; ++nt) v[nt] = acc[rb][nt][j];
+          vec_store<NT>(C + ((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + NT * i, v);
+        }
     }
     return;
   }
@@ -322,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
     __syncthreads();                                     // every wave is through with the B panels
     for (int id = tid; id < GPAN * KP * GCH; id += 256) {
       const int pg = id / (KP * GCH), rem = id % (KP * GCH), row = rem / GCH, ch = rem % GCH;
-      lds_write4(smem + pg * (KP * 64), row, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
+      lds_write4(smem + pg * (KP * 64), 16 * (row % NT) + row / NT, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
     }
     const float* Wrow = W + ((int64_t)(act ? tile : 0) * WR + i) * ldw + 4 * kq;
 #pragma unroll
@@ -351,24 +385,29 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = (int64_t)tile * WR + 16 * rb + 4 * kq + j;
+      float* p = W + row * ldw + NT * i;                        // bases NT i .. NT i + NT - 1 of this row
+      float wv_[NT], dn_[NT], out[NT];
+      vec_load<NT>(p, wv_);
+      if (DENBUF) vec_load<NT>(G + row * ldw + NT * i, dn_);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t row = (int64_t)tile * WR + 16 * rb + 4 * kq + j;
-        float* p = W + row * ldw + 16 * nt + i;
-        const float w = *p;
-        const float num = acc[rb][nt][j], dn = DENBUF ? G[row * ldw + 16 * nt + i] : den[rb][nt][j];
+      for (int nt = 0; nt < NT; ++nt) {
+        const float w = wv_[nt];
+        const float num = acc[rb][nt][j], dn = DENBUF ? dn_[nt] : den[rb][nt][j];
         if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
           const float r = w * ((fabsf(num) - num) / (2.0f * dn));
-          *p = (row < mvalid && (16 * nt + i) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
+          out[nt] = (row < mvalid && (NT * i + nt) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
         } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
           const float w1 = num + (3.0f * lamb) * (w * w);
           const float w2 = ((dn + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
-          *p = w * (w1 / w2);
+          out[nt] = w * (w1 / w2);
         } else {
-          *p = (w * num) / (dn + PMF_EPS_DEN);                // multiply, then divide (nmf.py:131-132)
+          out[nt] = (w * num) / (dn + PMF_EPS_DEN);           // multiply, then divide (nmf.py:131-132)
         }
       }
+      vec_store<NT>(p, out);
+    }
 }
 
 // Partials of P = W^T V and S = W^T W over one chunk of rows.
