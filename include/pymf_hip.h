@@ -183,6 +183,9 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *   "nndsvd_topk" pmf_nndsvd_init's eigen-solver: -1 (default) full Jacobi up to 1024 columns and the top-k subspace
  *                iteration beyond, 1 / 0 force one of them where both apply (top-k needs num_bases + 16 <= n, Jacobi
  *                n <= 4096).  Same W, H to ~1e-8 (well inside the float32 accuracy of the Gram matrix).
+ *   "colgemm_stream" 1 (default): the W^T V | W^T W partials of the two-pass path on k_colgemm_stream (V fragments straight
+ *                into registers, requests interleaved with the MFMAs, W rows through LDS once per workgroup) where it
+ *                applies (16 < num_bases <= 64; blocks of 128 bases); 0: k_colgemm.  Bit-identical results.
  *   "rowgemm_stream" 1 (default): plain products with a long contraction (V H^T of NMFALS / SNMF, W = V M^T) on
  *                k_rowgemm_stream (A fragments straight into registers, requests interleaved with the MFMAs);
  *                0: on k_rowgemm.  Bit-identical results (same order of summation).

@@ -104,6 +104,7 @@ struct pmf_ctx {
   bool wsnap_valid = false;
   int opt_nndsvd_topk = -1;     // pmf_set_option("nndsvd_topk"): -1 by size, 1 the filtered subspace iteration, 0 full Jacobi
   int nndsvd_products = 0;      // products with the Gram matrix the last top-k solve took
+  int opt_colgemm_stream = 1;   // pmf_set_option("colgemm_stream"): W^T V partials on k_colgemm_stream where it applies
   int opt_rowgemm_stream = 1;   // pmf_set_option("rowgemm_stream"): plain products with a long contraction on k_rowgemm_stream
   int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): num_bases <= 64 on the sixteen-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
@@ -274,18 +275,38 @@ int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, 
   return fail(c, PMF_EINVAL, "bad NT");
 }
 
-int colgemm(pmf_ctx* c, bool with_v = true) {
-  dim3 grid((unsigned)c->nchunks, with_v ? (unsigned)((c->np + 255) / 256) : 1u);
-  const float* Vp = with_v ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : nullptr;
-  switch (c->NT) {
-    case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
-    case 8: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, Vp, (int64_t)c->np, c->np, c->dW, (int64_t)c->KP, c->mp, c->rows_per_chunk, c->dSlab); break;
-    default: return fail(c, PMF_EINVAL, "bad NT");
+// Partials of (W^T X | W^T W) over row chunks into c->dSlab: X [rows_p][xn] (ldx), W [rows_p][.] (ldw), chunks of rpc rows.
+// k_colgemm_stream where it applies (NT = 4, or NT = 8 without S; rpc a multiple of its stage), else k_colgemm.
+template <int NT, bool WITH_S>
+int launch_colgemm(pmf_ctx* c, const float* X, int64_t ldx, int xn, const float* W, int64_t ldw, int64_t rows_p, int rpc, int nch) {
+  const dim3 grid((unsigned)nch, X ? (unsigned)((xn + 255) / 256) : 1u);
+  if constexpr (NT == 4 || (NT == 8 && !WITH_S)) {
+    constexpr int SR = NT == 4 ? 64 : 32;
+    if (c->opt_colgemm_stream && X != nullptr && rpc % SR == 0 && rows_p % SR == 0) {
+      hipLaunchKernelGGL((k_colgemm_stream<NT, WITH_S>), grid, dim3(256), (size_t)2 * SR * (16 * NT + 4) * sizeof(float), c->stream,
+                         X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab);
+      HIPCHK(c, hipGetLastError());
+      return PMF_OK;
+    }
   }
+  hipLaunchKernelGGL((k_colgemm<NT, WITH_S>), grid, dim3(256), 0, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
+}
+
+int colgemm_rows(pmf_ctx* c, const float* X, const float* W, int64_t rows_p, int rpc, int nch) {
+  switch (c->NT) {
+    case 1: return launch_colgemm<1, true>(c, X, c->np, c->np, W, c->KP, rows_p, rpc, nch);
+    case 2: return launch_colgemm<2, true>(c, X, c->np, c->np, W, c->KP, rows_p, rpc, nch);
+    case 4: return launch_colgemm<4, true>(c, X, c->np, c->np, W, c->KP, rows_p, rpc, nch);
+    case 8: return launch_colgemm<8, true>(c, X, c->np, c->np, W, c->KP, rows_p, rpc, nch);
+  }
+  return fail(c, PMF_EINVAL, "bad NT");
+}
+
+int colgemm(pmf_ctx* c, bool with_v = true) {
+  const float* Vp = with_v ? (c->algo == PMF_ALGO_RNMF ? c->dD : c->dV) : nullptr;
+  return colgemm_rows(c, Vp, c->dW, c->mp, c->rows_per_chunk, c->nchunks);
 }
 
 int64_t ps_elems(const pmf_ctx* c) { return (int64_t)c->KP * (c->np + c->KP); }
@@ -895,10 +916,7 @@ int bigk_ps_rows(pmf_ctx* c, const float* Xv, const float* Wr, int64_t rows_p, i
     for (int pass = 0; pass < 2; ++pass) {                 // 0: W_b^T V -> P rows,  1: W_b^T W -> S rows
       const float* X = pass == 0 ? Xv : Wr;
       const int xn = pass == 0 ? c->np : c->KP;
-      dim3 grid((unsigned)nch, (unsigned)((xn + 255) / 256));
-      hipLaunchKernelGGL((k_colgemm<8, false>), grid, dim3(256), 0, c->stream, X, (int64_t)xn, xn, Wr + b * 128, (int64_t)c->KP,
-                         rows_p, rpc, c->dSlab);
-      HIPCHK(c, hipGetLastError());
+      PMFCHK((launch_colgemm<8, false>(c, X, xn, xn, Wr + b * 128, c->KP, rows_p, rpc, nch)));
       const int64_t cnt4 = (int64_t)128 * xn / 4;
       const size_t off = (size_t)b * 128 * ldp + (pass == 0 ? 0 : c->np);
       if (acc)
@@ -1751,6 +1769,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   pmf_ctx* c = new (std::nothrow) pmf_ctx();
   if (!c) return fail(nullptr, PMF_ENOMEM, "host allocation failed");
   c->algo = algo; c->m = m_local; c->n = n; c->k = k; c->device = device; c->rank = rank; c->nranks = nranks;
+  if (const char* e = std::getenv("PMF_COLGEMM_STREAM")) c->opt_colgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("colgemm_stream")
   if (const char* e = std::getenv("PMF_ROWGEMM_STREAM")) c->opt_rowgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("rowgemm_stream")
   if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
@@ -1783,7 +1802,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     int want = std::max(1, 1024 / n_panels);
     int64_t blocks16 = c->mp / 16;
     c->nchunks = (int)std::min<int64_t>(want, blocks16);
-    c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 1) * 16);
+    c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 4) * 16);   // whole 64-row stages (k_colgemm_stream)
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
     c->fused_wgs = (c->nb == 1 && (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF))
                        ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
@@ -2315,19 +2334,12 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
     if ((c->st_flags & (PMF_COMPUTE_H | PMF_COMPUTE_ERR)) && !((c->st_flags & PMF_COMPUTE_W) == 0 && c->ps_valid)) {
       const int64_t blocks16 = rows_p / 16;
       int tch = (int)std::min<int64_t>(c->nchunks, blocks16);
-      const int rpc = (int)((blocks16 + tch - 1) / tch) * 16;
+      const int rpc = (int)round_up((blocks16 + tch - 1) / tch, 4) * 16;
       tch = (int)((rows_p + rpc - 1) / rpc);
-      dim3 grid((unsigned)tch, (unsigned)((c->np + 255) / 256));
       if (c->nb > 1) {
         PMFCHK(bigk_ps_rows(c, T, Wt, rows_p, rpc, tch, c->dPSacc, first));
       } else {
-      switch (c->NT) {
-        case 1: hipLaunchKernelGGL((k_colgemm<1>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
-        case 2: hipLaunchKernelGGL((k_colgemm<2>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
-        case 4: hipLaunchKernelGGL((k_colgemm<4>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
-        default: hipLaunchKernelGGL((k_colgemm<8>), grid, dim3(256), 0, c->stream, T, (int64_t)c->np, c->np, Wt, (int64_t)c->KP, rows_p, rpc, c->dSlab); break;
-      }
-      HIPCHK(c, hipGetLastError());
+      PMFCHK(colgemm_rows(c, T, Wt, rows_p, rpc, tch));
       const int64_t E = ps_elems(c);
       hipLaunchKernelGGL(k_reduce_slabs_acc, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->dSlab, tch,
                          E, c->dPSacc, first);
@@ -2531,6 +2543,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (std::strcmp(name, "nndsvd_topk") == 0) {
     if (value < -1 || value > 1) return fail(c, PMF_EINVAL, "nndsvd_topk: -1 (by size), 0 or 1");
     c->opt_nndsvd_topk = (int)value;
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "colgemm_stream") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "colgemm_stream: 0 or 1");
+    c->opt_colgemm_stream = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "rowgemm_stream") == 0) {

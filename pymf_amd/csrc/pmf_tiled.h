@@ -534,6 +534,149 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
     }
 }
 
+// The mirror of k_rowgemm_stream for the partials of P = W^T V (and S = W^T W): the V fragments of a wave's 64 columns go
+// straight into two register stages, one stage of SR rows ahead, the requests interleaved with the MFMAs (one b128 per
+// 4 NT MFMAs); the W rows of a stage travel through LDS ONCE per workgroup -- k_colgemm's four waves (and the four column
+// panels of a 1 024-column V) each fetch them from L2 -- one barrier per stage.  Same slab layout and the same order of
+// summation per accumulator as k_colgemm: bit-identical partials.  NT = 4 (SR = 64) and NT = 8 without the S tiles
+// (SR = 32: 128 accumulator registers leave room for 2 x 32 of V); rows_per_chunk a multiple of SR.  A chunk with an
+// odd number of stages runs one stage more on zeroed W rows (no branch inside the stage pair: LLVM would sink the
+// prefetch into it).  262 144 x 1 024, k = 64 in the lab (tools/colgemm_lab.hip): 0.33-0.35 ms against 0.39-0.42.
+template <int NT, bool WITH_S>
+__global__ __launch_bounds__(256, 2) void k_colgemm_stream(const float* __restrict__ V, int64_t ldv, int np,
+                                                           const float* __restrict__ W, int64_t ldw, int64_t mp,
+                                                           int rows_per_chunk, float* __restrict__ slab) {
+  static_assert(NT == 4 || (NT == 8 && !WITH_S), "k_colgemm_stream: NT = 4, or NT = 8 without the S tiles");
+  constexpr int KP = 16 * NT;
+  constexpr int ST = (NT + 3) / 4;
+  constexpr int SR = NT == 4 ? 64 : 32;                // rows per stage
+  constexpr int STEPS = SR / 16;
+  constexpr int WLD = KP + 4;                          // padded row of the W stage in LDS (floats)
+  constexpr int WCH = SR * (KP / 4) / 256;             // 16-byte pieces of a W stage per thread
+  constexpr int AQ = NT / 4;                           // 16-byte pieces of a lane's NT consecutive bases
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
+  int64_t r_end = r_begin + rows_per_chunk;
+  if (r_end > mp) r_end = mp;
+  const int nst = (int)((r_end - r_begin) / SR);
+  const int c0 = blockIdx.y * 256 + 64 * wv;
+  const bool pact = c0 < np;
+  const bool sact = WITH_S && blockIdx.y == 0;
+  const int c0l = pact ? c0 : np - 64;
+  f32x4 P[NT][4];
+  f32x4 S[NT][ST];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) P[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < ST; ++st) S[mt][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* Vl = V + (r_begin + 4 * kq) * ldv + c0l + 4 * i;
+  f32x4 va0[STEPS][4], va1[STEPS][4];                  // [16-row step][j]: V[r + 16 t + 4 kq + j][c0 + 4 i ..]
+  f32x4 pw[WCH];
+  auto load_w = [&](int s) {                           // (a stage beyond the chunk re-requests the last one: straight-line code)
+    const int ss = s < nst ? s : nst - 1;
+#pragma unroll
+    for (int q = 0; q < WCH; ++q) {
+      const int id = tid + 256 * q;
+      pw[q] = *reinterpret_cast<const f32x4*>(W + (r_begin + (int64_t)ss * SR + id / (KP / 4)) * ldw + 4 * (id % (KP / 4)));
+    }
+  };
+  auto store_w = [&](float* buf, int s) {
+    const bool live = s < nst;                         // ... and multiplies by zeros
+#pragma unroll
+    for (int q = 0; q < WCH; ++q) {
+      const int id = tid + 256 * q;
+      const f32x4 v = live ? pw[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(buf + (id / (KP / 4)) * WLD + 4 * (id % (KP / 4))) = v;
+    }
+  };
+  struct AFrag { f32x4 q[AQ]; };                       // bases NT i .. NT i + NT - 1 of one W row
+  auto read_a = [&](const float* wb, int row) {
+    AFrag a;
+#pragma unroll
+    for (int u = 0; u < AQ; ++u) a.q[u] = *reinterpret_cast<const f32x4*>(wb + row * WLD + NT * i + 4 * u);
+    return a;
+  };
+  auto stage = [&](int s, f32x4 (&va)[STEPS][4], f32x4 (&van)[STEPS][4]) {
+    const float* wb = smem + (s & 1) * (SR * WLD);
+    const int sn = s + 1 < nst ? s + 1 : nst - 1;
+    const float* Vn = Vl + (int64_t)sn * SR * ldv;
+    __syncthreads();
+    AFrag a = read_a(wb, 4 * kq);
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        AFrag an = a;
+        if (4 * t + j < 4 * STEPS - 1) {                 // the next step's W fragment: its LDS round trip runs under these MFMAs
+          const int tn = (4 * t + j + 1) >> 2, jn = (4 * t + j + 1) & 3;
+          an = read_a(wb, 16 * tn + 4 * kq + jn);
+        }
+        van[t][j] = *reinterpret_cast<const f32x4*>(Vn + (int64_t)(16 * t + j) * ldv);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) P[mt][nt] = mfma16(a.q[mt / 4][mt % 4], va[t][j][nt], P[mt][nt]);
+        if (sact) {
+          // wave w forms the S tiles (mt, nt = w + 4 st); the B operand is the same register file
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int st = 0; st < ST; ++st) {
+              float b = 0.f;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                if (nt == wv + 4 * st) b = a.q[nt / 4][nt % 4];
+              S[mt][st] = mfma16(a.q[mt / 4][mt % 4], b, S[mt][st]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = an;
+      }
+    store_w(smem + ((s + 1) & 1) * (SR * WLD), s + 1);  // W stage s + 1: its buffer was last read in stage s - 1
+    load_w(s + 2);
+  };
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) va0[t][j] = *reinterpret_cast<const f32x4*>(Vl + (int64_t)(16 * t + j) * ldv);
+  load_w(0);
+  store_w(smem, 0);
+  load_w(1);
+  for (int s = 0; s < nst; s += 2) {
+    stage(s, va0, va1);
+    stage(s + 1, va1, va0);
+  }
+  // tile (mt, nt), lane (c = i, q = kq), register jj  <->  base NT*(4q + jj) + mt,  column 4c + nt  (as k_colgemm)
+  const int64_t ldp = (int64_t)np + KP;
+  float* base = slab + (int64_t)blockIdx.x * KP * ldp;
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float* rowp = base + (int64_t)(NT * (4 * kq + jj) + mt) * ldp;
+      if (pact) {
+        f32x4 o;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt] = P[mt][nt][jj];
+        *reinterpret_cast<f32x4*>(rowp + c0 + 4 * i) = o;
+      }
+      if (sact) {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+          const int nt = wv + 4 * st;
+          if (nt < NT) rowp[np + NT * i + nt] = S[mt][st][jj];
+        }
+      }
+    }
+}
+
 // out[e] = sum over slabs of slab[c][e], fixed order, float64 accumulation.
 // One block (1024 threads) = 256 consecutive elements as 64 float4; wave w sums slabs
 // w, w+16, ... (coalesced 1-KiB reads), the 16 partials are combined in wave order.

@@ -89,8 +89,9 @@ def test_snmf_wide_vs_float64_oracle(pm, shape, k, mode):
         mdl.factorize(niter=3)
         o.factorize(niter=3)
         # k = 1024 on 1100 columns: H H^T is nearly singular (k / n = 0.93), the float32 roundings of M^T and
-        # (P | S) show in the sixth digit of the error; the other shapes sit at 1e-8
-        close(mdl.ferr, o.ferr, rtol=6e-6 if k == 1024 else 1e-6, what="mdl.ferr")
+        # (P | S) show in the sixth digit of the error -- 2e-6 or 8e-6 depending on nothing but the order in which
+        # the row chunks' partial sums are added (64- vs 16-row chunk granularity); the other shapes sit at 1e-8
+        close(mdl.ferr, o.ferr, rtol=3e-5 if k == 1024 else 1e-6, what="mdl.ferr")
     assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 2e-6
 
 

@@ -380,7 +380,8 @@ def test_bitwise_reproducible(pm):
 ])
 def test_rowgemm_stream_and_rowgemm_are_bit_identical(pm, algo_name, m, n, k):
     """`k_rowgemm_stream` (A straight into registers, requests interleaved with the MFMAs; contractions that are a
-    multiple of 128 wide) forms every accumulator in the same order as `k_rowgemm`: the W step (nmf.py:128-132,
+    multiple of 128 wide) forms every accumulator in the same order as `k_rowgemm`, and `k_colgemm_stream` (the
+    mirror for W^T V | W^T W: 32 < num_bases <= 64 and blocks of 128 bases) in the same order as `k_colgemm`: the W step (nmf.py:128-132,
     bnmf.py:87-90, rnmf.py:109-115; the plain product of nmfals.py:88 and of base blocks beyond 128) must come out
     bit for bit the same whichever of the two runs, ragged row counts and partly filled base tiles included."""
     from pymf_amd import _lib
@@ -395,6 +396,7 @@ def test_rowgemm_stream_and_rowgemm_are_bit_identical(pm, algo_name, m, n, k):
         c = _lib.Context(getattr(_lib, "ALGO_" + algo_name), m, n, k)
         c.set_option("force_tiled", 1)
         c.set_option("rowgemm_stream", stream)
+        c.set_option("colgemm_stream", stream)       # k_colgemm_stream vs k_colgemm: the same, for the H step's partials
         if algo_name == "BNMF":
             c.set_lambda(0.3, 0.2)
         if algo_name == "RNMF":
