@@ -280,11 +280,25 @@ int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, 
 template <int NT, bool WITH_S>
 int launch_colgemm(pmf_ctx* c, const float* X, int64_t ldx, int xn, const float* W, int64_t ldw, int64_t rows_p, int rpc, int nch) {
   const dim3 grid((unsigned)nch, X ? (unsigned)((xn + 255) / 256) : 1u);
+  constexpr int SR = NT == 4 ? 64 : 32;
+  const bool stream_ok = c->opt_colgemm_stream && X != nullptr && rpc % SR == 0 && rows_p % SR == 0;
+  const size_t smem = (size_t)2 * SR * (16 * NT + 4) * sizeof(float);
   if constexpr (NT == 4 || (NT == 8 && !WITH_S)) {
-    constexpr int SR = NT == 4 ? 64 : 32;
-    if (c->opt_colgemm_stream && X != nullptr && rpc % SR == 0 && rows_p % SR == 0) {
-      hipLaunchKernelGGL((k_colgemm_stream<NT, WITH_S>), grid, dim3(256), (size_t)2 * SR * (16 * NT + 4) * sizeof(float), c->stream,
-                         X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab);
+    if (stream_ok) {
+      hipLaunchKernelGGL((k_colgemm_stream<NT, WITH_S>), grid, dim3(256), smem, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab,
+                         (int64_t)xn + 16 * NT, 0);
+      HIPCHK(c, hipGetLastError());
+      return PMF_OK;
+    }
+  }
+  if constexpr (NT == 8 && WITH_S) {
+    // 64 < num_bases <= 128: with the S tiles k_colgemm<8> holds 192 accumulator registers; the stream kernel forms P and,
+    // as a second product with W in V's place, S -- into the same slabs (columns [xn, xn + 128))
+    if (stream_ok) {
+      hipLaunchKernelGGL((k_colgemm_stream<8, false>), grid, dim3(256), smem, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab,
+                         (int64_t)xn + 128, 0);
+      hipLaunchKernelGGL((k_colgemm_stream<8, false>), dim3((unsigned)nch, 1u), dim3(256), smem, c->stream, W, ldw, 128, W, ldw, rows_p, rpc,
+                         c->dSlab, (int64_t)xn + 128, xn);
       HIPCHK(c, hipGetLastError());
       return PMF_OK;
     }

@@ -545,7 +545,10 @@ __global__ __launch_bounds__(256) void k_colgemm(const float* __restrict__ V, in
 template <int NT, bool WITH_S>
 __global__ __launch_bounds__(256, 2) void k_colgemm_stream(const float* __restrict__ V, int64_t ldv, int np,
                                                            const float* __restrict__ W, int64_t ldw, int64_t mp,
-                                                           int rows_per_chunk, float* __restrict__ slab) {
+                                                           int rows_per_chunk, float* __restrict__ slab, int64_t ldp,
+                                                           int col_off) {
+  // ldp: row stride of a slab ([KP][ldp] per chunk), col_off: first slab column of this product (np for the pass that
+  // forms S = W^T W as a product of its own, with W in V's place: 64 < num_bases <= 128)
   static_assert(NT == 4 || (NT == 8 && !WITH_S), "k_colgemm_stream: NT = 4, or NT = 8 without the S tiles");
   constexpr int KP = 16 * NT;
   constexpr int ST = (NT + 3) / 4;
@@ -654,8 +657,7 @@ __global__ __launch_bounds__(256, 2) void k_colgemm_stream(const float* __restri
     stage(s + 1, va1, va0);
   }
   // tile (mt, nt), lane (c = i, q = kq), register jj  <->  base NT*(4q + jj) + mt,  column 4c + nt  (as k_colgemm)
-  const int64_t ldp = (int64_t)np + KP;
-  float* base = slab + (int64_t)blockIdx.x * KP * ldp;
+  float* base = slab + (int64_t)blockIdx.x * KP * ldp + col_off;
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void k_colgemm_stream(const float* __restri
 #pragma unroll
         for (int st = 0; st < ST; ++st) {
           const int nt = wv + 4 * st;
-          if (nt < NT) rowp[np + NT * i + nt] = S[mt][st][jj];
+          if (nt < NT) rowp[np - col_off + NT * i + nt] = S[mt][st][jj];
         }
       }
     }

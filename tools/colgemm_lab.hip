@@ -278,6 +278,6 @@ int main(int argc, char** argv) {
   printf("max rel diff of the slabs %.2e\n", md);
   return 0;
 }
-template __global__ void k_colgemm_stream<4, true>(const float*, int64_t, int, const float*, int64_t, int64_t, int, float*);
-template __global__ void k_colgemm_stream<4, false>(const float*, int64_t, int, const float*, int64_t, int64_t, int, float*);
-template __global__ void k_colgemm_stream<8, false>(const float*, int64_t, int, const float*, int64_t, int64_t, int, float*);
+template __global__ void k_colgemm_stream<4, true>(const float*, int64_t, int, const float*, int64_t, int64_t, int, float*, int64_t, int);
+template __global__ void k_colgemm_stream<4, false>(const float*, int64_t, int, const float*, int64_t, int64_t, int, float*, int64_t, int);
+template __global__ void k_colgemm_stream<8, false>(const float*, int64_t, int, const float*, int64_t, int64_t, int, float*, int64_t, int);
