@@ -6,6 +6,8 @@ m, n, k = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 niter = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 algo = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = _lib.Context(algo, m, n, k)
+if os.environ.get("QB_FORCE_TILED"):
+    ctx.set_option("force_tiled", 1)          # the any-shape two-pass kernels on a one-pass kernel's shape
 ctx.fill_v_uniform(1234); ctx.fill_w_uniform(42); ctx.fill_h_uniform(43)
 print("path", ctx.path_name)
 ctx.factorize(3, compute_err=False)
