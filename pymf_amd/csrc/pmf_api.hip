@@ -1481,15 +1481,17 @@ bool nnqp_use_quad(const pmf_ctx* c, int64_t nprob) {
 // What a half step's QPs need from HA = dGd alone, on stream s: the uniqueness flag and, for k_nnqp_quad,
 // B = inv(HA with its dead variables patched out).  k x k sized kernels, 36 + 2 + 18 us at k = 64.
 int nnqp_prepare(pmf_ctx* c, hipStream_t s, bool quad) {
-  PMFCHK(nnqp_warm_flag(c, s));
   if (quad) {
+    // the inverse's own pivots are the uniqueness test (k_inverse_spd_mfma's spd_flag): no k_spd_unique launch
+    if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
     if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
     double* Hp = c->dBinv + (size_t)c->KP * c->KP;
     hipLaunchKernelGGL(k_nnqp_patch_dead, dim3(1), dim3(256), 0, s, c->dGd, c->KP, c->k, Hp);
-    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
     HIPCHK(c, hipGetLastError());
+    return PMF_OK;
   }
-  return PMF_OK;
+  return nnqp_warm_flag(c, s);
 }
 
 // num_bases > 64: k_nnqp_big keeps one inverse image per workgroup in global memory

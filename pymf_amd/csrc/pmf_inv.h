@@ -48,9 +48,10 @@ __device__ __forceinline__ int tile_lds_index(int row, int col) {
 //   a_rc + pc_r pr_c,  pc_r = -a_rq (r != q), 1 - a_qq (r = q);  pr_c = a_qc / a_qq (c != q), 1 + 1 / a_qq (c = q),
 // which yields a_qc / a_qq in row q, -a_rq / a_qq in column q and 1 / a_qq in the corner.
 template <int Q>
-__device__ __forceinline__ void inv16_pivot(double (&a)[4], double* __restrict__ line /*[4][16]*/, int g, int cc) {
+__device__ __forceinline__ void inv16_pivot(double (&a)[4], double* __restrict__ line /*[4][16]*/, int g, int cc, double& pmin) {
   constexpr int QG = Q >> 2, QU = Q & 3;
   const double app = readlane_f64(a[QU], 16 * QG + Q);
+  pmin = fmin(pmin, app);                      // (the tile arrives with a unit-diagonal matrix's scaling: app IS pivot / diagonal entry)
   // every lane group stores its own row 4g + QU (straight-line code: a store under `if (g == QG)` lets the
   // compiler run the other groups' reads first); the pivot row is the line of group QG
   line[16 * g + cc] = a[QU];
@@ -68,25 +69,33 @@ __device__ __forceinline__ void inv16_pivot(double (&a)[4], double* __restrict__
   }
 }
 
-__device__ __forceinline__ void inv16_wave(const double* __restrict__ src, double* __restrict__ dst,
-                                           double* __restrict__ line /* [4][16] doubles, wave-private */, int lane) {
+// Returns the smallest pivot met (wave-uniform).
+__device__ __forceinline__ double inv16_wave(const double* __restrict__ src, double* __restrict__ dst,
+                                             double* __restrict__ line /* [4][16] doubles, wave-private */, int lane) {
   const int cc = lane & 15, g = lane >> 4;
+  double pmin = 1.0e300;
   double a[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) a[u] = src[tile_lds_index(4 * g + u, cc)];
-  inv16_pivot<0>(a, line, g, cc);   inv16_pivot<1>(a, line, g, cc);   inv16_pivot<2>(a, line, g, cc);   inv16_pivot<3>(a, line, g, cc);
-  inv16_pivot<4>(a, line, g, cc);   inv16_pivot<5>(a, line, g, cc);   inv16_pivot<6>(a, line, g, cc);   inv16_pivot<7>(a, line, g, cc);
-  inv16_pivot<8>(a, line, g, cc);   inv16_pivot<9>(a, line, g, cc);   inv16_pivot<10>(a, line, g, cc);  inv16_pivot<11>(a, line, g, cc);
-  inv16_pivot<12>(a, line, g, cc);  inv16_pivot<13>(a, line, g, cc);  inv16_pivot<14>(a, line, g, cc);  inv16_pivot<15>(a, line, g, cc);
+  inv16_pivot<0>(a, line, g, cc, pmin);   inv16_pivot<1>(a, line, g, cc, pmin);   inv16_pivot<2>(a, line, g, cc, pmin);   inv16_pivot<3>(a, line, g, cc, pmin);
+  inv16_pivot<4>(a, line, g, cc, pmin);   inv16_pivot<5>(a, line, g, cc, pmin);   inv16_pivot<6>(a, line, g, cc, pmin);   inv16_pivot<7>(a, line, g, cc, pmin);
+  inv16_pivot<8>(a, line, g, cc, pmin);   inv16_pivot<9>(a, line, g, cc, pmin);   inv16_pivot<10>(a, line, g, cc, pmin);  inv16_pivot<11>(a, line, g, cc, pmin);
+  inv16_pivot<12>(a, line, g, cc, pmin);  inv16_pivot<13>(a, line, g, cc, pmin);  inv16_pivot<14>(a, line, g, cc, pmin);  inv16_pivot<15>(a, line, g, cc, pmin);
 #pragma unroll
   for (int u = 0; u < 4; ++u) dst[tile_lds_index(4 * g + u, cc)] = a[u];
+  return pmin;
 }
 
 template <int NBLK>   // matrix order 16 NBLK (identity padded beyond k): 4 -> 64, 8 -> 128
 __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
                                                                              double* __restrict__ Ginv64,
                                                                              const int* __restrict__ stop,
-                                                                             int* __restrict__ singular = nullptr) {
+                                                                             int* __restrict__ singular = nullptr,
+                                                                             int* __restrict__ spd_flag = nullptr) {
+  // spd_flag (may be null): 1 iff every pivot of the (unpivoted) elimination stayed above 1e-8 of its diagonal entry --
+  // the blocked Gauss-Jordan meets exactly the pivots of the unblocked LDL^T (the diagonal tile of a step is the Schur
+  // complement of the blocks before it), and the unit-diagonal scaling makes them ratios already: k_spd_unique's test
+  // (pmf_nnls.h) for free where the inverse is formed anyway (NMFALS W step on k_nnqp_quad).
   if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep the inverse
   constexpr int CW = NBLK / 4;                 // waves per block row
   constexpr int KP = 16 * NBLK;
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   __shared__ __attribute__((aligned(32))) double line[64];   // inv16_wave's pivot rows, one per lane group
   __shared__ double sc[KP];                    // 1 / sqrt(g_ii)
   __shared__ int dflag;                        // = la once tile (la, la) of the look-ahead is in dsrc
+  __shared__ double pivmin[NBLK];              // smallest pivot of each step's diagonal tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bi = wv / CW, j0 = 4 * (wv % CW);
@@ -131,7 +141,8 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   if (bi == 0 && j0 == 0) {                    // D of step 0
     store_tile(dsrc, c[0]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    inv16_wave(dsrc, dD[0], line, lane);
+    const double pm = inv16_wave(dsrc, dD[0], line, lane);
+    if (lane == 0) pivmin[0] = pm;
   }
   if (bi == 0) {
 #pragma unroll
@@ -169,7 +180,8 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
     if (bi == p) {                             // these waves have no update to do in this step ...
       if (j0 == 0 && la < nsteps) {            // ... so one of them inverts the look-ahead tile
         while (__hip_atomic_load(&dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != la) __builtin_amdgcn_s_sleep(1);
-        inv16_wave(dsrc, dD[la & 1], line, lane);
+        const double pm = inv16_wave(dsrc, dD[la & 1], line, lane);
+        if (lane == 0) pivmin[la] = pm;
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) c[t] = (j0 + t == p) ? D : load_tile(pR[j0 + t]);   // new row panel
@@ -216,6 +228,11 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
       if (row < ld && col < ld) Ginv64[(int64_t)row * ld + col] = v;
     }
   if (singular != nullptr && __ballot(bad) != 0ull && lane == 0) *singular = 1;
+  if (spd_flag != nullptr && tid == 0) {       // (every inversion ended before the last step's first barrier)
+    double pm = 1.0e300;
+    for (int q = 0; q < nsteps; ++q) pm = fmin(pm, pivmin[q]);
+    *spd_flag = (pm > 1e-8) ? 1 : 0;
+  }
 }
 
 // ---- the k x n sized float64 products of the SNMF W step / Gram-space loop on the float64 MFMA -------

@@ -52,11 +52,18 @@ __device__ __forceinline__ double spd_readlane_f64(double v, int srclane) {
 }
 __global__ __launch_bounds__(64) void k_spd_unique(const double* __restrict__ Hd, int KP, int k,
                                                    int* __restrict__ flag) {
+  // Step j needs row j of the running matrix in every lane.  The matrix is symmetric, so entry (j, c) is also entry
+  // (c, j) = register j of lane c: every lane puts its register j into an LDS line (ONE store) and reads the line back
+  // two entries at a time (all lanes the same address: a broadcast) -- (64 - j) / 2 loads instead of the
+  // 2 (64 - j) v_readlane of a row broadcast entry by entry (36 us -> see profiles/r03_experiments.md).
+  __shared__ __attribute__((aligned(16))) double line[2][64];
+  __shared__ double d0s[64];
   const int t = threadIdx.x;
   double A[64];
 #pragma unroll
-  for (int c = 0; c < 64; ++c) A[c] = (t < k && c < k) ? Hd[(int64_t)t * KP + c] : (t == c ? 1.0 : 0.0);
+  for (int c = 0; c < 64; ++c) A[c] = (t < k && c < k) ? Hd[(int64_t)c * KP + t] : (t == c ? 1.0 : 0.0);   // (symmetric: the coalesced way round)
   const double d0 = t < k ? Hd[(int64_t)t * KP + t] : 1.0;
+  d0s[t] = d0;
   double dmax = t < k ? d0 : 0.0;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
@@ -66,15 +73,23 @@ __global__ __launch_bounds__(64) void k_spd_unique(const double* __restrict__ Hd
   spd_static_for<0, 64>([&](auto jc_) {
     constexpr int j = decltype(jc_)::value;
     if (j < k && ok && ((livem >> j) & 1ull)) {            // uniform; a dead basis is skipped
-      const double piv = spd_readlane_f64(A[j], j);
-      const double d0j = spd_readlane_f64(d0, j);
+      double* ln = line[j & 1];
+      ln[t] = A[j];                                          // column j = row j
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double piv = spd_readlane_f64(A[j], j);          // (ahead of the line: its reciprocal is under way while the line lands)
+      const double d0j = d0s[j];
       if (!(piv > 1e-8 * d0j)) {
         ok = 0;
       } else {
         const double l = (t > j && live_t) ? A[j] * pmf_rcp_f64(piv) : 0.0;
-        spd_static_for<j, 64>([&](auto cc_) {
-          constexpr int c = decltype(cc_)::value;
-          A[c] = fma(-l, spd_readlane_f64(A[c], j), A[c]);
+        constexpr int c0 = j & ~1;
+        spd_static_for<c0 / 2, 32>([&](auto cc_) {
+          constexpr int c = 2 * decltype(cc_)::value;
+          const double2 r = *reinterpret_cast<const double2*>(ln + c);
+          if (c >= j) A[c] = fma(-l, r.x, A[c]);
+          A[c + 1] = fma(-l, r.y, A[c + 1]);
         });
       }
     }

@@ -104,14 +104,16 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
 // Hp = HA with every DEAD variable (zero row and column: a basis that has died out) replaced by the identity, so
 // that B = inv(Hp) exists; such variables never become passive (k_nnqp rejects them when it borders).
 __global__ __launch_bounds__(256) void k_nnqp_patch_dead(const double* __restrict__ Hd, int KP, int k, double* __restrict__ Hp) {
-  __shared__ double dmax_s;
-  if (threadIdx.x == 0) {
-    double dm = 0.0;
-    for (int t = 0; t < k; ++t) dm = fmax(dm, Hd[(int64_t)t * KP + t]);
-    dmax_s = dm;
-  }
+  __shared__ double dg[256];               // (one thread walking the k diagonal entries one after the other took 12.5 us)
+  double dm = 0.0;
+  for (int t = threadIdx.x; t < k; t += 256) dm = fmax(dm, Hd[(int64_t)t * KP + t]);
+  dg[threadIdx.x] = dm;
   __syncthreads();
-  const double dead_below = 1e-12 * dmax_s;
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) dg[threadIdx.x] = fmax(dg[threadIdx.x], dg[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const double dead_below = 1e-12 * dg[0];
   for (int e = threadIdx.x; e < KP * KP; e += 256) {
     const int c = e / KP, t = e % KP;
     const bool dc = c >= k || !(Hd[(int64_t)c * KP + c] > dead_below), dt = t >= k || !(Hd[(int64_t)t * KP + t] > dead_below);
