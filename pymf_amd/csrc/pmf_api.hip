@@ -105,6 +105,9 @@ struct pmf_ctx {
   int opt_nndsvd_topk = -1;     // pmf_set_option("nndsvd_topk"): -1 by size, 1 the filtered subspace iteration, 0 full Jacobi
   int nndsvd_products = 0;      // products with the Gram matrix the last top-k solve took
   int opt_colgemm_stream = 1;   // pmf_set_option("colgemm_stream"): W^T V partials on k_colgemm_stream where it applies
+  int opt_resid_resident = 1;   // residual pass with H resident in LDS (k_resid_res) where it fits
+  int resid_parts = 0;          // float64 partials the last residual pass left in dPart
+  int64_t dpart_cap = 0;        // doubles dPart holds
   int opt_rowgemm_stream = 1;   // pmf_set_option("rowgemm_stream"): plain products with a long contraction on k_rowgemm_stream
   int opt_nnqp_quad = 1;        // pmf_set_option("nnqp_quad"): num_bases <= 64 on the sixteen-lanes-per-problem kernel
   double *dInvA = nullptr, *dInvB = nullptr;   // k_inverse_spd_big: the two images of the elimination, [KP][KP]
@@ -808,8 +811,26 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
 }
 
 // ---- NMF (multiplicative update) ---------------------------------------------------------
+// Leaves c->resid_parts float64 partials in c->dPart.
 template <int NT, bool RNMF>
 int launch_resid_t(pmf_ctx* c, float lamb, const float* V, const float* W, int64_t rows_p) {
+  const int ntiles = (int)(rows_p / 64);
+  const size_t res_smem = resid_res_smem_bytes<NT>(c->np);
+  if (c->opt_resid_resident && res_smem <= 150 * 1024 && ntiles >= 64) {
+    // H resident in LDS, persistent workgroups (a fixed count: the partials' grouping must not depend on the part)
+    static bool res_attr_dev[PMF_MAX_DEVICES] = {};
+    bool& res_attr = res_attr_dev[pmf_current_device()];
+    if (!res_attr) {
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resid_res<NT, RNMF>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      res_attr = true;
+    }
+    hipLaunchKernelGGL((k_resid_res<NT, RNMF>), dim3((unsigned)std::min(ntiles, 512)), dim3(256), res_smem, c->stream, V,
+                       (int64_t)c->np, c->np, W, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart, ntiles);
+    HIPCHK(c, hipGetLastError());
+    c->resid_parts = std::min(ntiles, 512);
+    return PMF_OK;
+  }
   const size_t smem = resid_smem_bytes<NT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[pmf_current_device()];
@@ -818,9 +839,10 @@ int launch_resid_t(pmf_ctx* c, float lamb, const float* V, const float* W, int64
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_resid<NT, RNMF>), dim3((unsigned)(rows_p / 64)), dim3(256), smem, c->stream, V,
+  hipLaunchKernelGGL((k_resid<NT, RNMF>), dim3((unsigned)ntiles), dim3(256), smem, c->stream, V,
                      (int64_t)c->np, c->np, W, c->dH, (int64_t)c->np, lamb, c->dD, c->dPart);
   HIPCHK(c, hipGetLastError());
+  c->resid_parts = ntiles;
   return PMF_OK;
 }
 
@@ -863,7 +885,7 @@ int rnmf_update_s(pmf_ctx* c) {   // rnmf.py:96-98; also leaves sum((V - W H)^2)
     PMFCHK(resid_bigk(c, true, c->dScal + 4));
   } else {
     PMFCHK(launch_resid(c, true, lamb));
-    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal + 4);
+    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, c->resid_parts, c->dScal + 4);
   }
   HIPCHK(c, hipGetLastError());
   PMFCHK(allreduce_sum(c, c->dScal + 4, 1, true));
@@ -1579,7 +1601,7 @@ int frobenius_direct(pmf_ctx* c, double* out) {
   if (c->v_csr) return fail(c, PMF_EINVAL, "frobenius on CSR data: the reference returns its -123456 sentinel (nmf.py:109-112)");
   const int nb = (int)(c->mp / 64);
   PMFCHK(launch_resid(c, false, 0.f));
-  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
+  hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, c->resid_parts, c->dScal);
   HIPCHK(c, hipGetLastError());
   PMFCHK(allreduce_sum(c, c->dScal, 1, true));
   double ss = 0.0;
@@ -1786,6 +1808,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   if (!c) return fail(nullptr, PMF_ENOMEM, "host allocation failed");
   c->algo = algo; c->m = m_local; c->n = n; c->k = k; c->device = device; c->rank = rank; c->nranks = nranks;
   if (const char* e = std::getenv("PMF_COLGEMM_STREAM")) c->opt_colgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("colgemm_stream")
+  if (const char* e = std::getenv("PMF_RESID_RESIDENT")) c->opt_resid_resident = std::atoi(e) != 0;
   if (const char* e = std::getenv("PMF_ROWGEMM_STREAM")) c->opt_rowgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("rowgemm_stream")
   if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
@@ -1846,7 +1869,8 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
       PMFCHK(dalloc(c, &c->dW1, (size_t)std::max<int64_t>(c->mp, c->np) * c->KP));
       PMFCHK(dalloc(c, &c->dW2, (size_t)c->mp * c->KP));
     }
-    PMFCHK(dalloc(c, &c->dPart, (size_t)std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2)));
+    c->dpart_cap = std::max<int64_t>(std::max<int64_t>(c->mp / 64, 1024), c->np / 8 + 2);
+    PMFCHK(dalloc(c, &c->dPart, (size_t)c->dpart_cap));
     PMFCHK(dalloc(c, &c->dScal, 8));
     PMFCHK(dalloc(c, &c->dGpart, (size_t)PMF_HGRAM_MAX_WGS * c->KP * c->KP));
     PMFCHK(dalloc(c, &c->dT1part, (size_t)2 * PMF_HGRAM_MAX_WGS));
@@ -2313,7 +2337,7 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
   const int first = c->st_tiles == 0;
   if (c->st_flags & PMF_STREAM_RESID) {
     PMFCHK(launch_resid(c, false, 0.f, T, Wt, rows_p));
-    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, (int)(rows_p / 64), c->dScal + 5);
+    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, c->resid_parts, c->dScal + 5);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_accum_f64, dim3(1), dim3(64), 0, c->stream, c->dStAcc + 1, c->dScal + 5, first);
     HIPCHK(c, hipGetLastError());

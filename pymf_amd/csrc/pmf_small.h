@@ -465,7 +465,14 @@ __global__ void k_sum_pairs_f64(const double* __restrict__ part, int n, double* 
 __global__ void k_sum_f64(const double* __restrict__ part, int n, double* __restrict__ out) {
   __shared__ double ws[4];
   double s = 0.0;
-  for (int q = threadIdx.x; q < n; q += 256) s += part[q];
+  // eight requests in flight, added in the order of the plain loop (one load per round trip took 26 us for 16 384 partials)
+  for (int q = threadIdx.x; q < n; q += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (q + 256 * u < n) ? part[q + 256 * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   s = wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
   __syncthreads();

@@ -838,6 +838,84 @@ __global__ __launch_bounds__(256) void k_resid(const float* __restrict__ V, int6
   if (tid == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// The same pass with H RESIDENT in LDS ([KP][np + 16] floats: up to 150 KiB) and persistent workgroups: k_resid stages
+// the H panels per 64-row tile (as many bytes of H from L2 as of V from HBM at cfg4 size, one barrier per 64 MFMAs); here
+// H is staged once per workgroup, the waves run free over their tiles, the V values of the next panel are requested before
+// the current panel's MFMAs.  Same arithmetic per element; one float64 partial per workgroup (its waves' sums over their
+// tiles, added in wave order): part[blockIdx.x] -- the grid is a fixed 512, not a property of the device.
+template <int NT>
+constexpr size_t resid_res_smem_bytes(int np) { return (size_t)16 * NT * (np + 16) * sizeof(float); }
+
+template <int NT, bool RNMF>
+__global__ __launch_bounds__(256, 2) void k_resid_res(const float* __restrict__ V, int64_t ldv, int np,
+                                                      const float* __restrict__ W,
+                                                      const float* __restrict__ H, int64_t ldh, float lamb,
+                                                      float* __restrict__ D, double* __restrict__ part, int ntiles) {
+  constexpr int KP = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) float hsm[];     // [KP][np + 16]
+  const int HLD = np + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  for (int id = tid; id < KP * (np / 4); id += 256) {
+    const int kk = id / (np / 4), c4 = id % (np / 4);
+    *reinterpret_cast<f32x4*>(hsm + kk * HLD + 4 * c4) = *reinterpret_cast<const f32x4*>(H + (int64_t)kk * ldh + 4 * c4);
+  }
+  __syncthreads();
+  __shared__ double wsum[4];
+  double wtot = 0.0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * 64 + 16 * wv;
+    float af[4 * NT];                                   // A[i = row][k = 4s + kq]
+#pragma unroll
+    for (int s = 0; s < 4 * NT; ++s) af[s] = W[(row0 + i) * KP + 4 * s + kq];
+    const float* Vr = V + (row0 + 4 * kq) * ldv + 4 * i;
+    float* Dr = RNMF ? D + (row0 + 4 * kq) * ldv + 4 * i : nullptr;
+    f32x4 vn[4];                                        // vn[j] = V[row 4kq + j][cp + 4i .. +3] of the NEXT panel
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vn[j] = *reinterpret_cast<const f32x4*>(Vr + (int64_t)j * ldv);
+    double tot = 0.0;
+    for (int cp = 0; cp < np; cp += 64) {
+      f32x4 vv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vv[j] = vn[j];
+      const int cn = cp + 64 < np ? cp + 64 : cp;       // (the last panel re-requests itself)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vn[j] = *reinterpret_cast<const f32x4*>(Vr + (int64_t)j * ldv + cn);
+      f32x4 acc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* hp = hsm + cp + 4 * i;
+#pragma unroll
+      for (int s = 0; s < 4 * NT; ++s) {
+        const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + (4 * s + kq) * HLD);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = mfma16(af[s], hq[e], acc[e]);
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 dq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = vv[j][e];
+          const float r = v - acc[e][j];
+          ss += r * r;
+          float sv = 0.f;                             // soft thresholding, rnmf.py:75-79
+          if (r > lamb) sv = r - lamb;
+          else if (r < -lamb) sv = r + lamb;
+          dq[e] = sv - v;
+        }
+        if (RNMF) *reinterpret_cast<f32x4*>(Dr + (int64_t)j * ldv + cp) = dq;
+      }
+      tot += (double)ss;
+    }
+    wtot += wave_sum_f64(tot);
+  }
+  if (lane == 0) wsum[wv] = wtot;
+  __syncthreads();
+  if (tid == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // ---- num_bases > 128 (NMF): the bases are handled in blocks of 128 by the NT = 8 kernels above ----
 // out[r * out_ld + c] = sum over slabs of slab[s][r][c]  (r < rows, c < ncols; slab rows have src_ld floats)
 // One block (1024 threads) = 64 float4 of the [rows][ncols] result; wave w sums slabs w, w + 16, ... in float64 (coalesced

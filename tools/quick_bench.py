@@ -9,6 +9,9 @@ ctx = _lib.Context(algo, m, n, k)
 if os.environ.get("QB_FORCE_TILED"):
     ctx.set_option("force_tiled", 1)          # the any-shape two-pass kernels on a one-pass kernel's shape
 ctx.fill_v_uniform(1234); ctx.fill_w_uniform(42); ctx.fill_h_uniform(43)
+if algo == _lib.ALGO_RNMF:
+    ctx.set_lambda(0.7, 0.0)
+    ctx.rnmf_update_s()                        # rnmf.py:94-98: S exists before the first W step
 print("path", ctx.path_name)
 ctx.factorize(3, compute_err=False)
 for ce in (False, True):
