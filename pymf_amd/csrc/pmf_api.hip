@@ -281,14 +281,16 @@ int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, 
 // Partials of (W^T X | W^T W) over row chunks into c->dSlab: X [rows_p][xn] (ldx), W [rows_p][.] (ldw), chunks of rpc rows.
 // k_colgemm_stream where it applies (NT = 4, or NT = 8 without S; rpc a multiple of its stage), else k_colgemm.
 template <int NT, bool WITH_S>
-int launch_colgemm(pmf_ctx* c, const float* X, int64_t ldx, int xn, const float* W, int64_t ldw, int64_t rows_p, int rpc, int nch) {
+int launch_colgemm(pmf_ctx* c, const float* X, int64_t ldx, int xn, const float* W, int64_t ldw, int64_t rows_p, int rpc, int nch,
+                   float* slab = nullptr) {
+  if (!slab) slab = c->dSlab;
   const dim3 grid((unsigned)nch, X ? (unsigned)((xn + 255) / 256) : 1u);
   constexpr int SR = NT == 4 ? 64 : 32;
   const bool stream_ok = c->opt_colgemm_stream && X != nullptr && rpc % SR == 0 && rows_p % SR == 0;
   const size_t smem = (size_t)2 * SR * (16 * NT + 4) * sizeof(float);
   if constexpr (NT == 4 || (NT == 8 && !WITH_S)) {
     if (stream_ok) {
-      hipLaunchKernelGGL((k_colgemm_stream<NT, WITH_S>), grid, dim3(256), smem, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab,
+      hipLaunchKernelGGL((k_colgemm_stream<NT, WITH_S>), grid, dim3(256), smem, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, slab,
                          (int64_t)xn + 16 * NT, 0);
       HIPCHK(c, hipGetLastError());
       return PMF_OK;
@@ -298,15 +300,15 @@ int launch_colgemm(pmf_ctx* c, const float* X, int64_t ldx, int xn, const float*
     // 64 < num_bases <= 128: with the S tiles k_colgemm<8> holds 192 accumulator registers; the stream kernel forms P and,
     // as a second product with W in V's place, S -- into the same slabs (columns [xn, xn + 128))
     if (stream_ok) {
-      hipLaunchKernelGGL((k_colgemm_stream<8, false>), grid, dim3(256), smem, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab,
+      hipLaunchKernelGGL((k_colgemm_stream<8, false>), grid, dim3(256), smem, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, slab,
                          (int64_t)xn + 128, 0);
       hipLaunchKernelGGL((k_colgemm_stream<8, false>), dim3((unsigned)nch, 1u), dim3(256), smem, c->stream, W, ldw, 128, W, ldw, rows_p, rpc,
-                         c->dSlab, (int64_t)xn + 128, xn);
+                         slab, (int64_t)xn + 128, xn);
       HIPCHK(c, hipGetLastError());
       return PMF_OK;
     }
   }
-  hipLaunchKernelGGL((k_colgemm<NT, WITH_S>), grid, dim3(256), 0, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, c->dSlab);
+  hipLaunchKernelGGL((k_colgemm<NT, WITH_S>), grid, dim3(256), 0, c->stream, X, ldx, xn, W, ldw, rows_p, rpc, slab);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -477,16 +479,11 @@ int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
   const int np = c->np;
   for (int c0 = 0; c0 < np;) {
     const int wdt = (np - c0 >= 128) ? 128 : 64;
-    dim3 grid((unsigned)gchunks, (unsigned)((np + 255) / 256));
-    if (wdt == 128)
-      hipLaunchKernelGGL((k_colgemm<8, false>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
-                         (int64_t)np, c->mp, rpc, slab);
-    else
-      hipLaunchKernelGGL((k_colgemm<4, false>), grid, dim3(256), 0, c->stream, c->dV, (int64_t)np, np, c->dV + c0,
-                         (int64_t)np, c->mp, rpc, slab);
-    HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((wdt * np + 255) / 256)), dim3(256), 0, c->stream, slab,
-                       gchunks, wdt, np, c0, Ad, np);
+    if (wdt == 128) PMFCHK((launch_colgemm<8, false>(c, c->dV, np, np, c->dV + c0, np, c->mp, rpc, gchunks, slab)));
+    else PMFCHK((launch_colgemm<4, false>(c, c->dV, np, np, c->dV + c0, np, c->mp, rpc, gchunks, slab)));
+    // (k_gram_reduce: one thread per element walking the slabs one load at a time -- 0.2 ms per pass at 512 slabs)
+    hipLaunchKernelGGL((k_reduce_slabs_block<double>), dim3((unsigned)(((int64_t)wdt * np / 4 + 63) / 64)), dim3(1024), 0, c->stream, slab,
+                       gchunks, wdt, np + wdt, np, Ad + (size_t)c0 * np, (int64_t)np, 0);
     HIPCHK(c, hipGetLastError());
     c0 += wdt;
   }
@@ -739,7 +736,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   int *order = nullptr, *info = nullptr, *wmode = nullptr;
   const int64_t blocks16 = c->mp / 16;
   int gchunks = (int)std::min<int64_t>(512, blocks16);
-  const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;
+  const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;     // (small chunks on purpose: fp32 sums inside a chunk, float64 across)
   gchunks = (int)((c->mp + rpc - 1) / rpc);
   const int kp16 = (int)round_up(c->k, 16);
   const bool can_jacobi = n <= PMF_NNDSVD_MAX_N;
@@ -1326,7 +1323,7 @@ int ensure_vgram(pmf_ctx* c) {
     DevTemps tmp;
     const int64_t blocks16 = c->mp / 16;
     int gchunks = (int)std::min<int64_t>(512, blocks16);
-    const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;
+    const int rpc = (int)((blocks16 + gchunks - 1) / gchunks) * 16;   // (small chunks on purpose: fp32 sums inside a chunk, float64 across)
     gchunks = (int)((c->mp + rpc - 1) / rpc);
     float* slab = nullptr;
     PMFCHK(talloc(c, tmp, &slab, (size_t)gchunks * 128 * (np + 128)));
