@@ -477,16 +477,20 @@ int talloc(pmf_ctx* c, DevTemps& t, T** out, size_t count) {
 // slab: gchunks * 128 * (np + 128) floats of scratch; rpc rows per chunk.
 int gram_vtv(pmf_ctx* c, double* Ad, float* slab, int gchunks, int rpc) {
   const int np = c->np;
+  // block row c0 against the columns from c0 on only (the matrix is symmetric: half the products), mirrored at the end
   for (int c0 = 0; c0 < np;) {
     const int wdt = (np - c0 >= 128) ? 128 : 64;
-    if (wdt == 128) PMFCHK((launch_colgemm<8, false>(c, c->dV, np, np, c->dV + c0, np, c->mp, rpc, gchunks, slab)));
-    else PMFCHK((launch_colgemm<4, false>(c, c->dV, np, np, c->dV + c0, np, c->mp, rpc, gchunks, slab)));
+    const int xn = np - c0;
+    if (wdt == 128) PMFCHK((launch_colgemm<8, false>(c, c->dV + c0, np, xn, c->dV + c0, np, c->mp, rpc, gchunks, slab)));
+    else PMFCHK((launch_colgemm<4, false>(c, c->dV + c0, np, xn, c->dV + c0, np, c->mp, rpc, gchunks, slab)));
     // (k_gram_reduce: one thread per element walking the slabs one load at a time -- 0.2 ms per pass at 512 slabs)
-    hipLaunchKernelGGL((k_reduce_slabs_block<double>), dim3((unsigned)(((int64_t)wdt * np / 4 + 63) / 64)), dim3(1024), 0, c->stream, slab,
-                       gchunks, wdt, np + wdt, np, Ad + (size_t)c0 * np, (int64_t)np, 0);
+    hipLaunchKernelGGL((k_reduce_slabs_block<double>), dim3((unsigned)(((int64_t)wdt * xn / 4 + 63) / 64)), dim3(1024), 0, c->stream, slab,
+                       gchunks, wdt, xn + wdt, xn, Ad + (size_t)c0 * np + c0, (int64_t)np, 0);
     HIPCHK(c, hipGetLastError());
     c0 += wdt;
   }
+  hipLaunchKernelGGL(k_mirror_upper_f64, dim3((unsigned)(((int64_t)np * np + 255) / 256)), dim3(256), 0, c->stream, Ad, np);
+  HIPCHK(c, hipGetLastError());
   return allreduce_sum(c, Ad, (size_t)np * np, true);
 }
 

@@ -28,6 +28,14 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ s
   Ad[(int64_t)(c0 + r) * ld + c] = s;
 }
 
+// A[r][c] = A[c][r] for r > c (n x n, leading dimension n): the Gram passes form the upper block triangle only
+__global__ __launch_bounds__(256) void k_mirror_upper_f64(double* __restrict__ A, int n) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (int64_t)n * n) return;
+  const int r = (int)(q / n), c = (int)(q % n);
+  if (r > c) A[q] = A[(int64_t)c * n + r];
+}
+
 // Symmetric eigen-decomposition of the nj x nj (nj even, <= PMF_NNDSVD_MAX_N) matrix A (leading dimension ld):
 // cyclic two-sided Jacobi in the round-robin parallel order, float64.  Every step rotates nj/2
 // disjoint (p, q) pairs at once: A <- J^T A J decomposes into independent 2 x 2 blocks
