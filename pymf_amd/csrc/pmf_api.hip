@@ -2448,6 +2448,15 @@ int pmf_nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   return nndsvd_init(c, rank_found);
 }
 
+#ifdef PMF_QUAD_COUNT
+extern "C" int pmf_debug_quad_counts(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_cnt), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_quad_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_quad_cnt), z, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_quad_t), z, 8 * sizeof(unsigned long long)); }
+  return 0;
+}
+#endif
+
 int pmf_last_loop_ms(pmf_ctx* c, double* ms) {
   if (!c || !ms) return PMF_EINVAL;
   *ms = c->last_loop_ms;

@@ -121,6 +121,16 @@ __global__ __launch_bounds__(256) void k_nnqp_patch_dead(const double* __restric
   }
 }
 
+#ifdef PMF_QUAD_COUNT
+#define PMF_QSTAMP(idx) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) atomicAdd(&g_quad_t[idx], t_ - tq_); tq_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ unsigned long long g_quad_t[8];   // ticks per section: lists, y product, gather, LDL^T, solves, z product, decision
+#else
+#define PMF_QSTAMP(idx) do { } while (0)
+#endif
+#ifdef PMF_QUAD_COUNT   // diagnostic build only: wave tasks, passes, sum of the largest system per pass, of the longest product, histogram of sizes / 4
+__device__ unsigned long long g_quad_cnt[16];
+#endif
+
 __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__ Horig, const double* __restrict__ Hd,
                                                       const double* __restrict__ Bd,
                                                       int KP, int k, const float* __restrict__ F, int64_t f_sk,
@@ -181,6 +191,9 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
 
     for (int pass = 0; pass < 8 * 64 + 16; ++pass) {
       if (__ballot(!done) == 0ull) break;
+#ifdef PMF_QUAD_COUNT
+      unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
       // ---- lists of P and N (ascending), the form of the solve ----
       // The system's unknowns sit at positions shift .. 31 of a 32-slot frame (shift = 32 - ns, identity in front):
       // the factorisation can then START at the first position any of the wave's problems uses.
@@ -195,6 +208,15 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
         ntmax = max(ntmax, __shfl_xor(ntmax, o, 64));
       }
       const int jstart = __builtin_amdgcn_readfirstlane(QNS - nsmax);
+#ifdef PMF_QUAD_COUNT
+      if (lane == 0) {
+        if (pass == 0) atomicAdd(&g_quad_cnt[0], 1ull);
+        atomicAdd(&g_quad_cnt[1], 1ull);
+        atomicAdd(&g_quad_cnt[2], (unsigned long long)__builtin_amdgcn_readfirstlane(nsmax));
+        atomicAdd(&g_quad_cnt[3], (unsigned long long)__builtin_amdgcn_readfirstlane(ntmax));
+        atomicAdd(&g_quad_cnt[4 + min(__builtin_amdgcn_readfirstlane(nsmax) / 4, 8)], 1ull);
+      }
+#endif
       ntmax = __builtin_amdgcn_readfirstlane(ntmax);
       {
         const int offP = comp ? 0 : shift, offN = comp ? shift : 0;   // the S list right-aligned at byte 32, the other at 0
@@ -223,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
         pcl[d] = (sld & 0x20202020u) | ((sld & 0x0f0f0f0fu) << 1) | ((sld >> 4) & 0x01010101u);   // the offset above, per byte
       }
 
+      PMF_QSTAMP(0);
       // ---- complement form: y = B (f on P), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
       double y[4] = {0.0, 0.0, 0.0, 0.0};
       {
@@ -255,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+      PMF_QSTAMP(1);
       // ---- gather M[S,S] into positions shift .. 31 (identity in front) and the right-hand side ----
       double Lr[48], dv[2], bv[2];
       static_for<0, 2>([&](auto mc_) {
@@ -273,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
           Lr[qoff(m) + c] = (live_i && c >= shift) ? val : (c == i ? 1.0 : 0.0);
         });
       });
+      PMF_QSTAMP(2);
       // ---- LDL^T, right-looking; row i in lane i % 16, every index a constant of the program text ----
       // The reciprocal of step j + 1's pivot is started as soon as column j + 1 has its step-j update (first in
       // the loop over c): its latency -- v_rcp_f64 and two Newton steps -- runs under the rest of step j's updates.
@@ -306,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
           static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; Lr[qoff(m) + j] = lij[m]; });
         }
       });
+      PMF_QSTAMP(3);
       // ---- forward: L z = b ----
       static_for<0, QNS>([&](auto jc_) {
         constexpr int j = decltype(jc_)::value;
@@ -335,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+      PMF_QSTAMP(4);
       // ---- z = M[:, S] mu over this lane's 4 variables ----
       double z[4] = {0.0, 0.0, 0.0, 0.0};
       for (int p0 = jstart & ~3; p0 < QNS; p0 += 4) {     // four positions at a time, as above
@@ -354,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
           z[2] = fma(row[e][32], mu[e], z[2]); z[3] = fma(row[e][33], mu[e], z[3]);
         }
       }
+      PMF_QSTAMP(5);
       // ---- candidate solution s and dual w per variable ----
       //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)
       //   primal:     P: s = mu(t), w = 0;   N: s = 0, w = f - z
@@ -407,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
         }
         (void)ninf_l; (void)top;
       }
+      PMF_QSTAMP(6);
       __builtin_amdgcn_wave_barrier();
     }
     if (valid) {
