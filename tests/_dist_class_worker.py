@@ -75,6 +75,8 @@ class FakeContext(object):
                 self.update_h()
             if compute_err:
                 ferr[i] = self.frobenius()
+                if i > 1 and abs(ferr[i] - ferr[i - 1]) / self.n < conv_eps:      # nmf.py:134-139, 198-202
+                    return ferr[:niter], i + 1, i
         return (ferr[:niter] if compute_err else None), niter, -1
 
     def close(self):
@@ -122,6 +124,23 @@ def main():
     check("NMF hooks W", gather_rows(mdl.W), ref.W, tolx)
     check("NMF hooks H", mdl.H, ref.H, tolx)
     assert abs(mdl.frobenius_norm() - ref.frobenius_norm()) <= tolf * ref.frobenius_norm()
+
+    # ---- rank skew and the early exit (nmf.py:198-202): the last rank arrives late at every collective of the loop, the
+    # data are exactly rank 1 so the fit becomes stationary within a few iterations -- every rank must leave the loop at
+    # the SAME iteration (the decision is taken on all-reduced numbers only), none may be left waiting in a collective ----
+    import time
+    rs1 = np.random.RandomState(11)
+    V1 = np.outer(rs1.random_sample(m) + 0.5, rs1.random_sample(n) + 0.5).astype(np.float32)
+    if w.rank == w.size - 1:
+        time.sleep(1.0)
+    np.random.seed(300 + w.rank)
+    e = pymf_amd.NMF(V1[lo:hi], num_bases=1)          # one basis on rank-1 data: exact after the first iteration
+    e.factorize(niter=300)
+    lens = [int(np.frombuffer(b, dtype=np.int64)[0]) for b in dist.allgather_bytes(np.array([len(e.ferr)], dtype=np.int64).tobytes())]
+    print("rank %d early exit after %d of 300 iterations (all ranks: %s) ferr %s" % (w.rank, len(e.ferr), lens, e.ferr[:6]))
+    assert len(set(lens)) == 1 and lens[0] < 300, lens
+    fs = dist.allgather_bytes(np.ascontiguousarray(e.ferr, dtype=np.float64).tobytes())
+    assert all(f == fs[0] for f in fs), "ferr must be bit-identical on every rank"
 
     if not FAKE:
         # ---- SNMF (mixed-sign data) ----
