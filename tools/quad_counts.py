@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic (build_ab/lib_quadcount.so, -DPMF_QUAD_COUNT): passes and system sizes of k_nnqp_quad at cfg3, per iteration."""
+"""Diagnostic: passes, system sizes and section ticks of k_nnqp_quad at cfg3, per iteration.  Needs a counting build:
+  (cd pymf_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 \
+      -DPMF_QUAD_COUNT pmf_api.hip -o ../../build_ab/lib_quadcount.so -lrccl)
+  PMF_LIB=build_ab/lib_quadcount.so python tools/quad_counts.py"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
