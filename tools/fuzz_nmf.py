@@ -59,7 +59,10 @@ for trial in range(ntrial):
                     # noise in ferr (W, H are stored in float32): where that noise exceeds the threshold the decision
                     # cannot be reproduced digit for digit and a different stopping iteration is a NOTE; where the
                     # threshold is well above the noise a difference is a FAILURE.
-                    scale = max(float(np.max(np.abs(a.ferr))) if len(a.ferr) else 0.0, float(np.max(np.abs(o.ferr))) if len(o.ferr) else 0.0)
+                    # (an exact fit -- k >= n, rank-deficient data -- leaves a residual of float32 rounding of W, H: its size is
+                    # eps32 ||V||, whatever ferr itself has shrunk to)
+                    scale = max(float(np.max(np.abs(a.ferr))) if len(a.ferr) else 0.0, float(np.max(np.abs(o.ferr))) if len(o.ferr) else 0.0,
+                                float(np.linalg.norm(np.asarray(Vo, dtype=np.float64))))
                     noise = 16.0 * float(np.finfo(np.float32).eps) * scale
                     if 1e-8 * n > noise:
                         bad += 1
