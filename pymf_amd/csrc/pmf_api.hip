@@ -236,8 +236,21 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
       // long contraction: A straight into registers, requests interleaved with the MFMAs (pmf_tiled.h)
       constexpr int RB = NT <= 4 ? 4 : 2;
       const int ntiles = (int)(rows_p / (16 * RB));
-      hipLaunchKernelGGL((k_rowgemm_stream<NT, RB, EPI>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256),
-                         (size_t)2 * 16 * NT * 64 * sizeof(float), c->stream, A, lda, kdimA, B, ldb, W, G, C, ldc, lamb, mvalid,
+      // persistent workgroups, two per CU of a 256-CU part (a fixed count; at 128 bases with the Den product one group each)
+      const int ngroups = (ntiles + 3) / 4;
+      const bool single = (EPI != EPI_STORE) && NT > 4;
+      const unsigned grid = (unsigned)(single ? ngroups : std::min(ngroups, 512));
+      const size_t ssm = rowgemm_stream_smem_bytes<NT, EPI, false>();
+      if (ssm > 64 * 1024) {
+        static bool sattr_dev[PMF_MAX_DEVICES] = {};
+        bool& sattr = sattr_dev[pmf_current_device()];
+        if (!sattr) {
+          HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowgemm_stream<NT, RB, EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssm));
+          sattr = true;
+        }
+      }
+      hipLaunchKernelGGL((k_rowgemm_stream<NT, RB, EPI>), dim3(grid), dim3(256), ssm, c->stream, A, lda, kdimA, B, ldb, W, G, C, ldc, lamb, mvalid,
                          c->k, ntiles, (int64_t)(16 * NT));
       HIPCHK(c, hipGetLastError());
       return PMF_OK;
@@ -909,7 +922,7 @@ int bigk_update_w_rows(pmf_ctx* c, const float* X, float* Wr, float* W1r, float*
   if (c->opt_rowgemm_stream && c->np % 128 == 0) {
     // Num = V H_b^T with the update rule as its epilogue: block b of W is rewritten in place (V H^T does not read W)
     const int ntiles = (int)(rows_p / 32);
-    const dim3 grid((unsigned)((ntiles + 3) / 4));
+    const dim3 grid((unsigned)std::min((ntiles + 3) / 4, 512));     // persistent workgroups (k_rowgemm_stream)
     const size_t smem = (size_t)2 * 128 * 64 * sizeof(float);
     for (int b = 0; b < c->nb; ++b) {
       const float* Hb = c->dH + (size_t)b * 128 * c->np;

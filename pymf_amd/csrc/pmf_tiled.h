@@ -266,24 +266,29 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
   static_assert(EPI == EPI_STORE || EPI == EPI_NMF_W || EPI == EPI_BNMF_W || EPI == EPI_RNMF_W, "k_rowgemm_stream: epilogue");
   constexpr int KP = 16 * NT;
   constexpr int WR = 16 * RB;                          // rows per wave
+  constexpr bool DENPROD = EPI != EPI_STORE && !DENBUF;   // Den = W_tile G formed here: G lives in LDS behind the B buffers
+  constexpr int GPAN = (KP + 63) / 64;                 // 64-column panels of G
+  constexpr int GCH = KP < 64 ? KP / 4 : 16;           // 16-byte chunks per row of a panel
+  // up to 64 bases G has a region of its own (staged once); at 128 bases that would be 128 KiB of LDS -- one workgroup per
+  // CU --, so G takes the B buffers' place after the product and the launch gives every workgroup ONE group of tiles
+  constexpr bool GSEP = NT <= 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sg = GSEP ? smem + 2 * KP * 64 : smem;        // [GPAN][KP][64] (DENPROD only; see rowgemm_stream_smem_bytes)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   const int npan = kdim >> 6;
-  const int tile = blockIdx.x * 4 + wv;                // tiles of WR rows
-  const bool act = tile < ntiles;
-  const float* Arow = A + ((int64_t)(act ? tile : 0) * WR + i) * lda + 4 * kq;
+  // PERSISTENT workgroups: group g of four wave tiles, g = blockIdx.x, + gridDim.x, ...; the prefetch runs on across the
+  // groups (the last panel of a tile requests panel 0 of the wave's next tile), B's panels wrap around, G is staged
+  // once.  A tile of a 256-column matrix is four panels: on its own it spent a good part of its life waiting for its
+  // first panel and draining its last (1 048 576 x 256, k = 64: 0.50 -> see profiles/r03_experiments.md).
+  const int ngroups = (ntiles + 3) >> 2;
   f32x4 acc[RB][NT];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 fa0[RB][4], fa1[RB][4];
   constexpr int BCH = KP * 16 / 256;                   // 16-byte pieces of a B panel per thread
   f32x4 pbr[BCH];
   auto load_b = [&](int p) {                           // unconditional: a guard is a branch the waitcnt pass trips over
-    const int pp = p < npan ? p : npan - 1;
+    const int pp = p < npan ? p : p - npan;            // (wraps: the next tile starts with panel 0 again)
 #pragma unroll
     for (int q = 0; q < BCH; ++q) {
       const int id = tid + 256 * q;
@@ -300,29 +305,15 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
       lds_write4(cb, 16 * (brow % NT) + brow / NT, id & 15, pbr[q]);
     }
   };
-  auto panel = [&](int p, f32x4 (&fa)[RB][4], f32x4 (&fan)[RB][4]) {
-    const float* cb = smem + (p & 1) * (KP * 64);
-    const float* An = Arow + 64 * (p + 1 < npan ? p + 1 : p);   // (the last panel re-requests itself: straight-line code)
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 b4[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(cb, 16 * nt + i, 4 * t + kq);
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        fan[rb][t] = *reinterpret_cast<const f32x4*>(An + (int64_t)(16 * rb) * lda + 16 * t);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = mfma16(fa[rb][t][e], b4[nt][e], acc[rb][nt]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+  auto stage_g = [&]() {                               // G as [GPAN][KP][64] panel images, rows in the order of B's
+    for (int id = tid; id < GPAN * KP * GCH; id += 256) {
+      const int pg = id / (KP * GCH), rem = id % (KP * GCH), row = rem / GCH, ch = rem % GCH;
+      lds_write4(sg + pg * (KP * 64), 16 * (row % NT) + row / NT, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
     }
-    store_b(smem + ((p + 1) & 1) * (KP * 64));         // B panel p + 1: its buffer was last read in panel p - 1
-    load_b(p + 2);
   };
+  if (DENPROD && GSEP) stage_g();
+  int tile = blockIdx.x * 4 + wv;                      // tiles of WR rows
+  const float* Arow = A + ((int64_t)(tile < ntiles ? tile : 0) * WR + i) * lda + 4 * kq;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -330,84 +321,120 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
   load_b(0);
   store_b(smem);
   load_b(1);
-  for (int p = 0; p < npan; p += 2) {                  // no branch INSIDE the pair: LLVM sinks the prefetch into it
-    panel(p, fa0, fa1);
-    panel(p + 1, fa1, fa0);
-  }
-  if (EPI == EPI_STORE) {
-    if (act) {
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v[NT];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) v[nt] = acc[rb][nt][j];
-          vec_store<NT>(C + ((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + NT * i, v);
-        }
-    }
-    return;
-  }
-  f32x4 den[RB][NT];
-  if (!DENBUF) {
-    // ---- Den = W_tile G: contraction over the KP bases, G as [ceil(KP / 64)][KP][64] panel images in LDS ----
-    constexpr int GPAN = (KP + 63) / 64;                 // 64-column panels of G
-    constexpr int GCH = KP < 64 ? KP / 4 : 16;           // 16-byte chunks per row of a panel
-    __syncthreads();                                     // every wave is through with the B panels
-    for (int id = tid; id < GPAN * KP * GCH; id += 256) {
-      const int pg = id / (KP * GCH), rem = id % (KP * GCH), row = rem / GCH, ch = rem % GCH;
-      lds_write4(smem + pg * (KP * 64), 16 * (row % NT) + row / NT, ch, *reinterpret_cast<const f32x4*>(G + row * KP + 64 * pg + 4 * ch));
-    }
-    const float* Wrow = W + ((int64_t)(act ? tile : 0) * WR + i) * ldw + 4 * kq;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const bool act = tile < ntiles;
+    const int tile_n = tile + 4 * gridDim.x;           // this wave's tile of the next group (if there is one)
+    const bool more = grp + (int)gridDim.x < ngroups;
+    const float* Arow_n = A + ((int64_t)(more && tile_n < ntiles ? tile_n : 0) * WR + i) * lda + 4 * kq;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) den[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+      for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto panel = [&](int p, f32x4 (&fa)[RB][4], f32x4 (&fan)[RB][4]) {
+      const float* cb = smem + (p & 1) * (KP * 64);
+      // next panel of this tile; after the last one, panel 0 of the next tile (or, on the very last, itself once more)
+      const float* An = p + 1 < npan ? Arow + 64 * (p + 1) : (more ? Arow_n : Arow + 64 * p);
+      __syncthreads();
 #pragma unroll
-    for (int pg = 0; pg < GPAN; ++pg)
-#pragma unroll
-      for (int t = 0; t < GCH / 4; ++t) {
+      for (int t = 0; t < 4; ++t) {
         f32x4 b4[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(smem + pg * (KP * 64), 16 * nt + i, 4 * t + kq);
+        for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(cb, 16 * nt + i, 4 * t + kq);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wrow + (int64_t)(16 * rb) * ldw + 64 * pg + 16 * t);
+          fan[rb][t] = *reinterpret_cast<const f32x4*>(An + (int64_t)(16 * rb) * lda + 16 * t);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) den[rb][nt] = mfma16(a4[e], b4[nt][e], den[rb][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = mfma16(fa[rb][t][e], b4[nt][e], acc[rb][nt]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-  }
-  if (!act) return;
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t row = (int64_t)tile * WR + 16 * rb + 4 * kq + j;
-      float* p = W + row * ldw + NT * i;                        // bases NT i .. NT i + NT - 1 of this row
-      float wv_[NT], dn_[NT], out[NT];
-      vec_load<NT>(p, wv_);
-      if (DENBUF) vec_load<NT>(G + row * ldw + NT * i, dn_);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float w = wv_[nt];
-        const float num = acc[rb][nt][j], dn = DENBUF ? dn_[nt] : den[rb][nt][j];
-        if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
-          const float r = w * ((fabsf(num) - num) / (2.0f * dn));
-          out[nt] = (row < mvalid && (NT * i + nt) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
-        } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
-          const float w1 = num + (3.0f * lamb) * (w * w);
-          const float w2 = ((dn + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
-          out[nt] = w * (w1 / w2);
-        } else {
-          out[nt] = (w * num) / (dn + PMF_EPS_DEN);           // multiply, then divide (nmf.py:131-132)
-        }
-      }
-      vec_store<NT>(p, out);
+      store_b(smem + ((p + 1) & 1) * (KP * 64));       // B panel p + 1 (mod npan): its buffer was last read in panel p - 1
+      load_b(p + 2);
+    };
+    for (int p = 0; p < npan; p += 2) {                // no branch INSIDE the pair: LLVM sinks the prefetch into it
+      panel(p, fa0, fa1);
+      panel(p + 1, fa1, fa0);
     }
+    // ---- this tile's epilogue (the next tile's first panel and B panels 0, 1 are on their way) ----
+    if (EPI == EPI_STORE) {
+      if (act) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[rb][nt][j];
+            vec_store<NT>(C + ((int64_t)tile * WR + 16 * rb + 4 * kq + j) * ldc + NT * i, v);
+          }
+      }
+    } else {
+      if (DENPROD && !GSEP) {                          // (single group per workgroup: nothing needs the B buffers any more)
+        __syncthreads();
+        stage_g();
+        __syncthreads();
+      }
+      const float* Wrow = W + ((int64_t)(act ? tile : 0) * WR + i) * ldw + 4 * kq;
+      // one block of 16 rows at a time: Den = W_tile G for it (contraction over the KP bases, the W fragments straight from
+      // global memory as A was), then its rows' update -- NT accumulators live instead of RB * NT beside the prefetched panel
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        f32x4 den[NT];
+        if (DENPROD) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) den[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int pg = 0; pg < GPAN; ++pg)
+#pragma unroll
+            for (int t = 0; t < GCH / 4; ++t) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wrow + (int64_t)(16 * rb) * ldw + 64 * pg + 16 * t);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 b4 = lds_read4(sg + pg * (KP * 64), 16 * nt + i, 4 * t + kq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) den[nt] = mfma16(a4[e], b4[e], den[nt]);
+              }
+            }
+        }
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t row = (int64_t)tile * WR + 16 * rb + 4 * kq + j;
+            float* p = W + row * ldw + NT * i;                        // bases NT i .. NT i + NT - 1 of this row
+            float wv_[NT], dn_[NT], out[NT];
+            vec_load<NT>(p, wv_);
+            if (DENBUF) vec_load<NT>(G + row * ldw + NT * i, dn_);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const float w = wv_[nt];
+              const float num = acc[rb][nt][j], dn = DENBUF ? dn_[nt] : den[nt][j];
+              if (EPI == EPI_RNMF_W) {                              // rnmf.py:109-115 (A = S - data, no epsilon)
+                const float r = w * ((fabsf(num) - num) / (2.0f * dn));
+                out[nt] = (row < mvalid && (NT * i + nt) < kvalid) ? r : 0.f;   // 0/0 on the zero padding
+              } else if (EPI == EPI_BNMF_W) {                       // bnmf.py:87-90
+                const float w1 = num + (3.0f * lamb) * (w * w);
+                const float w2 = ((dn + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
+                out[nt] = w * (w1 / w2);
+              } else {
+                out[nt] = (w * num) / (dn + PMF_EPS_DEN);           // multiply, then divide (nmf.py:131-132)
+              }
+            }
+            vec_store<NT>(p, out);
+          }
+        }
+      }
+    }
+    tile = tile_n;
+    Arow = Arow_n;
+  }
+}
+
+template <int NT, int EPI, bool DENBUF>
+constexpr size_t rowgemm_stream_smem_bytes() {
+  return (size_t)(2 * 16 * NT * 64 + ((EPI != EPI_STORE && !DENBUF && NT <= 4) ? ((16 * NT + 63) / 64) * 16 * NT * 64 : 0)) * sizeof(float);
 }
 
 // Partials of P = W^T V and S = W^T W over one chunk of rows.
