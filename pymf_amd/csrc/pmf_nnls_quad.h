@@ -188,6 +188,33 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
     }
     bool done = !valid;
     int npass = 0, ninf_best = k + 1, backup = 3;
+    // y0 = B (f on the live variables), ONCE per problem: the complement form needs y = B (f on P) in every pass, and
+    // P is the large set there (at cfg3 about 56 of 64 variables, 1.9 passes per wave task) -- y = y0 - B (f on N)
+    // costs |N| terms per pass instead of |P|.
+    double y0[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) vecV[16 * s + r] = f[s];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int c0 = 0; c0 < k; c0 += 4) {
+        double fc[4];
+        const double* row[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + e;
+          const bool lv = c < k && ((kmask >> c) & 1ull);
+          fc[e] = lv ? vecV[c] : 0.0;
+          row[e] = sM + 64 * QLD + (c < 64 ? c : 0) * QLD + r * 2;    // B, row c, this lane's two 16-byte pieces
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y0[0] = fma(row[e][0], fc[e], y0[0]); y0[1] = fma(row[e][1], fc[e], y0[1]);
+          y0[2] = fma(row[e][32], fc[e], y0[2]); y0[3] = fma(row[e][33], fc[e], y0[3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
 
     for (int pass = 0; pass < 8 * 64 + 16; ++pass) {
       if (__ballot(!done) == 0ull) break;
@@ -218,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       }
 #endif
       ntmax = __builtin_amdgcn_readfirstlane(ntmax);
+      (void)ntmax;                                   // (diagnostic builds count it: the product over P that is no longer formed)
       {
         const int offP = comp ? 0 : shift, offN = comp ? shift : 0;   // the S list right-aligned at byte 32, the other at 0
 #pragma unroll
@@ -236,7 +264,6 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const unsigned char* lS = lst + (comp ? 64 : 0);      // entry of position p at lS[p], p >= shift
-      const unsigned char* lT = lst + (comp ? 0 : 64);      // entry i at lT[i]
       const double* Msel = sM + (comp ? 64 * QLD : 0);
       unsigned pcl[8];                               // permuted column offsets of the S frame, packed bytes
 #pragma unroll
@@ -246,27 +273,26 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       }
 
       PMF_QSTAMP(0);
-      // ---- complement form: y = B (f on P), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
-      double y[4] = {0.0, 0.0, 0.0, 0.0};
+      // ---- complement form: y = B (f on P) = y0 - B (f on N), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
+      double y[4] = {y0[0], y0[1], y0[2], y0[3]};
       {
-        // four terms at a time: one dword of the list, then the four operands and eight row pieces are requested
-        // TOGETHER (term by term the loop was a chain of dependent LDS round trips: list byte -> operand -> row)
-        const int nt = comp ? np_ : 0;
-        for (int i0 = 0; i0 < ntmax; i0 += 4) {
-          const unsigned u = reinterpret_cast<const unsigned*>(lT)[i0 >> 2];
+        // over the positions of the S frame (S = N here), four at a time: one dword of the list, then the four operands
+        // and eight row pieces are requested TOGETHER (term by term: a chain of dependent LDS round trips)
+        for (int p0 = jstart & ~3; p0 < QNS; p0 += 4) {
+          const unsigned u = reinterpret_cast<const unsigned*>(lS)[p0 >> 2];
           double fc[4];
           const double* row[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool live = i0 + e < nt;
-            const int c = live ? (int)((u >> (8 * e)) & 0xffu) : 0;
-            fc[e] = live ? vecV[c] : 0.0;
+            const bool lv = comp && p0 + e >= shift;
+            const int c = lv ? (int)((u >> (8 * e)) & 0xffu) : 0;
+            fc[e] = lv ? vecV[c] : 0.0;
             row[e] = sM + 64 * QLD + c * QLD + r * 2;                 // B, row c, this lane's two 16-byte pieces
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            y[0] = fma(row[e][0], fc[e], y[0]); y[1] = fma(row[e][1], fc[e], y[1]);
-            y[2] = fma(row[e][32], fc[e], y[2]); y[3] = fma(row[e][33], fc[e], y[3]);
+            y[0] = fma(-row[e][0], fc[e], y[0]); y[1] = fma(-row[e][1], fc[e], y[1]);
+            y[2] = fma(-row[e][32], fc[e], y[2]); y[3] = fma(-row[e][33], fc[e], y[3]);
           }
         }
       }
