@@ -464,19 +464,18 @@ def main():
         }
         if algo_name == "NMFALS":
             # The QP kernel runs float64 VALU code: neither HBM nor MFMA bounds it.  Against the 78.6 TFLOP/s float64
-            # vector peak: flop of ONE solve per problem (k_nnqp_quad: LDL^T of the smaller of HA[P,P] / inv(HA)[N,N],
-            # order ns ~ 26 of 64 at cfg3, two triangular solves, the two products with the shared matrices) times the
-            # solves per problem, the latter from the recorded VALU instruction count of a W-step launch in this bench's
-            # state (rocprofv3 SQ_INSTS_VALU, profiles/r03_pmc_cfg3_nnqp_quad.txt: 1.18e8 per launch = 450 per problem
-            # = one solve: after the pre-roll the active sets of most rows no longer change).
+            # vector peak: the FMA flop of k_nnqp_quad per problem in this bench's state -- B f once (2 * 64 * 64), then per
+            # pass the correction over N and the product with the solution (2 * 64 * ns each), the LDL^T of inv(HA)[N,N]
+            # (2 ns^3 / 3) and the two triangular solves (2 * 2 ns^2) -- with the RECORDED sizes of that state: ns = 8
+            # unknowns, 1.9 passes (tools/quad_counts.py on a counting build, profiles/r03_experiments.md) and the recorded
+            # VALU instruction count of a W-step launch (rocprofv3 SQ_INSTS_VALU, profiles/r03_pmc_cfg3_nnqp_quad.txt:
+            # 1.16e8 per launch = 442 per problem).
             qps = float(hi - lo)
             quad = "quad" in stats["name"]
             if quad and k == 64:
-                ns, npas = 26.0, 38.0
-                flop_per_solve = 2.0 * (ns ** 3 / 3.0 + 2.0 * ns * ns + 64.0 * (ns + npas))
-                valu_instr = 1.18e8 * qps / 262144.0
-                solves = valu_instr / (450.0 * qps)
-                fma_flop = flop_per_solve * solves * qps
+                ns, passes = 8.0, 1.9
+                fma_flop = (2.0 * 64.0 * 64.0 + passes * (4.0 * 64.0 * ns + 2.0 * ns ** 3 / 3.0 + 4.0 * ns * ns)) * qps
+                valu_instr = 1.16e8 * qps / 262144.0
                 src = "profiles/r03_pmc_cfg3_nnqp_quad.txt (SQ_INSTS_VALU of k_nnqp_quad in this bench's state)"
             else:                                 # lane-per-variable kernel: DESIGN.md 3.4, profiles/r02_pmc_summary.csv
                 fma_flop = 2.0 * 2.24e5 * qps * (k / 64.0) ** 3
