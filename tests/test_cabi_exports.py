@@ -133,3 +133,22 @@ def test_host_checksum_is_position_sensitive(lib):
     nc = W[::2, ::3]                                                   # non-contiguous view: digest of its contents
     assert lib.host_checksum(nc) == lib.host_checksum(np.ascontiguousarray(nc))
     assert lib.host_checksum(np.zeros((0, 4)))[0] == (0, 4)
+
+
+@pytest.mark.gpu
+def test_every_documented_option_is_known_to_the_library(lib):
+    """include/pymf_hip.h lists the tuning knobs of pmf_set_option by name: each must be accepted with its default
+    value, an undocumented name must be PMF_EINVAL."""
+    import re
+    from pymf_amd import _lib
+    text = open(os.path.join(ROOT, "include", "pymf_hip.h")).read()
+    block = text[text.index("Tuning knobs"):text.index("int pmf_set_option")]
+    names = re.findall(r'^ \*   "([a-z_]+)"', block, flags=re.M)
+    assert set(names) >= {"snmf_gram", "nnqp_quad", "force_tiled", "rowgemm_stream", "colgemm_stream", "nndsvd_topk"}, names
+    defaults = {"snmf_gram": -1, "nnqp_quad": 1, "force_tiled": 0, "rowgemm_stream": 1, "colgemm_stream": 1, "nndsvd_topk": -1}
+    ctx = _lib.Context(_lib.ALGO_NMF, 256, 64, 8)
+    for name in names:
+        ctx.set_option(name, defaults.get(name, 0))
+    with pytest.raises(_lib.PmfError):
+        ctx.set_option("no_such_option", 1)
+    ctx.close()
