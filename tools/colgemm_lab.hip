@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifndef WPAD
+#define WPAD 4
+#endif
 #include "../pymf_amd/csrc/pmf_dev.h"
 #include "../pymf_amd/csrc/pmf_tiled.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -117,7 +120,10 @@ __global__ __launch_bounds__(256, 2) void k_col3(const float* __restrict__ V, in
   constexpr int KP = 16 * NT;
   constexpr int ST = (NT + 3) / 4;
   constexpr int SR = 64;                               // rows per stage
-  constexpr int WLD = KP + 4;                          // padded row of the W stage in LDS (floats)
+#ifndef WPAD
+#define WPAD 4
+#endif
+  constexpr int WLD = KP + WPAD;                       // padded row of the W stage in LDS (floats)
   constexpr int WCH = SR * (KP / 4) / 256;             // 16-byte pieces of a W stage per thread
   static_assert(NT == 4, "lab: NT = 4");
   extern __shared__ __attribute__((aligned(16))) float sw[];
@@ -262,7 +268,7 @@ int main(int argc, char** argv) {
   RUN("k_col2<4> MFMAs only, no S", (k_col2<NT, 3>), S2)
   RUN("k_col2<4>", (k_col2<NT, 0>), S2)
   {
-    const size_t smem3 = (size_t)2 * 64 * (KP + 4) * sizeof(float);
+    const size_t smem3 = (size_t)2 * 64 * (KP + WPAD) * sizeof(float);
     for (int it = 0; it < 6; ++it) {
       CK(hipEventRecord(e0));
       hipLaunchKernelGGL((k_col3<NT, true>), grid, dim3(256), smem3, 0, V, (int64_t)np, np, W, (int64_t)KP, m, rpc, S2);
