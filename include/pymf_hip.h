@@ -189,6 +189,10 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *   "rowgemm_stream" 1 (default): plain products with a long contraction (V H^T of NMFALS / SNMF, W = V M^T) on
  *                k_rowgemm_stream (A fragments straight into registers, requests interleaved with the MFMAs);
  *                0: on k_rowgemm.  Bit-identical results (same order of summation).
+ *   "nnqp_frame16" 1 (default): the sixteen-lanes-per-problem kernel first on a 16-slot frame (settled active sets factorise
+ *                systems of about 8 unknowns: twelve waves around one LDS image of HA and inv(HA), 168 registers -- three
+ *                waves per SIMD instead of two), problems that outgrow it on the 32-slot frame behind; 0: the 32-slot
+ *                frame for all.  Bit-identical results.
  *   "force_tiled" 1: every path of this context takes the any-shape two-pass kernels (k_rowgemm / k_colgemm)
  *                even where a one-pass kernel covers the shape; 0 gives the one-pass kernels back.  For tests
  *                and measurements of the any-shape kernels on the bench shapes. */

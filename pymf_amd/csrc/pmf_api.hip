@@ -100,6 +100,11 @@ struct pmf_ctx {
   int* dSing = nullptr;         // SNMF: raised by the inverse kernels when H H^T has a zero pivot (check_singular)
   double* dQp = nullptr;        // k_nnqp_big (NMFALS, num_bases > 64): per-workgroup inverse images
   double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
+  int* dDefer = nullptr;        // k_nnqp_quad<16>: problems left to the 32-slot frame
+  int64_t defer_cap = 0;
+  int* dNbig = nullptr;         // [2 sites][2]: problems of the last two W / H half steps whose first system was beyond 16 unknowns
+  int nbig_flip[2] = {0, 0};
+  int opt_nnqp_frame16 = 1;     // pmf_set_option("nnqp_frame16"): the 16-slot frame first (three waves per SIMD)
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
   bool wsnap_valid = false;
   int opt_nndsvd_topk = -1;     // pmf_set_option("nndsvd_topk"): -1 by size, 1 the filtered subspace iteration, 0 full Jacobi
@@ -1553,7 +1558,28 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
   PMFCHK(nnqp_scratch(c, &qp));
   if (stat) stat_begin(c, SITE_NNQP_W);
   int rc = PMF_OK;
-  if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm);
+  int* defer = nullptr;
+  int* nbig = nullptr;
+  const int* nbig_prev = nullptr;
+  if (quad && c->opt_nnqp_frame16) {
+    // The 16-slot frame pays when most problems fit it (settled active sets: three waves per SIMD instead of two).  Whether
+    // they do is decided ON THE DEVICE from the count the previous half step of this kind left (no host round trip: the
+    // loop is enqueued ahead of the GPU): two counters per site, written alternately.
+    const int site = stat ? 0 : 1;                   // W / H half step
+    if (!c->dNbig) PMFCHK(dalloc(c, &c->dNbig, 4));
+    if (c->defer_cap < nprob) {
+      if (c->dDefer) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->dDefer)); c->dDefer = nullptr; }
+      PMFCHK(dalloc(c, &c->dDefer, (size_t)nprob));
+      c->defer_cap = nprob;
+    }
+    defer = c->dDefer;
+    nbig_prev = c->dNbig + 2 * site + c->nbig_flip[site];
+    c->nbig_flip[site] ^= 1;
+    nbig = c->dNbig + 2 * site + c->nbig_flip[site];
+    HIPCHK(c, hipMemsetAsync(nbig, 0, sizeof(int), c->stream));
+  }
+  if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, defer,
+                                  nbig, nbig_prev);
   if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, quad ? 1 : 0);
   if (stat) stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch failed");
@@ -1824,6 +1850,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   if (const char* e = std::getenv("PMF_COLGEMM_STREAM")) c->opt_colgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("colgemm_stream")
   if (const char* e = std::getenv("PMF_RESID_RESIDENT")) c->opt_resid_resident = std::atoi(e) != 0;
   if (const char* e = std::getenv("PMF_ROWGEMM_STREAM")) c->opt_rowgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("rowgemm_stream")
+  if (const char* e = std::getenv("PMF_NNQP_FRAME16")) c->opt_nnqp_frame16 = std::atoi(e) != 0;   // as pmf_set_option("nnqp_frame16")
   if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
   c->np = (int)round_up(n, 64);
@@ -1936,7 +1963,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dWsnap})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
@@ -2596,6 +2623,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
     if (c->g_parts > 0) { c->g_valid = false; c->g_parts = 0; }
     choose_stat_site(c, false);
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "nnqp_frame16") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "nnqp_frame16: 0 or 1");
+    c->opt_nnqp_frame16 = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "nnqp_quad") == 0) {

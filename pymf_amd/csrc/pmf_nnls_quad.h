@@ -42,10 +42,11 @@
 constexpr int QLD = 66;            // LDS row stride of the shared matrices in doubles (528 B: rows start on different banks)
 constexpr int QNS = 32;            // largest system a problem factorises
 constexpr int QPW = 4;             // problems per wave
+template <int QN = QNS, int NW = 4>
 constexpr size_t nnqp_quad_smem_bytes() {
   return (size_t)2 * 64 * QLD * sizeof(double)                    // HA, B
-         + (size_t)4 * QPW * (64 + QNS) * sizeof(double)          // per wave and problem: a 64-vector and a 32-vector
-         + (size_t)4 * QPW * 128;                                 // ... and the P and N lists (bytes)
+         + (size_t)NW * QPW * (64 + QN) * sizeof(double)          // per wave and problem: a 64-vector and a QN-vector
+         + (size_t)NW * QPW * 128;                                // ... and the P and N lists (bytes)
 }
 
 template <int R>
@@ -131,11 +132,21 @@ __device__ unsigned long long g_quad_t[8];   // ticks per section: lists, y prod
 __device__ unsigned long long g_quad_cnt[16];
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__ Horig, const double* __restrict__ Hd,
+// QN: the frame -- the largest system a problem factorises here (32: every problem, k / 2 <= 32; 16: the form for settled
+// active sets, 12 waves per workgroup around ONE LDS image of HA and B and a third less registers: three waves per SIMD
+// instead of two; a problem that needs more marks itself in `defer` and is left, untouched, to a QN = 32 launch behind).
+// defer (may be null): QN = 16 writes 1 / 0 per problem; QN = 32 solves only the problems marked 1.
+template <int QN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const double* __restrict__ Horig, const double* __restrict__ Hd,
                                                       const double* __restrict__ Bd,
                                                       int KP, int k, const float* __restrict__ F, int64_t f_sk,
                                                       int64_t f_sp, float* __restrict__ X, int64_t x_sk, int64_t x_sp,
-                                                      int64_t nprob, const int* __restrict__ warm_flag) {
+                                                      int64_t nprob, const int* __restrict__ warm_flag, int* __restrict__ defer,
+                                                      int* __restrict__ nbig, const int* __restrict__ nbig_prev) {
+  constexpr int MB = QN / 16;                        // 16-row blocks of the frame
+  // the previous half step of this kind met more than a tenth of its problems beyond a 16-slot frame (the first iterations
+  // from a random start): the 16-slot launch hands everything on at once, the 32-slot launch counts for the next decision
+  const bool all_big = nbig_prev != nullptr && 10 * (int64_t)(*nbig_prev) > nprob;
   if (*warm_flag == 0) return;                       // HA not safely positive definite: k_nnqp takes the half step
   extern __shared__ __attribute__((aligned(16))) double qsm[];
   // [2][64][QLD]: 0 = HA, 1 = B.  Entry (c, t), t = 16 s + r, at c * QLD + (s / 2) * 32 + 2 r + s % 2: lane r's four
@@ -145,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, r = lane & 15;
-  double* vecV = qsm + 2 * 64 * QLD + (size_t)(wv * QPW + q) * (64 + QNS);   // this problem's 64-vector
+  double* vecV = qsm + 2 * 64 * QLD + (size_t)(wv * QPW + q) * (64 + QN);    // this problem's 64-vector
   double* vecC = vecV + 64;                                                   // ... and 32-vector
-  unsigned char* lst = reinterpret_cast<unsigned char*>(qsm + 2 * 64 * QLD + 4 * QPW * (64 + QNS)) +
+  unsigned char* lst = reinterpret_cast<unsigned char*>(qsm + 2 * 64 * QLD + NW * QPW * (64 + QN)) +
                        (size_t)(wv * QPW + q) * 128;                          // [2][64]: P list, N list
-  for (int e = tid; e < 2 * 64 * 64; e += 256) {
+  for (int e = tid; e < 2 * 64 * 64; e += 64 * NW) {
     const int which = e >> 12, c = (e >> 6) & 63, t = e & 63;
     const double* src = which ? Bd : Hd;
     const double v = (c < k && t < k) ? src[(int64_t)c * KP + t] : (c == t ? 1.0 : 0.0);
@@ -165,10 +176,16 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
   const unsigned long long live = kmask;
   const int klive = __popcll(kmask);
 
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * QPW; base < nprob; base += nwaves * QPW) {
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  for (int64_t base = ((int64_t)blockIdx.x * NW + wv) * QPW; base < nprob; base += nwaves * QPW) {
     const int64_t prob = base + q;
-    const bool valid = prob < nprob;
+    const bool valid = prob < nprob && (QN < 32 || defer == nullptr || defer[prob < nprob ? prob : 0] != 0);
+    bool deferred = false;                           // QN = 16: this problem's system outgrew the frame
+    if (QN < 32 && all_big) {
+      if (defer != nullptr && prob < nprob && r == 0) defer[prob] = 1;
+      continue;
+    }
+    if (__ballot(valid) == 0ull) continue;           // (QN = 32 behind QN = 16: nothing of this wave's four was left over)
     // ---- this problem's right-hand side and warm start: variable 16 s + r in slot s of lane r ----
     double f[4], x[4];
     unsigned long long pm = 0ull;
@@ -224,17 +241,25 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       // ---- lists of P and N (ascending), the form of the solve ----
       // The system's unknowns sit at positions shift .. 31 of a 32-slot frame (shift = 32 - ns, identity in front):
       // the factorisation can then START at the first position any of the wave's problems uses.
+      if (pass == 0 && nbig != nullptr && !done && r == 0 && (QN < 32 || defer == nullptr || all_big)) {   // how many problems START beyond
+        const int np0 = __popcll(pm);                              // a 16-slot frame: the next half step's choice of the form
+        if (min(np0, klive - np0) > 16) atomicAdd(nbig, 1);
+      }
+      if (QN < 32 && !done) {                        // does the smaller of |P|, |N| still fit the frame?
+        const int np0 = __popcll(pm);
+        if (min(np0, klive - np0) > QN) { deferred = true; done = true; pm = 0ull; }   // (pm = 0: an empty system for the rest of the wave's passes)
+      }
       const int np_ = __popcll(pm), nn = klive - np_;
       const bool comp = nn < np_;                    // complement form: factorise B[N,N]
-      const int ns = comp ? nn : np_;                // <= k / 2 <= 32
-      const int shift = QNS - ns;
+      const int ns = comp ? nn : np_;                // <= min(k / 2, QN)
+      const int shift = QN - ns;
       int nsmax = ns, ntmax = comp ? np_ : 0;
 #pragma unroll
       for (int o = 32; o >= 16; o >>= 1) {
         nsmax = max(nsmax, __shfl_xor(nsmax, o, 64));
         ntmax = max(ntmax, __shfl_xor(ntmax, o, 64));
       }
-      const int jstart = __builtin_amdgcn_readfirstlane(QNS - nsmax);
+      const int jstart = __builtin_amdgcn_readfirstlane(QN - nsmax);
 #ifdef PMF_QUAD_COUNT
       if (lane == 0) {
         if (pass == 0) atomicAdd(&g_quad_cnt[0], 1ull);
@@ -265,9 +290,9 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const unsigned char* lS = lst + (comp ? 64 : 0);      // entry of position p at lS[p], p >= shift
       const double* Msel = sM + (comp ? 64 * QLD : 0);
-      unsigned pcl[8];                               // permuted column offsets of the S frame, packed bytes
+      unsigned pcl[QN / 4];                               // permuted column offsets of the S frame, packed bytes
 #pragma unroll
-      for (int d = 0; d < 8; ++d) {
+      for (int d = 0; d < QN / 4; ++d) {
         const unsigned sld = reinterpret_cast<const unsigned*>(lS)[d];
         pcl[d] = (sld & 0x20202020u) | ((sld & 0x0f0f0f0fu) << 1) | ((sld >> 4) & 0x01010101u);   // the offset above, per byte
       }
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       {
         // over the positions of the S frame (S = N here), four at a time: one dword of the list, then the four operands
         // and eight row pieces are requested TOGETHER (term by term: a chain of dependent LDS round trips)
-        for (int p0 = jstart & ~3; p0 < QNS; p0 += 4) {
+        for (int p0 = jstart & ~3; p0 < QN; p0 += 4) {
           const unsigned u = reinterpret_cast<const unsigned*>(lS)[p0 >> 2];
           double fc[4];
           const double* row[4];
@@ -306,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
 
       PMF_QSTAMP(1);
       // ---- gather M[S,S] into positions shift .. 31 (identity in front) and the right-hand side ----
-      double Lr[48], dv[2], bv[2];
-      static_for<0, 2>([&](auto mc_) {
+      double Lr[8 * MB * (MB + 1)], dv[MB], bv[MB];
+      static_for<0, MB>([&](auto mc_) {
         constexpr int m = decltype(mc_)::value;
         const int i = 16 * m + r;
         const bool live_i = i >= shift;
@@ -328,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       // The reciprocal of step j + 1's pivot is started as soon as column j + 1 has its step-j update (first in
       // the loop over c): its latency -- v_rcp_f64 and two Newton steps -- runs under the rest of step j's updates.
       double dnext = 1.0, invnext = 1.0;
-      static_for<0, QNS>([&](auto jc_) {
+      static_for<0, QN>([&](auto jc_) {
         constexpr int j = decltype(jc_)::value;
         constexpr int mj = j >> 4, rj = j & 15;
         if (j >= jstart) {                           // (below: identity in every problem of this wave)
@@ -339,12 +364,12 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
           }
           if (r == rj) dv[mj] = dj;
           double lij[2];
-          static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; lij[m] = Lr[qoff(m) + j] * inv; });
-          static_for<j + 1, QNS>([&](auto cc_) {
+          static_for<mj, MB>([&](auto mm_) { constexpr int m = decltype(mm_)::value; lij[m] = Lr[qoff(m) + j] * inv; });
+          static_for<j + 1, QN>([&](auto cc_) {
             constexpr int c = decltype(cc_)::value;
             constexpr int mc = c >> 4, rc = c & 15;
             const double acj = row_bcast<rc>(Lr[qoff(mc) + j]);
-            static_for<mc, 2>([&](auto mm_) {
+            static_for<mc, MB>([&](auto mm_) {
               constexpr int m = decltype(mm_)::value;
               Lr[qoff(m) + c] = fma(-lij[m], acj, Lr[qoff(m) + c]);
             });
@@ -354,43 +379,43 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
             }
           });
           // (rows <= j of block mj: padding, never read again)
-          static_for<mj, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; Lr[qoff(m) + j] = lij[m]; });
+          static_for<mj, MB>([&](auto mm_) { constexpr int m = decltype(mm_)::value; Lr[qoff(m) + j] = lij[m]; });
         }
       });
       PMF_QSTAMP(3);
       // ---- forward: L z = b ----
-      static_for<0, QNS>([&](auto jc_) {
+      static_for<0, QN>([&](auto jc_) {
         constexpr int j = decltype(jc_)::value;
         constexpr int mj = j >> 4, rj = j & 15;
         if (j >= jstart) {
           const double zj = row_bcast<rj>(bv[mj]);
           if (rj < 15) bv[mj] = fma(-(r > rj ? Lr[qoff(mj) + j] : 0.0), zj, bv[mj]);
-          static_for<mj + 1, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; bv[m] = fma(-Lr[qoff(m) + j], zj, bv[m]); });
+          static_for<mj + 1, MB>([&](auto mm_) { constexpr int m = decltype(mm_)::value; bv[m] = fma(-Lr[qoff(m) + j], zj, bv[m]); });
         }
       });
-      static_for<0, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; bv[m] = bv[m] * pmf_rcp_f64(dv[m]); });
+      static_for<0, MB>([&](auto mm_) { constexpr int m = decltype(mm_)::value; bv[m] = bv[m] * pmf_rcp_f64(dv[m]); });
       // ---- backward: L^T mu = z ----
-      static_for<0, QNS>([&](auto jr_) {
-        constexpr int j = QNS - 1 - decltype(jr_)::value;
+      static_for<0, QN>([&](auto jr_) {
+        constexpr int j = QN - 1 - decltype(jr_)::value;
         constexpr int mj = j >> 4, rj = j & 15;
         if (j >= jstart) {
           double part = 0.0;
           if (rj < 15) part = (r > rj ? Lr[qoff(mj) + j] : 0.0) * bv[mj];
-          static_for<mj + 1, 2>([&](auto mm_) { constexpr int m = decltype(mm_)::value; part = fma(Lr[qoff(m) + j], bv[m], part); });
+          static_for<mj + 1, MB>([&](auto mm_) { constexpr int m = decltype(mm_)::value; part = fma(Lr[qoff(m) + j], bv[m], part); });
           const double tot = row_sum(part);
           if (r == rj) bv[mj] -= tot;
         }
       });
       // mu (by position) -> vecC
 #pragma unroll
-      for (int m = 0; m < 2; ++m) vecC[16 * m + r] = bv[m];
+      for (int m = 0; m < MB; ++m) vecC[16 * m + r] = bv[m];
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
       PMF_QSTAMP(4);
       // ---- z = M[:, S] mu over this lane's 4 variables ----
       double z[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int p0 = jstart & ~3; p0 < QNS; p0 += 4) {     // four positions at a time, as above
+      for (int p0 = jstart & ~3; p0 < QN; p0 += 4) {     // four positions at a time, as above
         const unsigned u = reinterpret_cast<const unsigned*>(lS)[p0 >> 2];
         double mu[4];
         const double* row[4];
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
         const unsigned long long below = (1ull << v) - 1ull;
         const unsigned long long smask = comp ? (~pm & kmask) : pm;
         const bool inS = (smask >> v) & 1ull;
-        const double muv = inS ? vecC[(shift + __popcll(smask & below)) & (QNS - 1)] : 0.0;
+        const double muv = inS ? vecC[(shift + __popcll(smask & below)) & (QN - 1)] : 0.0;
         if (comp) { sv[s] = inP ? y[s] + z[s] : 0.0; w[s] = (real && !inP) ? f[s] - muv : 0.0; }
         else { sv[s] = inP ? muv : 0.0; w[s] = (real && !inP) ? f[s] - z[s] : 0.0; }
       }
@@ -464,29 +489,47 @@ __global__ __launch_bounds__(256, 2) void k_nnqp_quad(const double* __restrict__
       PMF_QSTAMP(6);
       __builtin_amdgcn_wave_barrier();
     }
-    if (valid) {
+    if (valid && !deferred) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int v = 16 * s + r;
         if (v < k) X[(int64_t)v * x_sk + prob * x_sp] = (float)(((pm >> v) & 1ull) ? x[s] : 0.0);
       }
     }
+    if (QN < 32 && defer != nullptr && prob < nprob && r == 0) defer[prob] = deferred ? 1 : 0;
   }
 }
 
-static inline int launch_nnqp_quad(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
-                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm) {
+template <int QN, int NW>
+static inline int launch_nnqp_quad_t(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
+                                     int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, int* defer, int* nbig,
+                                     const int* nbig_prev) {
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[pmf_current_device()];
-  const size_t smem = nnqp_quad_smem_bytes();
+  const size_t smem = nnqp_quad_smem_bytes<QN, NW>();
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nnqp_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nnqp_quad<QN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return PMF_EHIP;
     attr_done = true;
   }
-  int64_t blocks = (nprob + 4 * QPW - 1) / (4 * QPW);
-  if (blocks > 512) blocks = 512;                      // two workgroups per CU
+  int64_t blocks = (nprob + NW * QPW - 1) / (NW * QPW);
+  const int64_t cap = NW == 4 ? 512 : 256;             // two workgroups of 4 waves, or one of 12, per CU
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_nnqp_quad, dim3((unsigned)blocks), dim3(256), smem, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm);
+  hipLaunchKernelGGL((k_nnqp_quad<QN, NW>), dim3((unsigned)blocks), dim3(64 * NW), smem, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm,
+                     defer, nbig, nbig_prev);
   return PMF_OK;
+}
+
+// defer == nullptr: every problem on the 32-slot frame (one launch).  Else: the 16-slot frame first (three waves per SIMD),
+// then the 32-slot frame for the problems it marked.
+static inline int launch_nnqp_quad(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
+                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, int* defer = nullptr,
+                                   int* nbig = nullptr, const int* nbig_prev = nullptr) {
+  if (defer) {      // nbig (may be null): += the problems whose first system is beyond 16 unknowns, counted by the launch that sees them first
+    const int rc = launch_nnqp_quad_t<16, 12>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, defer, nbig, nbig_prev);
+    if (rc != PMF_OK) return rc;
+    return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, defer, nbig, nbig_prev);
+  }
+  return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, nullptr, nbig, nullptr);
 }

@@ -193,3 +193,25 @@ def test_nnqp_quad_leaves_dead_bases_at_zero(pm):
         c.close()
     assert np.all(res[2][:, 11] == 0.0) and np.isfinite(res[2]).all()
     assert rel_fro(res[2], res[0], what="W with a dead basis: k_nnqp_quad vs k_nnqp") < 2e-5
+
+
+@pytest.mark.parametrize("shape,k,niter", [((20000, 300), 50, 8), ((32768, 512), 64, 12), ((18000, 90), 20, 6)])
+def test_nnqp_quad_frames_are_bit_identical(pm, shape, k, niter):
+    """`nnqp_frame16`: the 16-slot frame (three waves per SIMD) with the 32-slot frame behind it for the problems that
+    outgrow it, or the 32-slot frame for all -- a problem's unknowns sit right-aligned in either frame, in the same lanes,
+    so the arithmetic is the same: W and H bit for bit, over iterations that start with every system beyond 16 unknowns
+    (random start: the device-side switch hands whole half steps to the 32-slot frame) and end with most of them inside."""
+    from pymf_amd import _lib
+    m, n = shape
+    out = []
+    for f16 in (1, 0):
+        c = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+        c.set_option("nnqp_quad", 2)
+        c.set_option("nnqp_frame16", f16)
+        c.fill_v_uniform(1234); c.fill_w_uniform(42); c.fill_h_uniform(43)
+        c.factorize(niter, compute_err=False)
+        out.append((c.get_w(), c.get_h()))
+        c.close()
+    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
