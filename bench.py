@@ -490,7 +490,7 @@ def main():
                                                  "frac": valu_instr / mean_s / 1e9 / (1024 * 2.4 / 4.0),
                                                  "source": src}
             out["roofline"]["note"] = ("float64 VALU kernel: `achieved` counts the FMA flop of the solves (recorded instruction counts, "
-                                       "live launch time); at two waves per SIMD the kernel is bound by the dependent chains of its "
+                                       "live launch time of the 16-slot-frame launch and the 32-slot one behind it); at three / two waves per SIMD the kernel is bound by the dependent chains of its "
                                        "factorisations and triangular solves, not by issue slots (valu_issue.frac)")
         if args.config == "cfg5":
             out["config"]["nnz_local"] = nnz_local
