@@ -102,8 +102,8 @@ struct pmf_ctx {
   double* dBinv = nullptr;      // k_nnqp_quad: B = inv(HA), [KP][KP] float64
   int* dDefer = nullptr;        // k_nnqp_quad<16>: problems left to the 32-slot frame
   int64_t defer_cap = 0;
-  int* dNbig = nullptr;         // [2 sites][2]: problems of the last two W / H half steps whose first system was beyond 16 unknowns
-  int nbig_flip[2] = {0, 0};
+  int* dNbig = nullptr;         // [2 sites][3 + 2]: rotating counters of k_nnqp_quad (QuadCtl: nbig x 3, dcount x 2)
+  int64_t quad_calls[2] = {0, 0};
   int opt_nnqp_frame16 = 1;     // pmf_set_option("nnqp_frame16"): the 16-slot frame first (three waves per SIMD)
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
   bool wsnap_valid = false;
@@ -1558,28 +1558,35 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
   PMFCHK(nnqp_scratch(c, &qp));
   if (stat) stat_begin(c, SITE_NNQP_W);
   int rc = PMF_OK;
-  int* defer = nullptr;
-  int* nbig = nullptr;
-  const int* nbig_prev = nullptr;
-  if (quad && c->opt_nnqp_frame16) {
+  QuadCtl ctl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const bool frames = quad && c->opt_nnqp_frame16;
+  if (frames) {
     // The 16-slot frame pays when most problems fit it (settled active sets: three waves per SIMD instead of two).  Whether
     // they do is decided ON THE DEVICE from the count the previous half step of this kind left (no host round trip: the
-    // loop is enqueued ahead of the GPU): two counters per site, written alternately.
+    // loop is enqueued ahead of the GPU).  Counters rotate over the calls and are zeroed by the kernels themselves.
     const int site = stat ? 0 : 1;                   // W / H half step
-    if (!c->dNbig) PMFCHK(dalloc(c, &c->dNbig, 4));
+    if (!c->dNbig) {
+      PMFCHK(dalloc(c, &c->dNbig, 10));
+      // no history yet: the first half step of either kind goes to the 32-slot frame (from a random start every system is
+      // beyond 16 unknowns, and 262 144 problems appending themselves to the list one atomic each is the slowest way to find out)
+      for (int st = 0; st < 2; ++st) HIPCHK(c, hipMemsetAsync(c->dNbig + 5 * st + 2, 0x3f, sizeof(int), c->stream));
+    }
     if (c->defer_cap < nprob) {
       if (c->dDefer) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->dDefer)); c->dDefer = nullptr; }
       PMFCHK(dalloc(c, &c->dDefer, (size_t)nprob));
       c->defer_cap = nprob;
     }
-    defer = c->dDefer;
-    nbig_prev = c->dNbig + 2 * site + c->nbig_flip[site];
-    c->nbig_flip[site] ^= 1;
-    nbig = c->dNbig + 2 * site + c->nbig_flip[site];
-    HIPCHK(c, hipMemsetAsync(nbig, 0, sizeof(int), c->stream));
+    int* base = c->dNbig + 5 * site;
+    const int64_t t = c->quad_calls[site]++;
+    ctl.dlist = c->dDefer;
+    ctl.nbig = base + (int)(t % 3);
+    ctl.nbig_prev = base + (int)((t + 2) % 3);
+    ctl.nbig_next = base + (int)((t + 1) % 3);
+    ctl.dcount = base + 3 + (int)(t & 1);
+    ctl.dcount_next = base + 3 + (int)((t + 1) & 1);
   }
-  if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, defer,
-                                  nbig, nbig_prev);
+  if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm,
+                                  frames ? &ctl : nullptr);
   if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, quad ? 1 : 0);
   if (stat) stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch failed");

@@ -134,20 +134,44 @@ __device__ unsigned long long g_quad_cnt[16];
 
 // QN: the frame -- the largest system a problem factorises here (32: every problem, k / 2 <= 32; 16: the form for settled
 // active sets, 12 waves per workgroup around ONE LDS image of HA and B and a third less registers: three waves per SIMD
-// instead of two; a problem that needs more marks itself in `defer` and is left, untouched, to a QN = 32 launch behind).
-// defer (may be null): QN = 16 writes 1 / 0 per problem; QN = 32 solves only the problems marked 1.
+// instead of two; a problem that needs more puts itself on a list and is left, untouched, to a QN = 32 launch behind).
+// QuadCtl (all null: every problem on this launch's frame): dlist / dcount -- the problems QN = 16 leaves to the QN = 32 launch
+// behind it, as a compact list (that launch returns before staging anything when the list is empty); nbig_* -- how many
+// problems of a half step START beyond 16 unknowns, this call's count, the previous call's (read) and the next call's
+// (zeroed here: no memset launches between the kernels).
+struct QuadCtl {
+  int* dlist;
+  int* dcount;            // this call's list length
+  int* dcount_next;       // the next call's: zeroed by the first launch of this call
+  int* nbig;              // this call's count
+  const int* nbig_prev;   // the previous call's
+  int* nbig_next;         // the next call's: zeroed likewise
+};
 template <int QN, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const double* __restrict__ Horig, const double* __restrict__ Hd,
                                                       const double* __restrict__ Bd,
                                                       int KP, int k, const float* __restrict__ F, int64_t f_sk,
                                                       int64_t f_sp, float* __restrict__ X, int64_t x_sk, int64_t x_sp,
-                                                      int64_t nprob, const int* __restrict__ warm_flag, int* __restrict__ defer,
-                                                      int* __restrict__ nbig, const int* __restrict__ nbig_prev) {
+                                                      int64_t nprob, const int* __restrict__ warm_flag, const QuadCtl ctl) {
+  int* const nbig = ctl.nbig;
+  const int* const nbig_prev = ctl.nbig_prev;
   constexpr int MB = QN / 16;                        // 16-row blocks of the frame
   // the previous half step of this kind met more than a tenth of its problems beyond a 16-slot frame (the first iterations
   // from a random start): the 16-slot launch hands everything on at once, the 32-slot launch counts for the next decision
   const bool all_big = nbig_prev != nullptr && 10 * (int64_t)(*nbig_prev) > nprob;
+  if (QN < 32 && blockIdx.x == 0 && threadIdx.x == 0) {               // (the first launch of a call: the next call's counters)
+    if (ctl.dcount_next) *ctl.dcount_next = 0;
+    if (ctl.nbig_next) *ctl.nbig_next = 0;
+  }
   if (*warm_flag == 0) return;                       // HA not safely positive definite: k_nnqp takes the half step
+  if (QN < 32 && all_big) return;                    // everything goes to the 32-slot launch behind
+  const bool listed = QN == 32 && ctl.dlist != nullptr && !all_big;   // this launch solves the problems of the list only
+  int64_t ntot = nprob;
+  if (listed) {
+    ntot = *ctl.dcount;
+    if (ntot == 0) return;                           // nothing was left over: not even the LDS images are staged
+  }
+  if ((int64_t)blockIdx.x * NW * QPW >= ntot) return;   // (a short list: the workgroups beyond it leave before staging, too)
   extern __shared__ __attribute__((aligned(16))) double qsm[];
   // [2][64][QLD]: 0 = HA, 1 = B.  Entry (c, t), t = 16 s + r, at c * QLD + (s / 2) * 32 + 2 r + s % 2: lane r's four
   // entries of a row are two 16-byte pieces, and the 16 lanes of a problem read 256 contiguous bytes per piece --
@@ -177,15 +201,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
   const int klive = __popcll(kmask);
 
   const int64_t nwaves = (int64_t)gridDim.x * NW;
-  for (int64_t base = ((int64_t)blockIdx.x * NW + wv) * QPW; base < nprob; base += nwaves * QPW) {
-    const int64_t prob = base + q;
-    const bool valid = prob < nprob && (QN < 32 || defer == nullptr || defer[prob < nprob ? prob : 0] != 0);
+  for (int64_t base = ((int64_t)blockIdx.x * NW + wv) * QPW; base < ntot; base += nwaves * QPW) {
+    const int64_t slot = base + q;
+    const bool valid = slot < ntot;
+    const int64_t prob = listed ? (int64_t)ctl.dlist[valid ? slot : 0] : slot;
     bool deferred = false;                           // QN = 16: this problem's system outgrew the frame
-    if (QN < 32 && all_big) {
-      if (defer != nullptr && prob < nprob && r == 0) defer[prob] = 1;
-      continue;
-    }
-    if (__ballot(valid) == 0ull) continue;           // (QN = 32 behind QN = 16: nothing of this wave's four was left over)
+    bool ever_big = false;
     // ---- this problem's right-hand side and warm start: variable 16 s + r in slot s of lane r ----
     double f[4], x[4];
     unsigned long long pm = 0ull;
@@ -241,9 +262,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
       // ---- lists of P and N (ascending), the form of the solve ----
       // The system's unknowns sit at positions shift .. 31 of a 32-slot frame (shift = 32 - ns, identity in front):
       // the factorisation can then START at the first position any of the wave's problems uses.
-      if (pass == 0 && nbig != nullptr && !done && r == 0 && (QN < 32 || defer == nullptr || all_big)) {   // how many problems START beyond
-        const int np0 = __popcll(pm);                              // a 16-slot frame: the next half step's choice of the form
-        if (min(np0, klive - np0) > 16) atomicAdd(nbig, 1);
+      if (!done) {                                   // (for the next half step's choice of the form: did this problem EVER go beyond 16?)
+        const int np0 = __popcll(pm);
+        if (min(np0, klive - np0) > 16) ever_big = true;
       }
       if (QN < 32 && !done) {                        // does the smaller of |P|, |N| still fit the frame?
         const int np0 = __popcll(pm);
@@ -496,14 +517,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
         if (v < k) X[(int64_t)v * x_sk + prob * x_sp] = (float)(((pm >> v) & 1ull) ? x[s] : 0.0);
       }
     }
-    if (QN < 32 && defer != nullptr && prob < nprob && r == 0) defer[prob] = deferred ? 1 : 0;
+    if (QN < 32 && ctl.dlist != nullptr && deferred && r == 0) ctl.dlist[atomicAdd(ctl.dcount, 1)] = (int)prob;
+    // counted by the launch that sees the problem first (the listed ones were counted when they were put on the list)
+    if (nbig != nullptr && valid && ever_big && r == 0 && (QN < 32 || ctl.dlist == nullptr || all_big)) atomicAdd(nbig, 1);
   }
 }
 
 template <int QN, int NW>
 static inline int launch_nnqp_quad_t(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
-                                     int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, int* defer, int* nbig,
-                                     const int* nbig_prev) {
+                                     int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, const QuadCtl& ctl) {
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[pmf_current_device()];
   const size_t smem = nnqp_quad_smem_bytes<QN, NW>();
@@ -517,19 +539,18 @@ static inline int launch_nnqp_quad_t(hipStream_t s, int KP, int k, const double*
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_nnqp_quad<QN, NW>), dim3((unsigned)blocks), dim3(64 * NW), smem, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm,
-                     defer, nbig, nbig_prev);
+                     ctl);
   return PMF_OK;
 }
 
-// defer == nullptr: every problem on the 32-slot frame (one launch).  Else: the 16-slot frame first (three waves per SIMD),
-// then the 32-slot frame for the problems it marked.
+// ctl == nullptr: every problem on the 32-slot frame (one launch).  Else: the 16-slot frame first (three waves per SIMD),
+// then the 32-slot frame for the problems it listed.
 static inline int launch_nnqp_quad(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
-                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, int* defer = nullptr,
-                                   int* nbig = nullptr, const int* nbig_prev = nullptr) {
-  if (defer) {      // nbig (may be null): += the problems whose first system is beyond 16 unknowns, counted by the launch that sees them first
-    const int rc = launch_nnqp_quad_t<16, 12>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, defer, nbig, nbig_prev);
+                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, const QuadCtl* ctl = nullptr) {
+  if (ctl) {
+    const int rc = launch_nnqp_quad_t<16, 12>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl);
     if (rc != PMF_OK) return rc;
-    return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, defer, nbig, nbig_prev);
+    return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl);
   }
-  return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, nullptr, nbig, nullptr);
+  return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, QuadCtl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 }

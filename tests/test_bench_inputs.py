@@ -51,42 +51,3 @@ def test_gen_csr_row_blocks_partition_the_matrix():
         np.testing.assert_array_equal(np.concatenate(cols), ix)
         np.testing.assert_array_equal(np.concatenate(vals), vv)
         assert rows == m
-
-
-@pytest.mark.gpu
-def test_two_rank_bench_line_on_one_gpu():
-    """The N > 1 harness end to end on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py
-    --gpus 2 --debug-share-gpu` (both ranks on device 0, each with its own 1-rank RCCL communicator: rows still
-    sharded, barriers and the max over ranks still used).  Rank 0 prints ONE line; both ranks' own step times are
-    in it and agree (same work, same GPU), and `value` is K over the slowest."""
-    import json
-    import socket
-    import subprocess
-    import sys
-    def free_port():
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        return port
-
-    errs = []
-    for attempt in range(3):        # the rendezvous port is picked, released and re-bound by the launcher: a rare race
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
-               "--rows", "131072", "--fill", "device", "--debug-share-gpu", "--no-cpu-baseline", "--preroll-ms", "20"]
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
-                           env=dict(os.environ, OMP_NUM_THREADS="4"))
-        if p.returncode == 0:
-            break
-        errs.append(p.stderr.decode()[-1500:])
-        print("attempt %d of the two-rank launch failed:\n%s" % (attempt, errs[-1]))
-    assert p.returncode == 0, "\n----\n".join(errs)
-    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout.decode()
-    j = lines[0]
-    assert j["n_gpus"] == 2 and j["steps"] == 20 and len(j["rank_ms_per_step"]) == 2
-    a, b = j["rank_ms_per_step"]
-    assert abs(a - b) <= 0.5 * max(a, b), j["rank_ms_per_step"]       # two processes time-slicing one GPU
-    assert abs(j["ms_per_step"] - max(a, b)) < 1e-9 and abs(j["value"] - 1e3 / max(a, b)) < 1e-6 * j["value"]
-    assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None

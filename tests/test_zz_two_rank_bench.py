@@ -1,0 +1,58 @@
+"""The N > 1 bench harness end to end on a 1-GPU box.  Kept in a module of its own that sorts LAST: the launcher it drives
+(`python -m torch.distributed.run`, a rendezvous port picked and released by the test) failed to come up twice in some
+fifteen full runs of the suite on fresh boxes and never when run on its own -- with `pytest -x` a launcher hiccup in the first
+module would hide every test behind it."""
+import os
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_line_on_one_gpu():
+    """The N > 1 harness end to end on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 --debug-share-gpu` (both ranks on device 0, each with its own 1-rank RCCL communicator: rows still
+    sharded, barriers and the max over ranks still used).  Rank 0 prints ONE line; both ranks' own step times are
+    in it and agree (same work, same GPU), and `value` is K over the slowest."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    errs = []
+    for attempt in range(5):        # the rendezvous port is picked, released and re-bound by the launcher: a rare race
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+               "--rows", "131072", "--fill", "device", "--debug-share-gpu", "--no-cpu-baseline", "--preroll-ms", "20"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                           env=dict(os.environ, OMP_NUM_THREADS="4"))
+        if p.returncode == 0:
+            break
+        time.sleep(2.0)
+        errs.append(p.stderr.decode()[-3000:])
+        print("attempt %d of the two-rank launch failed:\n%s" % (attempt, errs[-1]))
+        try:                                             # (kept for the post-mortem when the run's output is not)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "two_rank_launch_failures.txt"), "a") as fh:
+                fh.write("---- attempt %d\n%s\n" % (attempt, errs[-1]))
+        except OSError:
+            pass
+    assert p.returncode == 0, "\n----\n".join(errs)
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and len(j["rank_ms_per_step"]) == 2
+    a, b = j["rank_ms_per_step"]
+    assert abs(a - b) <= 0.5 * max(a, b), j["rank_ms_per_step"]       # two processes time-slicing one GPU
+    assert abs(j["ms_per_step"] - max(a, b)) < 1e-9 and abs(j["value"] - 1e3 / max(a, b)) < 1e-6 * j["value"]
+    assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None
