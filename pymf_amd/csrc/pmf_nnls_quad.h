@@ -31,8 +31,15 @@
 // Every pass of the wave's loop is ONE solve for each of its 4 problems followed by the exchange; a problem that
 // has finished idles until the wave's 4 are done.
 //
+// TWO FRAMES (template QN, NW): the kernel is a row of latency chains, so its throughput is its waves per SIMD
+// (256 / 384 / 512 workgroups of the 32-slot form: 0.84 / 0.62 / 0.48 ms at cfg3).  <32, 4>: the 32-slot frame above, 234
+// registers and its own 68 KiB image of HA and B per four-wave workgroup -- two waves per SIMD twice over.  <16, 12>: a
+// 16-slot frame (16 doubles per lane, 168 registers) and twelve waves around ONE image -- three waves per SIMD; once the
+// active sets have settled a problem factorises about 8 unknowns.  A problem that outgrows 16 puts itself on a list
+// and the <32, 4> launch behind solves the list (QuadCtl); bit-identical results (same lanes, same order).
+//
 // Preconditions (the host checks them, k_nnqp serves the rest): k <= 64, and *warm_flag != 0, i.e.
-// k_spd_unique found HA positive definite and well conditioned -- then B exists and every principal block of
+// k_inverse_spd_mfma's pivots (or k_spd_unique) found HA positive definite and well conditioned -- then B exists and every principal block of
 // HA and of B is positive definite too.
 #pragma once
 #include <type_traits>
