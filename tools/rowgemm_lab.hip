@@ -346,10 +346,17 @@ int main(int argc, char** argv) {
   }
   for (int it = 0; it < 6; ++it) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_rowgemm_stream<NT, 4, EPI_STORE>), dim3((ntiles64 + 3) / 4), dim3(256), smem, 0, A, (int64_t)K, K, B, (int64_t)K, (float*)nullptr, (const float*)nullptr, C2, (int64_t)KP, 0.f, m, KP, ntiles64, (int64_t)KP);
+    hipLaunchKernelGGL((k_rowgemm_stream<NT, 4, EPI_STORE>), dim3(512), dim3(256), smem, 0, A, (int64_t)K, K, B, (int64_t)K, (float*)nullptr, (const float*)nullptr, C2, (int64_t)KP, 0.f, m, KP, ntiles64, (int64_t)KP);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (it >= 3) printf("k_rowgemm_stream<4,4>: %.3f ms  %.1f TFLOP/s\n", ms, flop / ms / 1e9);
+  }
+  for (int it = 0; it < 6; ++it) {       // 32-row wave tiles: half the registers, twice the waves
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_rowgemm_stream<NT, 2, EPI_STORE>), dim3(512), dim3(256), smem, 0, A, (int64_t)K, K, B, (int64_t)K, (float*)nullptr, (const float*)nullptr, C2, (int64_t)KP, 0.f, m, KP, (int)(m / 32), (int64_t)KP);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 3) printf("k_rowgemm_stream<4,2>: %.3f ms  %.1f TFLOP/s\n", ms, flop / ms / 1e9);
   }
   {
     unsigned long long ha[8][4];
