@@ -30,6 +30,7 @@
 #include "pmf_coop.h"
 #include "pmf_nnls.h"
 #include "pmf_nnls_quad.h"
+#include "pmf_nnls_wave.h"
 #include "pmf_inv.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
@@ -104,6 +105,7 @@ struct pmf_ctx {
   int64_t defer_cap = 0;
   int* dNbig = nullptr;         // [2 sites][3 + 2]: rotating counters of k_nnqp_quad (QuadCtl: nbig x 3, dcount x 2)
   int64_t quad_calls[2] = {0, 0};
+  int opt_nnqp_wave = 1;        // pmf_set_option("nnqp_wave"): 64 < num_bases <= 128 on the wave-per-problem block-pivoting kernel
   int opt_nnqp_frame16 = 1;     // pmf_set_option("nnqp_frame16"): the 16-slot frame first (three waves per SIMD)
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
   bool wsnap_valid = false;
@@ -1518,6 +1520,8 @@ int nnqp_warm_flag(pmf_ctx* c, hipStream_t s) {   // dWarm[0] = 1 iff the QPs ov
 bool nnqp_use_quad(const pmf_ctx* c, int64_t nprob) {
   return c->opt_nnqp_quad && c->k <= 64 && (nprob >= 16384 || c->opt_nnqp_quad == 2);
 }
+// 64 < num_bases <= 128: k_nnqp_wave (pmf_nnls_wave.h) on B = inv(HA), whatever the number of problems
+bool nnqp_use_wave(const pmf_ctx* c) { return c->opt_nnqp_wave && c->k > 64 && c->k <= 128; }
 
 // What a half step's QPs need from HA = dGd alone, on stream s: the uniqueness flag and, for k_nnqp_quad,
 // B = inv(HA with its dead variables patched out).  k x k sized kernels, 36 + 2 + 18 us at k = 64.
@@ -1528,7 +1532,8 @@ int nnqp_prepare(pmf_ctx* c, hipStream_t s, bool quad) {
     if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
     double* Hp = c->dBinv + (size_t)c->KP * c->KP;
     hipLaunchKernelGGL(k_nnqp_patch_dead, dim3(1), dim3(256), 0, s, c->dGd, c->KP, c->k, Hp);
-    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
+    if (c->k <= 64) hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
+    else hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
     HIPCHK(c, hipGetLastError());
     return PMF_OK;
   }
@@ -1552,8 +1557,8 @@ int nnqp_scratch(pmf_ctx* c, double** out) {
 // selects on the device, without a host round trip) k_nnqp / k_nnqp_big.
 int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, bool stat,
                 bool prepared = false) {
-  const bool quad = nnqp_use_quad(c, nprob);
-  if (!prepared) PMFCHK(nnqp_prepare(c, c->stream, quad));
+  const bool quad = nnqp_use_quad(c, nprob), wave = nnqp_use_wave(c);
+  if (!prepared) PMFCHK(nnqp_prepare(c, c->stream, quad || wave));
   double* qp = nullptr;
   PMFCHK(nnqp_scratch(c, &qp));
   if (stat) stat_begin(c, SITE_NNQP_W);
@@ -1587,7 +1592,8 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
   }
   if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm,
                                   frames ? &ctl : nullptr);
-  if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, quad ? 1 : 0);
+  if (wave) rc = launch_nnqp_wave(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm);
+  if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, (quad || wave) ? 1 : 0);
   if (stat) stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch failed");
   HIPCHK(c, hipGetLastError());
@@ -1806,6 +1812,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
     st.site = SITE_NNQP_W;
     if (c->opt_nnqp_quad && c->k <= 64 && (c->m >= 16384 || c->opt_nnqp_quad == 2)) snprintf(buf, sizeof(buf), "k_nnqp_quad(update_w)");
     else if (c->k <= 64) snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
+    else if (nnqp_use_wave(c)) snprintf(buf, sizeof(buf), "k_nnqp_wave(update_w)");
     else snprintf(buf, sizeof(buf), "k_nnqp_big<%d>(update_w)", nnqp_big_vpl(c->k));
     st.name = buf;
     st.bytes = 4.0 * (3.0 * m * k);               // right-hand sides read, warm start read, solution written
@@ -1857,6 +1864,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   if (const char* e = std::getenv("PMF_COLGEMM_STREAM")) c->opt_colgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("colgemm_stream")
   if (const char* e = std::getenv("PMF_RESID_RESIDENT")) c->opt_resid_resident = std::atoi(e) != 0;
   if (const char* e = std::getenv("PMF_ROWGEMM_STREAM")) c->opt_rowgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("rowgemm_stream")
+  if (const char* e = std::getenv("PMF_NNQP_WAVE")) c->opt_nnqp_wave = std::atoi(e) != 0;   // as pmf_set_option("nnqp_wave")
   if (const char* e = std::getenv("PMF_NNQP_FRAME16")) c->opt_nnqp_frame16 = std::atoi(e) != 0;   // as pmf_set_option("nnqp_frame16")
   if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
@@ -2630,6 +2638,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
     if (c->g_parts > 0) { c->g_valid = false; c->g_parts = 0; }
     choose_stat_site(c, false);
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "nnqp_wave") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "nnqp_wave: 0 or 1");
+    c->opt_nnqp_wave = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "nnqp_frame16") == 0) {

@@ -355,10 +355,11 @@ __global__ __launch_bounds__(64) void k_nnqp_big(const double* __restrict__ Hd, 
                                                  const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
                                                  float* __restrict__ X, int64_t x_sk, int64_t x_sp,
                                                  int64_t nprob, const int* __restrict__ warm_flag,
-                                                 double* __restrict__ scratch) {
+                                                 double* __restrict__ scratch, int skip_if_warm) {
   constexpr int KS = 64 * VPL;
   __shared__ double vb[KS];
   const bool warm = warm_flag != nullptr && *warm_flag != 0;
+  if (skip_if_warm && warm) return;                  // k_nnqp_wave (pmf_nnls_wave.h) has taken the half step
   const int t = threadIdx.x;
   double* __restrict__ A = scratch + (size_t)blockIdx.x * KS * KS;
   bool act[VPL];
@@ -608,10 +609,10 @@ static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, co
     if (!scratch || k > 1024) return PMF_EINVAL;
     const unsigned blocks = (unsigned)nnqp_big_blocks(k, nprob);
     switch (nnqp_big_vpl(k)) {
-      case 2: hipLaunchKernelGGL((k_nnqp_big<2>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
-      case 4: hipLaunchKernelGGL((k_nnqp_big<4>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
-      case 8: hipLaunchKernelGGL((k_nnqp_big<8>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
-      default: hipLaunchKernelGGL((k_nnqp_big<16>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch); break;
+      case 2: hipLaunchKernelGGL((k_nnqp_big<2>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch, skip_if_warm); break;
+      case 4: hipLaunchKernelGGL((k_nnqp_big<4>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch, skip_if_warm); break;
+      case 8: hipLaunchKernelGGL((k_nnqp_big<8>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch, skip_if_warm); break;
+      default: hipLaunchKernelGGL((k_nnqp_big<16>), dim3(blocks), dim3(64), 0, s, Hd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, scratch, skip_if_warm); break;
     }
     return PMF_OK;
   }
