@@ -148,10 +148,11 @@ def test_als_wide_vs_float64_oracle(pm, cls_name, shape, k, hooks):
     assert abs(mdl.frobenius_norm() - o.frobenius_norm()) <= 1e-5 * max(o.frobenius_norm(), 1.0)
 
 
-def test_nnqp_big_equals_register_kernel(pm):
-    """The generic QP kernel and the register-resident one implement the same pivoting rules: on a k = 64 problem
-    solved as-is and embedded in a 65-variable problem whose extra variable can never enter (f = -1), the first
-    64 coordinates agree to rounding."""
+@pytest.mark.parametrize("wave", [0, 1])
+def test_nnqp_big_equals_register_kernel(pm, wave):
+    """The kernels beyond 64 bases (k_nnqp_big, one variable at a time; k_nnqp_wave, block principal pivoting) end at
+    the KKT point of the register-resident one: on a k = 64 problem solved as-is and embedded in a 65-variable problem
+    whose extra variable is a dead basis, the first 64 coordinates agree to rounding."""
     from pymf_amd import _lib
     rs = np.random.RandomState(4)
     m, n = 900, 120
@@ -163,12 +164,37 @@ def test_nnqp_big_equals_register_kernel(pm):
         if k == 65:
             H[64] = 0.0                                      # dead basis: zero row of H H^T, stays out
         ctx = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+        ctx.set_option("nnqp_wave", wave)
         ctx.set_v_dense(V); ctx.set_w(np.zeros((m, k), dtype=np.float32)); ctx.set_h(H)
         ctx.update_w()
         outs.append(ctx.get_w())
         ctx.close()
     assert np.all(outs[1][:, 64] == 0.0)
-    assert rel_fro(outs[1][:, :64], outs[0], what="k_nnqp_big vs k_nnqp") < 1e-9
+    assert rel_fro(outs[1][:, :64], outs[0], what="beyond-64 kernel vs k_nnqp") < (1e-6 if wave else 1e-9)
+
+
+@pytest.mark.parametrize("m,n,k,zero_rows", [(3000, 300, 128, 0), (2000, 260, 72, 0), (1500, 400, 100, 3), (700, 900, 127, 1)])
+def test_nnqp_wave_equals_nnqp_big(pm, m, n, k, zero_rows):
+    """k_nnqp_wave (pmf_nnls_wave.h) against k_nnqp_big over whole iterations from a cold start and warm: both half
+    steps, dead bases (zero rows of H), data with structural zeros.  The QPs are strictly convex: one KKT point."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(m + k)
+    V = (rs.random_sample((m, n)) * (rs.random_sample((m, n)) < 0.6)).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = rs.random_sample((k, n)).astype(np.float32)
+    H0[:zero_rows] = 0.0
+    res = []
+    for wave in (0, 1):
+        ctx = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+        ctx.set_option("nnqp_wave", wave)
+        ctx.set_v_dense(V); ctx.set_w(W0); ctx.set_h(H0)
+        ferr, done, _ = ctx.factorize(4, compute_err=True, conv_eps=0.0)
+        res.append((ctx.get_w(), ctx.get_h(), np.asarray(ferr[:done], dtype=np.float64)))
+        ctx.close()
+    (Wb, Hb, fb), (Ww, Hw, fw) = res
+    close(fw, fb, rtol=2e-6, what="ferr: wave vs big")
+    assert rel_fro(Ww, Wb, what="W: wave vs big") < 1e-4 and rel_fro(Hw, Hb, what="H: wave vs big") < 1e-4
+    assert Ww.min() >= 0.0 and Hw.min() >= 0.0 and np.isfinite(Ww).all() and np.isfinite(Hw).all()
 
 
 def test_rnmf_wide_vs_float64_oracle(pm):
