@@ -8,26 +8,55 @@
 // step, the SMALLER of HA[P,P] / B[N,N] factorised per problem, block principal pivoting with Murty's rule as the
 // safeguard -- the same rules, tolerances and pass limits) at a wave per problem:
 //   * lane t owns variables t and t + 64, so the passive set is two ballots;
-//   * the system has at most k / 2 <= 64 unknowns whatever the support: its LDL^T lives in a 64 x 65 LDS image of the
-//     wave's own (left-looking, lane = row: a column is one register accumulation over two LDS reads per term, the
-//     pivot row U = L D kept in the upper triangle so that its entry is ONE broadcast read);
+//   * the system has at most k / 2 <= 64 unknowns whatever the support: row i of its LDL^T factor lives in the REGISTERS
+//     of lane i (64 doubles, every index a constant of the program text: straight-line code as in k_nnqp_quad); a step's
+//     pivot column crosses the lanes through one 64-double LDS line (one write, broadcast reads).  A first form with the
+//     factor in a 64 x 65 LDS image (left-looking, 35 KiB: one wave per SIMD) took 7.5-12 ms where this one takes
+//     (profiles/r03_experiments.md);
 //   * products with HA / B read rows of the shared matrices from L2 (128 KiB each: beyond LDS), coalesced.
 // Preconditions as k_nnqp_quad: *warm_flag != 0 (k_inverse_spd_mfma's pivots found HA positive definite and well
 // conditioned); otherwise the kernel returns at once and k_nnqp_big takes the half step.
 #pragma once
 #include "pmf_dev.h"
 #include "pmf_nnls.h"
+#include "pmf_nnls_quad.h"   // static_for
 
 constexpr int WVN = 64;            // largest system a problem factorises (k <= 128)
-constexpr int WVLD = 65;           // LDS row stride of the factor in doubles
 
-__global__ __launch_bounds__(64) void k_nnqp_wave(const double* __restrict__ Horig, const double* __restrict__ Hd,
+// a0 += sum_p coef(p) M[row(p)][t], a1 += ... M[row(p)][t + 64] over the positions p < ns of the system's list; coef(p) is
+// cv[row(p)] (BYVAR) or cv[p].  EIGHT rows -- sixteen requests -- go out together: the rows come from L2 (the matrices are
+// 128 KiB each) and a wave is alone on its SIMD, so the requests in flight are the whole of its latency hiding
+// (two rows at a time: 12 ms for 65 536 problems at k = 128; eight: see profiles/r03_experiments.md).
+template <bool BYVAR, bool NEG>
+__device__ __forceinline__ void wv_rows_dot(const double* __restrict__ M, int KP, int t, const int* lst, const double* cv, int ns,
+                                            double& a0, double& a1) {
+  for (int p = 0; p < ns; p += 8) {
+    int c[8];
+    double m[8], v0[8], v1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = p + e < ns;
+      c[e] = ok ? lst[p + e] : 0;
+      const double mv = ok ? cv[BYVAR ? c[e] : p + e] : 0.0;
+      m[e] = NEG ? -mv : mv;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double* r = M + (int64_t)c[e] * KP + t;
+      v0[e] = r[0]; v1[e] = r[64];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a0 = fma(v0[e], m[e], a0); a1 = fma(v1[e], m[e], a1); }
+  }
+}
+
+__global__ __launch_bounds__(64, 2) void k_nnqp_wave(const double* __restrict__ Horig, const double* __restrict__ Hd,
                                                   const double* __restrict__ Bd, int KP, int k,
                                                   const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
                                                   float* __restrict__ X, int64_t x_sk, int64_t x_sp, int64_t nprob,
                                                   const int* __restrict__ warm_flag) {
   if (*warm_flag == 0) return;
-  __shared__ double S[WVN * WVLD];
+  __shared__ double vecP[2 * WVN]; // the pivot column of a factorisation step, double buffered
   __shared__ double vecV[128];     // f, then (complement form) y, by variable
   __shared__ double vecC[WVN];     // mu by position
   __shared__ int lst[WVN];         // the variable at each position of the system
@@ -87,111 +116,90 @@ __global__ __launch_bounds__(64) void k_nnqp_wave(const double* __restrict__ Hor
       double y[2] = {0.0, 0.0};
       if (comp) {
         if (!have_y0) {
-          double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-          for (int c = 0; c < k; c += 2) {
-            const bool l0 = (live[c >> 6] >> (c & 63)) & 1ull, l1 = c + 1 < k && ((live[(c + 1) >> 6] >> ((c + 1) & 63)) & 1ull);
-            const double f0 = l0 ? vecV[c] : 0.0, f1 = l1 ? vecV[c + 1] : 0.0;
-            const double* r0 = Bd + (int64_t)c * KP + t;
-            const double* r1 = Bd + (int64_t)(c + 1 < k ? c + 1 : c) * KP + t;
-            a0 = fma(r0[0], f0, a0); a1 = fma(r0[64], f0, a1);
-            b0 = fma(r1[0], f1, b0); b1 = fma(r1[64], f1, b1);
+          double a0 = 0.0, a1 = 0.0;
+          for (int c0 = 0; c0 < k; c0 += 16) {         // sixteen rows, 32 requests, together
+            double fc[16], v0[16], v1[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int c = c0 + e;
+              const bool lv = c < k && ((live[c >> 6] >> (c & 63)) & 1ull);
+              fc[e] = lv ? vecV[c] : 0.0;
+              const double* r = Bd + (int64_t)(c < k ? c : 0) * KP + t;
+              v0[e] = r[0]; v1[e] = r[64];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a0 = fma(v0[e], fc[e], a0); a1 = fma(v1[e], fc[e], a1); }
           }
-          y0[0] = a0 + b0; y0[1] = a1 + b1;
+          y0[0] = a0; y0[1] = a1;
           have_y0 = true;
         }
-        double a0 = y0[0], a1 = y0[1], b0 = 0.0, b1 = 0.0;
-        int p = 0;
-        for (; p + 1 < ns; p += 2) {
-          const int c0 = lst[p], c1 = lst[p + 1];
-          const double f0 = vecV[c0], f1 = vecV[c1];
-          const double* r0 = Bd + (int64_t)c0 * KP + t;
-          const double* r1 = Bd + (int64_t)c1 * KP + t;
-          a0 = fma(-r0[0], f0, a0); a1 = fma(-r0[64], f0, a1);
-          b0 = fma(-r1[0], f1, b0); b1 = fma(-r1[64], f1, b1);
-        }
-        if (p < ns) {
-          const int c0 = lst[p];
-          const double f0 = vecV[c0];
-          const double* r0 = Bd + (int64_t)c0 * KP + t;
-          a0 = fma(-r0[0], f0, a0); a1 = fma(-r0[64], f0, a1);
-        }
-        y[0] = a0 + b0; y[1] = a1 + b1;
+        y[0] = y0[0]; y[1] = y0[1];
+        wv_rows_dot<true, true>(Bd, KP, t, lst, vecV, ns, y[0], y[1]);
         __syncthreads();
         vecV[t] = y[0]; vecV[t + 64] = y[1];
         __syncthreads();
       }
-      // ---- the system: M[S,S] into the LDS image (row = position), the right-hand side by position in lane = position ----
-      const int myvar = t < ns ? lst[t] : 0;
+      // ---- the system, right-aligned in a 64-slot frame (positions shift .. 63, identity in front: the factorisation
+      //      starts at the first position in use); row i of M[S,S] in the REGISTERS of lane i, every index a constant of
+      //      the program text; all 64 requests of a row go out together ----
+      const int shift = WVN - ns;
+      // (the lane number behind an opaque move: LLVM otherwise hoists the 64 identity entries and the 2 x 63 lane masks below
+      //  out of the problem loop and spills them -- 64 doubles of scratch, 414 SGPR spills)
+      int tt = t;
+      asm volatile("" : "+v"(tt));
+      const bool on_t = t >= shift;
+      const int myvar = on_t ? lst[t - shift] : 0;
       double b = 0.0;
-      if (t < ns) b = comp ? -vecV[myvar] : vecV[myvar];
-      {
-        int i = 0;
-        for (; i + 3 < ns; i += 4) {
-          const int r0 = lst[i], r1 = lst[i + 1], r2 = lst[i + 2], r3 = lst[i + 3];
-          const double v0 = Msel[(int64_t)r0 * KP + myvar], v1 = Msel[(int64_t)r1 * KP + myvar];
-          const double v2 = Msel[(int64_t)r2 * KP + myvar], v3 = Msel[(int64_t)r3 * KP + myvar];
-          S[(i + 0) * WVLD + t] = v0; S[(i + 1) * WVLD + t] = v1; S[(i + 2) * WVLD + t] = v2; S[(i + 3) * WVLD + t] = v3;
-        }
-        for (; i < ns; ++i) S[i * WVLD + t] = Msel[(int64_t)lst[i] * KP + myvar];
-      }
-      __syncthreads();
-      // ---- LDL^T, left-looking: column j of lane t >= j is a_tj - sum_p L[t][p] U[j][p], U[j][p] = d_p L[j][p] at S[p][j] ----
+      if (on_t) b = comp ? -vecV[myvar] : vecV[myvar];
+      double Lr[WVN];
+      static_for<0, WVN>([&](auto cc_) {
+        constexpr int c = decltype(cc_)::value;
+        const int rv = c >= shift ? lst[c - shift] : 0;
+        // (a 32-bit offset from the uniform base: one address register per request, not two -- 64 requests are in flight)
+        const double val = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Msel) + (unsigned)(rv * KP + myvar) * 8u);
+        Lr[c] = (on_t && c >= shift) ? val : (c == tt ? 1.0 : 0.0);
+      });
+      // ---- LDL^T, right-looking: step j scales column j and takes l_ij a_cj off every later column c; a_cj = A[c][j]
+      //      (symmetry: lane c's own entry j) reaches all lanes through a 64-double LDS line, ONE write and broadcast reads ----
       double dv = 1.0;
-      for (int j = 0; j < ns; ++j) {
-        const double* Lrow = S + t * WVLD;
-        const double* Ucol = S + j;
-        double a0 = Lrow[j], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int p = 0;
-        for (; p + 3 < j; p += 4) {
-          a0 = fma(-Lrow[p], Ucol[p * WVLD], a0);
-          a1 = fma(-Lrow[p + 1], Ucol[(p + 1) * WVLD], a1);
-          a2 = fma(-Lrow[p + 2], Ucol[(p + 2) * WVLD], a2);
-          a3 = fma(-Lrow[p + 3], Ucol[(p + 3) * WVLD], a3);
+      static_for<0, WVN>([&](auto jc_) {
+        constexpr int j = decltype(jc_)::value;
+        if (j >= shift) {
+          double* col = vecP + (j & 1) * WVN;
+          col[t] = Lr[j];
+          __syncthreads();
+          const double dj = col[j];
+          const double inv = pmf_rcp_f64(dj);
+          const double lij = Lr[j] * inv;
+          if (tt == j) dv = dj;
+          static_for<j + 1, WVN>([&](auto cc_) {
+            constexpr int c = decltype(cc_)::value;
+            Lr[c] = fma(-lij, col[c], Lr[c]);
+          });
+          Lr[j] = lij;
         }
-        for (; p < j; ++p) a0 = fma(-Lrow[p], Ucol[p * WVLD], a0);
-        const double a = (a0 + a1) + (a2 + a3);
-        const double dj = readlane_f64(a, j);
-        const double inv = pmf_rcp_f64(dj);
-        if (t == j) dv = dj;
-        if (t > j && t < ns) {                       // (row j beyond the diagonal and column j below it: read by no lane in this step)
-          S[j * WVLD + t] = a;                       // U[t][j]
-          S[t * WVLD + j] = a * inv;                 // L[t][j]
-        }
-        __syncthreads();
-      }
+      });
       // ---- L z = b, z / d, L^T mu = z ----
-      for (int j = 0; j < ns; ++j) {
-        const double zj = readlane_f64(b, j);
-        if (t > j && t < ns) b = fma(-S[t * WVLD + j], zj, b);
-      }
+      static_for<0, WVN - 1>([&](auto jc_) {
+        constexpr int j = decltype(jc_)::value;
+        if (j >= shift) {
+          const double zj = readlane_f64(b, j);
+          b = fma(-(tt > j ? Lr[j] : 0.0), zj, b);
+        }
+      });
       b *= pmf_rcp_f64(dv);
-      for (int j = ns - 1; j >= 0; --j) {
-        const double mj = readlane_f64(b, j);
-        if (t < j) b = fma(-S[j * WVLD + t], mj, b);
-      }
-      if (t < ns) vecC[t] = b;
+      static_for<1, WVN>([&](auto jr_) {
+        constexpr int j = WVN - 1 - decltype(jr_)::value;
+        if (j >= shift) {
+          const double tot = wave_sum_f64(tt > j ? Lr[j] * b : 0.0);
+          if (tt == j) b -= tot;
+        }
+      });
+      if (on_t) vecC[t - shift] = b;
       __syncthreads();
       // ---- z = M[:, S] mu over this lane's 2 variables ----
-      double z[2];
-      {
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        int p = 0;
-        for (; p + 1 < ns; p += 2) {
-          const int c0 = lst[p], c1 = lst[p + 1];
-          const double m0 = vecC[p], m1 = vecC[p + 1];
-          const double* r0 = Msel + (int64_t)c0 * KP + t;
-          const double* r1 = Msel + (int64_t)c1 * KP + t;
-          a0 = fma(r0[0], m0, a0); a1 = fma(r0[64], m0, a1);
-          b0 = fma(r1[0], m1, b0); b1 = fma(r1[64], m1, b1);
-        }
-        if (p < ns) {
-          const int c0 = lst[p];
-          const double m0 = vecC[p];
-          const double* r0 = Msel + (int64_t)c0 * KP + t;
-          a0 = fma(r0[0], m0, a0); a1 = fma(r0[64], m0, a1);
-        }
-        z[0] = a0 + b0; z[1] = a1 + b1;
-      }
+      double z[2] = {0.0, 0.0};
+      wv_rows_dot<false, false>(Msel, KP, t, lst, vecC, ns, z[0], z[1]);
       // ---- candidate solution s and dual w per variable, then block principal pivoting (k_nnqp_quad's rules) ----
       //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)
       //   primal:     P: s = mu(t), w = 0;   N: s = 0, w = f - z
@@ -237,7 +245,7 @@ static inline int launch_nnqp_wave(hipStream_t s, int KP, int k, const double* H
                                    int64_t f_sk, int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm) {
   if (k <= 64 || k > 128) return PMF_EINVAL;
   int64_t blocks = nprob;
-  if (blocks > 256 * 4) blocks = 256 * 4;              // four 35 KiB images per CU
+  if (blocks > 256 * 8) blocks = 256 * 8;              // two waves per SIMD (registers)
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_nnqp_wave, dim3((unsigned)blocks), dim3(64), 0, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm);
   return PMF_OK;
