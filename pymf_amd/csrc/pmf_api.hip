@@ -105,6 +105,8 @@ struct pmf_ctx {
   int64_t defer_cap = 0;
   int* dNbig = nullptr;         // [2 sites][3 + 2]: rotating counters of k_nnqp_quad (QuadCtl: nbig x 3, dcount x 2)
   int64_t quad_calls[2] = {0, 0};
+  double* dY0 = nullptr;        // k_nnqp_wave: inv(HA) f of every problem of a half step
+  int64_t y0_cap = 0;
   int opt_nnqp_wave = 1;        // pmf_set_option("nnqp_wave"): 64 < num_bases <= 128 on the wave-per-problem block-pivoting kernel
   int opt_nnqp_frame16 = 1;     // pmf_set_option("nnqp_frame16"): the 16-slot frame first (three waves per SIMD)
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
@@ -1592,7 +1594,14 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
   }
   if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm,
                                   frames ? &ctl : nullptr);
-  if (wave) rc = launch_nnqp_wave(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm);
+  if (wave) {
+    if (c->y0_cap < nprob) {                         // y0 = inv(HA) f of every problem (k_nnqp_y0): [nprob][KP] float64
+      if (c->dY0) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->dY0)); c->dY0 = nullptr; }
+      PMFCHK(dalloc(c, &c->dY0, (size_t)nprob * c->KP));
+      c->y0_cap = nprob;
+    }
+    rc = launch_nnqp_wave(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, c->dY0);
+  }
   if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, (quad || wave) ? 1 : 0);
   if (stat) stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch failed");
@@ -1978,7 +1987,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);

@@ -5,7 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$1; K=$2; shift 3
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc -- python3 "$@" > /dev/null 2>&1
+PMC=${PMC:-SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE}   # PMC="..." overrides the counter list
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc -- python3 "$@" > /dev/null 2>&1
 python3 - $O "$K" <<'PY'
 import csv, glob, sys, collections
 O, K = sys.argv[1], sys.argv[2]

@@ -7,7 +7,7 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pymf_amd import _lib
-m, n, k = 262144, 1024, 64
+m, n, k = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (262144, 1024, 64)   # k > 64: k_nnqp_wave's counters (sizes / 8)
 ctx = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
 ctx.fill_v_uniform(1234); ctx.fill_w_uniform(42); ctx.fill_h_uniform(43)
 lib = ctx._lib
