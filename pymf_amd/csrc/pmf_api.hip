@@ -2374,7 +2374,7 @@ int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
     // what the W step of every tile needs from H: G = H H^T (NMF, BNMF); M^T = inv(H H^T) H (SNMF, snmf.py:67-70);
     // the Hessian H H^T in float64 + the warm-start verdict (NMFALS, nmfals.py:85-97)
     if (c->algo == PMF_ALGO_SNMF) PMFCHK(snmf_inverse(c));
-    else if (c->algo == PMF_ALGO_NMFALS) { PMFCHK(ensure_gram(c, 1.0)); PMFCHK(nnqp_warm_flag(c, c->stream)); }
+    else if (c->algo == PMF_ALGO_NMFALS) { PMFCHK(ensure_gram(c, 1.0)); PMFCHK(nnqp_prepare(c, c->stream, nnqp_use_wave(c))); }
     else PMFCHK(ensure_gram(c, 0.0));
   }
   return PMF_OK;
@@ -2426,11 +2426,15 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
       } else if (c->algo == PMF_ALGO_NMFALS) {  // nmfals.py:85-97: right-hand sides V H^T of the tile's rows, one QP per row
         float* Ft = c->dW1 + row0 * c->KP;
         PMFCHK(rowgemm<EPI_STORE>(c, T, c->np, c->np, c->dH, c->np, nullptr, nullptr, Ft, rows_p, rows));
-        double* qp = nullptr;
-        PMFCHK(nnqp_scratch(c, &qp));
-        const int qrc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm, qp);
-        if (qrc != PMF_OK) return fail(c, qrc, "nnqp launch (streamed W tile) failed");
-        HIPCHK(c, hipGetLastError());
+        if (nnqp_use_wave(c)) {                  // 64 < num_bases <= 128: k_nnqp_wave, inv(HA) prepared by pmf_stream_begin
+          PMFCHK(solve_nnqps(c, Ft, 1, c->KP, Wt, 1, c->KP, rows, false, true));
+        } else {
+          double* qp = nullptr;
+          PMFCHK(nnqp_scratch(c, &qp));
+          const int qrc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm, qp);
+          if (qrc != PMF_OK) return fail(c, qrc, "nnqp launch (streamed W tile) failed");
+          HIPCHK(c, hipGetLastError());
+        }
       } else {
         PMFCHK(rowgemm<EPI_NMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
       }
