@@ -71,9 +71,10 @@ def test_streamed_equals_resident(pm, shape, k, rows, tmp_path):
 
 @pytest.mark.parametrize("cls_name,shape,k,rows", [("NMF", (3000, 256), 200, 1024), ("NMF", (2000, 192), 130, 512),
                                                   ("BNMF", (2048, 128), 140, 640), ("SNMF", (3000, 320), 150, 1024),
-                                                  ("NMFALS", (700, 160), 130, 256)])
+                                                  ("NMFALS", (700, 160), 130, 256), ("NMFALS", (900, 200), 100, 256)])
 def test_streamed_equals_resident_beyond_128_bases(pm, cls_name, shape, k, rows, tmp_path):
-    """num_bases > 128 (the products in blocks of 128 bases) through the row-tile passes: the same
+    """num_bases > 128 (the products in blocks of 128 bases; NMFALS also at 100 bases: k_nnqp_wave per tile)
+    through the row-tile passes: the same
     iteration as on resident data (per tile the W rule, W_b^T V and W_b^T W partials accumulated in float64)."""
     rs = np.random.RandomState(shape[0] + k)
     V = rs.random_sample(shape).astype(np.float32)
