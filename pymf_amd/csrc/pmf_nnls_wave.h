@@ -100,12 +100,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restr
   __shared__ double s_vecV[NWV][128];     // f, then (complement form) y, by variable
   __shared__ double s_vecC[NWV][WVN];     // mu by position
   __shared__ int s_lst[NWV][WVN];         // the variable at each position of the system
+  __shared__ double s_R[NWV][WVN * (WVN - 1) / 2 + WVN];   // L by rows, packed (row i: i entries at i (i - 1) / 2): the backward solve's operand
   const int t = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* const vecP = s_vecP[wv];
   double* const vecV = s_vecV[wv];
   double* const vecC = s_vecC[wv];
   int* const lst = s_lst[wv];
+  double* const R = s_R[wv];
+  const int tri = t * (t - 1) / 2;
   const unsigned long long below = (1ull << t) - 1ull;
   double hm = 0.0, dg[2];
 #pragma unroll
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restr
           const double inv = pmf_rcp_f64(dj);
           const double lij = Lr[j] * inv;
           if (tt == j) dv = dj;
+          if (tt > j) R[tri + j] = lij;
           if constexpr (j + 1 < WVN) {
             double* coln = vecP + ((j + 1) & 1) * WVN;
             Lr[j + 1] = fma(-lij, col[j + 1], Lr[j + 1]);
@@ -259,11 +263,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restr
         }
       });
       b *= pmf_rcp_f64(dv);
-      static_for<1, WVN>([&](auto jr_) {
-        constexpr int j = WVN - 1 - decltype(jr_)::value;
-        if (j >= shift) {
-          const double tot = wave_sum_f64(tt > j ? Lr[j] * b : 0.0);
-          if (tt == j) b -= tot;
+      // (column-oriented, from the packed copy of L's rows in LDS: mu_i is final when its turn comes, row i's entries are
+      //  contiguous over the lanes.  The row-oriented form on the registers -- a 64-lane sum per unknown -- was 30
+      //  instructions per step instead of 6.)
+      __builtin_amdgcn_wave_barrier();
+      static_for<0, WVN - 1>([&](auto ir_) {
+        constexpr int i = WVN - 1 - decltype(ir_)::value;      // 63 .. 1
+        if (i > shift) {
+          const double mi = readlane_f64(b, i);
+          const double l = R[i * (i - 1) / 2 + t];
+          if (tt < i && tt >= shift) b = fma(-l, mi, b);
         }
       });
       if (on_t) vecC[t - shift] = b;
