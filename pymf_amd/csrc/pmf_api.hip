@@ -1533,7 +1533,7 @@ int nnqp_prepare(pmf_ctx* c, hipStream_t s, bool quad) {
     if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
     if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
     double* Hp = c->dBinv + (size_t)c->KP * c->KP;
-    hipLaunchKernelGGL(k_nnqp_patch_dead, dim3(1), dim3(256), 0, s, c->dGd, c->KP, c->k, Hp);
+    hipLaunchKernelGGL(k_nnqp_patch_dead, dim3((unsigned)std::max(1, c->KP * c->KP / 1024)), dim3(256), 0, s, c->dGd, c->KP, c->k, Hp);
     if (c->k <= 64) hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
     else hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
     HIPCHK(c, hipGetLastError());

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void k_nnqp_patch_dead(const double* __restric
     __syncthreads();
   }
   const double dead_below = 1e-12 * dg[0];
-  for (int e = threadIdx.x; e < KP * KP; e += 256) {
+  // (any number of workgroups: each finds the largest diagonal entry for itself and patches a slice)
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < KP * KP; e += gridDim.x * 256) {
     const int c = e / KP, t = e % KP;
     const bool dc = c >= k || !(Hd[(int64_t)c * KP + c] > dead_below), dt = t >= k || !(Hd[(int64_t)t * KP + t] > dead_below);
     Hp[e] = (dc || dt) ? (c == t ? 1.0 : 0.0) : Hd[e];
