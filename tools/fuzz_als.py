@@ -6,9 +6,12 @@ import numpy as np
 import pymf_amd
 from oracle import NMFALSOracle
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"      # 65 .. 128 bases: k_nnqp_wave
 bad = 0
 for t in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     m = int(rs.choice([3, 10, 40, 90])); n = int(rs.choice([3, 12, 50, 80])); k = int(rs.choice([1, 2, 5, 16, 17, 33, 64]))
+    if wide:
+        m = int(rs.choice([130, 200, 331])); n = int(rs.choice([129, 160, 260])); k = int(rs.choice([65, 72, 96, 100, 127, 128]))
     if k > min(m, n): k = min(m, n)          # Gram matrices of full rank: unique minimisers
     V = rs.random_sample((m, n)).astype(np.float32)
     if rs.random_sample() < 0.3: V[rs.random_sample((m, n)) < 0.6] = 0
