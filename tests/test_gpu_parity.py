@@ -999,6 +999,40 @@ def test_full_size_properties_cfg3(pm):
     c.close()
 
 
+def test_full_size_properties_nmfals_128_bases(pm):
+    """NMFALS 262,144 x 1024 at k = 128 (k_nnqp_wave, pmf_nnls_wave.h: one wave per QP): the KKT conditions of the row QPs
+    of the first W half step from the random start (systems of 50-60 unknowns, 3-5 block-pivoting passes) and of a later,
+    warm one, on a row sample in float64; monotone objective; the column QPs at a fixed point."""
+    from pymf_amd import _lib
+    m, n, k = 262144, 1024, 128
+    c = _lib.Context(_lib.ALGO_NMFALS, m, n, k)
+    c.fill_v_uniform(1234); c.fill_w_uniform(42); c.fill_h_uniform(43)
+    rows = np.arange(0, m, 509)
+    Vs = _synthetic_rows(1234, rows, n).astype(np.float64)
+    f_prev = c.frobenius()
+    for it in range(3):
+        H0 = c.get_h().astype(np.float64)
+        c.update_w()
+        W1 = c.get_w()
+        assert float(W1.min()) >= 0.0 and np.isfinite(W1).all()
+        HA, Fm = H0.dot(H0.T), Vs.dot(H0.T)
+        Ws = W1[rows].astype(np.float64)
+        g = Ws.dot(HA) - Fm
+        scale = np.abs(Fm).max()
+        assert g.min() > -2e-4 * scale, (it, g.min() / scale)
+        assert np.abs(Ws * g).max() < 2e-4 * scale * max(1.0, Ws.max()), it
+        f1 = c.frobenius()
+        c.update_h()
+        f2 = c.frobenius()
+        assert f1 <= f_prev * (1 + 1e-6) and f2 <= f1 * (1 + 1e-6), (it, f_prev, f1, f2)
+        f_prev = f2
+    H1 = c.get_h().astype(np.float64)
+    assert float(H1.min()) >= 0.0
+    c.update_h()
+    assert rel_fro(c.get_h().astype(np.float64), H1, what="k = 128 H: update_h twice (fixed point of the exact QP)") < 1e-9
+    c.close()
+
+
 def test_full_size_properties_cfg5(pm):
     """cfg5 (SNMF on CSR 4,194,304 x 128 at 1 % nnz, k = 128; the full 2 GiB W): the Gram-space loop and
     the pass-per-iteration loop agree, the materialised W satisfies W (H H^T) = V H^T row by row (the normal
