@@ -194,7 +194,7 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *                waves per SIMD instead of two), problems that outgrow it on the 32-slot frame behind; 0: the 32-slot
  *                frame for all.  Bit-identical results.
  *   "nnqp_wave"  1 (default): NMFALS / NMFNNLS sub-problems at 64 < num_bases <= 128 on k_nnqp_wave (one wave per problem,
- *                block principal pivoting on the smaller of HA[P,P] / inv(HA)[N,N], LDL^T in LDS); 0: k_nnqp_big (one
+ *                block principal pivoting on the smaller of HA[P,P] / inv(HA)[N,N], LDL^T in registers); 0: k_nnqp_big (one
  *                variable at a time, the inverse image in global memory).  Same KKT point, float32 results equal to rounding.
  *   "force_tiled" 1: every path of this context takes the any-shape two-pass kernels (k_rowgemm / k_colgemm)
  *                even where a one-pass kernel covers the shape; 0 gives the one-pass kernels back.  For tests
