@@ -129,22 +129,37 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_nnqp_wave(const double* _
   // serves the others -- measured with NWV = 8: 20-40 % SLOWER (waves idle for the slowest problem's passes; instruction fetch is
   // not the limit: waves wait on memory 6 % of their cycles, the VALU is busy 40 % with two waves of dependent float64 chains
   // per SIMD, profiles/r03_experiments.md).  NWV = 1 is the form in use: every wave on its own.
+  // A problem's inputs (right-hand side, warm start, its row of Y0: HBM, ~2 us away) are requested one problem AHEAD, under
+  // the previous problem's passes.
+  float f_nx[2], x_nx[2];
+  double y0_nx[2];
+  auto request = [&](int64_t pr) {
+    const bool ok = pr < nprob;
+    const int64_t p = ok ? pr : nprob - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int v = t + 64 * s;
+      const bool act = ok && v < k;
+      f_nx[s] = act ? F[(int64_t)v * f_sk + p * f_sp] : 0.f;
+      x_nx[s] = act ? X[(int64_t)v * x_sk + p * x_sp] : 0.f;
+      y0_nx[s] = Y0[p * KP + v];
+    }
+  };
+  request((int64_t)blockIdx.x * NWV + wv);
   for (int64_t pbase = (int64_t)blockIdx.x * NWV; pbase < nprob; pbase += (int64_t)gridDim.x * NWV) {
     const bool valid = pbase + wv < nprob;
     const int64_t prob = valid ? pbase + wv : nprob - 1;
     double f[2], x[2];
     unsigned long long pm[2];
+    const double y0[2] = {y0_nx[0], y0_nx[1]};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int v = t + 64 * s;
-      const bool act = valid && v < k;
-      f[s] = act ? (double)F[(int64_t)v * f_sk + prob * f_sp] : 0.0;
-      const float x0 = act ? X[(int64_t)v * x_sk + prob * x_sp] : 0.f;
+      f[s] = (double)f_nx[s];
+      const float x0 = x_nx[s];
       x[s] = x0 > 0.f ? (double)x0 : 0.0;
       pm[s] = __ballot(x0 > 0.f) & live[s];
     }
-    bool have_y0 = false;
-    double y0[2] = {0.0, 0.0};
+    request(pbase + (int64_t)gridDim.x * NWV + wv);      // (a problem of this wave's own, later: nobody writes its X before)
     int npass = 0, ninf_best = k + 1, backup = 3;
 
     bool done = !valid;
@@ -181,10 +196,6 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_nnqp_wave(const double* _
       // ---- complement form: y = B (f on P) = y0 - B (f on N), y0 = B (f on the live variables) once per problem ----
       double y[2] = {0.0, 0.0};
       if (comp) {
-        if (!have_y0) {                              // y0 = B f, formed for all problems by k_nnqp_y0
-          y0[0] = Y0[prob * KP + t]; y0[1] = Y0[prob * KP + t + 64];
-          have_y0 = true;
-        }
         y[0] = y0[0]; y[1] = y0[1];
         wv_rows_dot<true, true>(Bd, KP, t, lst, vecV, ns, y[0], y[1]);
         __builtin_amdgcn_wave_barrier();
