@@ -11,9 +11,12 @@
 //   * the system has at most k / 2 <= 64 unknowns whatever the support: row i of its LDL^T factor lives in the REGISTERS
 //     of lane i (64 doubles, every index a constant of the program text: straight-line code as in k_nnqp_quad); a step's
 //     pivot column crosses the lanes through one 64-double LDS line (one write, broadcast reads).  A first form with the
-//     factor in a 64 x 65 LDS image (left-looking, 35 KiB: one wave per SIMD) took 7.5-12 ms where this one takes
-//     (profiles/r03_experiments.md);
-//   * products with HA / B read rows of the shared matrices from L2 (128 KiB each: beyond LDS), coalesced.
+//     factor in a 64 x 65 LDS image (left-looking, 35 KiB: one wave per SIMD) took 7.5-12 ms per iteration where this
+//     one takes 2.1-4.9 (65 536 x 512, k = 128; profiles/r03_experiments.md).  The backward solve runs column by column
+//     from a packed copy of L's rows in LDS (16 KiB per wave);
+//   * products with HA / B read rows of the shared matrices from L2 (128 KiB each: beyond LDS), coalesced, sixteen rows
+//     per round trip; y0 = B f of ALL problems is one float64-MFMA product (k_nnqp_y0 below);
+//   * a problem's inputs are requested one problem ahead.
 // Preconditions as k_nnqp_quad: *warm_flag != 0 (k_inverse_spd_mfma's pivots found HA positive definite and well
 // conditioned); otherwise the kernel returns at once and k_nnqp_big takes the half step.
 #pragma once
@@ -30,7 +33,7 @@ constexpr int WVN = 64;            // largest system a problem factorises (k <= 
 // a0 += sum_p coef(p) M[row(p)][t], a1 += ... M[row(p)][t + 64] over the positions p < ns of the system's list; coef(p) is
 // cv[row(p)] (BYVAR) or cv[p].  SIXTEEN rows -- 32 requests -- go out together: the rows come from L2 (the matrices are
 // 128 KiB each) and a wave is alone on its SIMD, so the requests in flight are the whole of its latency hiding
-// (two rows at a time: 12 ms for 65 536 problems at k = 128; eight: see profiles/r03_experiments.md).
+// (profiles/r03_experiments.md).
 template <bool BYVAR, bool NEG>
 __device__ __forceinline__ void wv_rows_dot(const double* __restrict__ M, int KP, int t, const int* lst, const double* cv, int ns,
                                             double& a0, double& a1) {
