@@ -32,7 +32,7 @@ constexpr int WVN = 64;            // largest system a problem factorises (k <= 
 
 // a0 += sum_p coef(p) M[row(p)][t], a1 += ... M[row(p)][t + 64] over the positions p < ns of the system's list; coef(p) is
 // cv[row(p)] (BYVAR) or cv[p].  SIXTEEN rows -- 32 requests -- go out together: the rows come from L2 (the matrices are
-// 128 KiB each) and a wave is alone on its SIMD, so the requests in flight are the whole of its latency hiding
+// 128 KiB each) and a SIMD holds two such waves, so the requests in flight are most of the latency hiding
 // (profiles/r03_experiments.md).
 template <bool BYVAR, bool NEG>
 __device__ __forceinline__ void wv_rows_dot(const double* __restrict__ M, int KP, int t, const int* lst, const double* cv, int ns,
