@@ -121,10 +121,11 @@ def test_snmf_wide_on_sparse_data(pm, hooks):
 
 @pytest.mark.parametrize("cls_name,shape,k,hooks", [("NMFALS", (600, 200), 80, False), ("NMFALS", (500, 300), 100, True),
                                                     ("NMFALS", (400, 380), 200, False), ("NMFNNLS", (300, 260), 96, False),
-                                                    ("NMFALS", (150, 700), 520, False)])
+                                                    ("NMFALS", (150, 700), 520, False), ("NMFALS", (90, 400), 100, False)])
 def test_als_wide_vs_float64_oracle(pm, cls_name, shape, k, hooks):
-    """k_nnqp_big with 2, 4 and 16 variables per lane; the last case has more bases than rows (rank-deficient
-    H H^T: the cold-start path, as the reference test's rank-3 data)."""
+    """k_nnqp_wave (65-128 bases) and k_nnqp_big with 4 and 16 variables per lane; the last two cases have more bases than
+    rows (rank-deficient Hessians: the cold-start path, as the reference test's rank-3 data -- at 100 bases k_nnqp_wave
+    stands back on the inverse's pivots and k_nnqp_big<2> takes the half step)."""
     import oracle
     rs = np.random.RandomState(sum(shape) + k)
     V = rs.random_sample(shape).astype(np.float32)
