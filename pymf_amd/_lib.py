@@ -91,6 +91,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PmfError("libpymf_hip.so not built: run `python -m pymf_amd.csrc.build` "
                        "(hipcc, gfx950). There is no CPU fallback.")
+    if not os.environ.get("PMF_LIB"):                 # (an A/B build named explicitly is the caller's business)
+        from .csrc import build as _build
+        if _build.built_hash() != _build.source_hash():
+            raise PmfError("libpymf_hip.so was not built from the sources at hand (hash of csrc/*.h, csrc/*.hip, "
+                           "include/pymf_hip.h and the flags differs from libpymf_hip.so.srchash): run "
+                           "`python -m pymf_amd.csrc.build`. A stale binary is never loaded.")
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

@@ -732,6 +732,11 @@ int eigh_topk(pmf_ctx* c, DevTemps& tmp, double* G, int n, int np, int k, double
     PMFCHK(ortho(Ya));
     PMFCHK(rayleigh_ritz(Ya));
   }
+  // out of iterations with pairs still unlocked whose Ritz values are NOT negligible: the solver did not converge (the
+  // caller falls back to Jacobi where that exists) -- "fewer than num_bases eigenvalues" would be the wrong diagnosis
+  if (nl < k && th[0] > 1e-14 * scale)
+    return fail(c, PMF_EHIP, "pmf_nndsvd_init: the top-k eigen-solver did not converge (" + std::to_string(nl) + " of " +
+                std::to_string(k) + " pairs in " + std::to_string(kMaxIter) + " filter steps)");
   std::vector<double> out(kp16, -1.0);
   for (int j = 0; j < nl && j < kp16; ++j) out[j] = thl[j];
   HIPCHK(c, hipMemcpyAsync(ev_dev, out.data(), (size_t)kp16 * sizeof(double), hipMemcpyHostToDevice, c->stream));

@@ -209,6 +209,14 @@ def init_from_env(make_nccl_id=None, timeout=None):
         bind_ip = "127.0.0.1" if addr == "localhost" else socket.gethostbyname(addr)
     except OSError:
         raise RuntimeError("pymf_amd.dist: MASTER_ADDR=%s does not resolve" % addr)
+    local_size = int(os.environ.get("LOCAL_WORLD_SIZE", str(size)) or size)
+    if size > local_size and _is_loopback(bind_ip):
+        # a multi-node launch whose MASTER_ADDR resolves to loopback ON THIS HOST (the Debian / Ubuntu /etc/hosts
+        # default for the host's own name): rank 0 would listen where no other node can reach it and the job would
+        # die after the timeout with "only 1 of N ranks joined" -- fail at once instead
+        raise RuntimeError("pymf_amd.dist: WORLD_SIZE=%d > LOCAL_WORLD_SIZE=%d (multi-node) but MASTER_ADDR=%s resolves to "
+                           "the loopback address %s here; pass an address the other nodes can reach (IPv4)"
+                           % (size, local_size, addr, bind_ip))
     key = _key(addr, mport, size, bind_ip)
     _WORLD = World(rank, size, local_rank, None)
     _PEERS = _serve(bind_ip, base, size, key, timeout) if rank == 0 else _join(bind_ip, base, rank, key, timeout)

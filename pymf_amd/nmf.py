@@ -24,6 +24,7 @@ current host arrays.
 import logging
 import os
 import sys
+import warnings
 
 import numpy as np
 
@@ -64,8 +65,21 @@ def _draw_rows(m_total, ncols, lo, hi, chunk=65536):
     return out
 
 
+class PrecisionWarning(UserWarning):
+    """float64 `data` is computed on in float32 (see NMF's class docstring)."""
+
+
 class NMF(object):
     """Non-negative matrix factorization, multiplicative updates (Lee & Seung).
+
+    Precision: the reference's arithmetic follows its operands (float64 by default: nmf.py:117,120,122-132).
+    Here every contraction runs on the float32 matrix cores and `data`, W and H are STORED in float32 on the
+    device whatever the dtype of the host arrays (which keep their dtype: results are written back into
+    float64 W / H arrays in place).  Results agree with the float64 reference within the tolerances of
+    DESIGN.md section 4 (2e-5 relative Frobenius on W and H, 1e-5 on ferr after <= 50 iterations); float64
+    `data` is rounded once on upload and a PrecisionWarning says so, once per object.
+    `eager_factors = True` gives up the lazy write-back of W / H, which relies on CPython reference counts
+    (other interpreters, tracers and debuggers that hold extra references are handled safely but eagerly).
 
     Parameters mirror the reference (pymf/nmf.py:23-66): data is m x n
     (m = _data_dimension rows, n = _num_samples columns), W is m x num_bases,
@@ -222,12 +236,20 @@ class NMF(object):
             self._upload_sparse(ctx)
         else:
             arr = np.asarray(self.data[:, :])                   # data[:,:] idiom, nmf.py:123,129
+            self._warn_if_float64(arr)
             fp = _fingerprint(arr) if self.check_data else None
             if same_obj and fp == self._v_fp:
                 return
             ctx.set_v_dense(arr)
         self._v_src = self.data
         self._v_fp = fp
+
+    def _warn_if_float64(self, arr):
+        if getattr(arr, "dtype", None) == np.float64 and not self.__dict__.get("_warned_f64", False):
+            self._warned_f64 = True
+            warnings.warn("%s: float64 data is rounded to float32 on the device (fp32 MFMA arithmetic; the "
+                          "reference would compute in float64, nmf.py:122-132) -- tolerances: DESIGN.md section 4"
+                          % type(self).__name__, PrecisionWarning, stacklevel=4)
 
     def _upload_sparse(self, ctx):
         raise TypeError("scipy.sparse data is not supported by %s (the reference fails "
@@ -245,7 +267,9 @@ class NMF(object):
         ctx.stream_begin(max_tile_rows=rows, **flags)
         m = self._data_dimension
         for r0 in range(0, m, rows):
-            ctx.stream_tile(r0, np.asarray(self.data[r0:min(m, r0 + rows), :]))
+            tile = np.asarray(self.data[r0:min(m, r0 + rows), :])
+            self._warn_if_float64(tile)
+            ctx.stream_tile(r0, tile)
         return ctx.stream_end()
 
     def _stream_iteration(self, ctx, rows, compute_w, compute_h, compute_err):
@@ -320,6 +344,9 @@ class NMF(object):
         st = dict(self.__dict__)
         st["_ctx"] = None
         st["_v_src"] = st["_v_fp"] = st["_w_fp"] = st["_h_fp"] = None
+        st["_host_stale"], st["_handed"] = set(), set()       # the copy shares no bookkeeping with the original
+        st["_defer_pull"] = st["_in_loop"] = st["_loop_data_checked"] = False
+        st.pop("_span", None)
         return st
 
     # ---- reference surface ----------------------------------------------------------
@@ -374,21 +401,37 @@ class NMF(object):
     #: True for classes whose W step can raise (SNMF: np.linalg.inv on a singular H H^T, snmf.py:69)
     _W_STEP_MAY_FAIL = False
 
-    def _snapshot_w_if_the_step_may_fail(self, ctx):
+    def _snapshot_w_if_the_step_may_fail(self, ctx, whole_loop=False):
         """The reference raises before it rebinds W (snmf.py:69-70): W is what it was, H is untouched.  A failing
-        step here leaves garbage in the device W, so where that can happen and the device copy is the only
-        current one (the host array was not refreshed since), W is copied device to device first."""
-        if self._W_STEP_MAY_FAIL and "W" in self._host_stale and hasattr(ctx, "snapshot_w"):
-            ctx.snapshot_w()
-            return True
+        step here leaves garbage in the device W (and, behind a whole pmf_factorize loop, in the device H), so
+        where that can happen and the device copy is the only current one (the host array was not refreshed
+        since), W is copied device to device first and -- before a whole loop -- a device-only H (k x n: cheap)
+        is brought to the host (a single W step does not touch H)."""
+        if not self._W_STEP_MAY_FAIL:
+            return False
+        if whole_loop and "H" in self._host_stale:
+            self._refresh_host("H")
+        if "W" in self._host_stale:
+            if hasattr(ctx, "snapshot_w"):
+                ctx.snapshot_w()
+                return True
+            self._refresh_host("W")                            # a context without snapshots: the host keeps the copy
         return False
 
     def _after_failed_w_step(self, ctx, snap):
         if snap:
             ctx.restore_w()                                    # device W = the previous W again; still the newer copy
-        else:
+        elif "W" not in self._host_stale:
             self._w_fp = None                                  # the (current) host array goes up again with the next call
-            self._host_stale.discard("W")
+        # else: the device copy is the only current one and nothing better exists -- it stays the newer copy; a
+        # stale host array is never declared current
+
+    def _after_failed_call(self, ctx, snap):
+        """A whole factorize() raised: the device factors are in an unknown state wherever the host arrays were
+        current when the call started (they go up again); a factor that lived on the device alone keeps doing so."""
+        self._after_failed_w_step(ctx, snap)
+        if "H" not in self._host_stale:
+            self._h_fp = None
 
     def converged(self, i):                                    # nmf.py:134-139
         derr = np.abs(self.ferr[i] - self.ferr[i - 1]) / self._num_samples
@@ -428,7 +471,7 @@ class NMF(object):
             # the hooks synchronise what THEY need: a subclass that computes on the host never pays for an upload
             return self._factorize_by_hooks(niter, compute_w, compute_h, compute_err)
         ctx = self._sync_to_device()
-        snap = compute_w and self._snapshot_w_if_the_step_may_fail(ctx)
+        snap = compute_w and self._snapshot_w_if_the_step_may_fail(ctx, whole_loop=True)
         if rows:                                               # a Python loop already: logs as it runs
             ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
             self._last_iters = done
@@ -444,10 +487,9 @@ class NMF(object):
                                                     conv_eps=self._EPS)
             except Exception:
                 # the device factors are in an unknown state (e.g. behind a singular H H^T): W goes back to the
-                # snapshot (or to the host array, which then is the current one), H to the host array
-                self._after_failed_w_step(ctx, snap)
-                self._h_fp = None
-                self._host_stale.discard("H")
+                # snapshot (or to the host array where that is the current one), H to the host array (a class
+                # whose step may fail had it flushed before the call)
+                self._after_failed_call(ctx, snap)
                 raise
         self._last_iters = done
         self._pull(ctx, compute_w and done > 0, compute_h and done > 0)

@@ -105,8 +105,14 @@ def main():
     NMF, SNMF, NNLS = mods["nmf"].NMF, mods["snmf"].SNMF, mods["nmfnnls"].NMFNNLS
     BNMF = mods["bnmf"].BNMF
     cases = {}
+    only = sys.argv[1:]          # e.g. `gen_golden.py nndsvd` rewrites only the nndsvd_* fixtures
+
+    def wanted(name):
+        return not only or any(name.startswith(o) for o in only)
 
     def add(name, cls, V, vdesc, k, niter, seed, cast32, **kw):
+        if not wanted(name):
+            return
         r = run_case(cls, V, k, niter, seed, cast32, **kw)
         r.update(vdesc)
         r["k"] = np.int64(k)
@@ -187,6 +193,19 @@ def main():
     add("nmfals_cfg3s", ALS, Vc3, dict(V_seed=np.int64(1234), V_shape=np.array([2048, 1024], dtype=np.int64)),
         64, 2, 42, False)
 
+    # Round 4: the SAME inputs through pymf/nmfnnls.py -- the reference's own NNLS class, REAL scipy.optimize.nnls, no
+    # stand-in anywhere -- which minimises the identical objective row by row / column by column (nmfnnls.py:69-80):
+    # these pin NMFALS' NUMBERS at the shapes that matter (cfg3's width and num_bases among them); the nmfals_* fixtures
+    # above (stub cvxopt) pin nmfals.py's data flow only.
+    add("nnls_130x90_k33", NNLS, V5, dict(V=V5), 33, 3, 5, False)
+    add("nnls_cfg3s", NNLS, Vc3, dict(V_seed=np.int64(1234), V_shape=np.array([2048, 1024], dtype=np.int64)), 64, 2, 42, False)
+    Vq_, dq_ = (np.random.RandomState(78).random_sample((300, 200))).astype(np.float32), \
+        dict(V_seed=np.int64(78), V_shape=np.array([300, 200], dtype=np.int64), V_shift=np.float64(0.0))
+    add("nnls_300x200_k72", NNLS, Vq_, dq_, 72, 2, 42, False)
+    Vq_, dq_ = (np.random.RandomState(79).random_sample((260, 300))).astype(np.float32), \
+        dict(V_seed=np.int64(79), V_shape=np.array([260, 300], dtype=np.int64), V_shift=np.float64(0.0))
+    add("nnls_260x300_k130", NNLS, Vq_, dq_, 130, 2, 42, False)
+
     # cfg5's shape class (k = n = 128): H H^T of a square uniform H has cond ~ 1e7.  Two iterations (no
     # convergence test can fire before i > 1, so both runs execute exactly two) of reference SNMF
     # (snmf.py:67-91) with float64-default operands = the golden; the SAME run with all-float32 operands
@@ -200,8 +219,9 @@ def main():
     for tag, Vk, desc in (("snmf_cfg5s_dense_f64", Vs5, dict(V_seed=np.int64(1234), V_shape=np.array([384, 128], dtype=np.int64))),
                           ("snmf_csr_k128_f64", Vd, dict(V=Vd))):
         add(tag, SNMF, Vk, desc, 128, 2, 42, False)
-        r32 = run_case(SNMF, Vk, 128, 2, 42, True)
-        cases[tag].update(W32=r32["W"], H32=r32["H"], ferr32=r32["ferr"])
+        if wanted(tag):
+            r32 = run_case(SNMF, Vk, 128, 2, 42, True)
+            cases[tag].update(W32=r32["W"], H32=r32["H"], ferr32=r32["ferr"])
 
     # BNMF ("next" row 1): binary data, the reference test's own input (tests/test_pymf.py:80)
     Vb = (np.random.RandomState(17).random_sample((96, 64)) < 0.3).astype(np.float32)
@@ -284,7 +304,6 @@ def main():
     cases["bigk_rnmf_300x256_k140"] = dict(V=Vr, W=mdl.W, H=mdl.H, S=mdl.S, ferr=np.asarray(mdl.ferr, dtype=np.float64),
                                            k=np.int64(140), niter=np.int64(6), seed=np.int64(7), lamb=np.float64(1.0))
 
-    only = sys.argv[1:]          # e.g. `gen_golden.py nndsvd` rewrites only the nndsvd_* fixtures
     for name, d in cases.items():
         if only and not any(name.startswith(o) for o in only):
             continue

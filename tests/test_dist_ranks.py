@@ -121,6 +121,18 @@ def test_non_loopback_rendezvous_needs_a_secret(monkeypatch):
     assert dist._key("127.0.0.1", "29500", 2, "127.0.0.1")           # loopback: derived from the launcher's env
 
 
+def test_multi_node_launch_with_a_loopback_master_addr_fails_at_once(monkeypatch):
+    """Advisor (round 3): MASTER_ADDR = the host's own name resolves to 127.0.1.1 on Debian/Ubuntu -- a multi-node job would
+    wait 300 s for ranks that can never connect."""
+    from pymf_amd import dist
+    for kk, vv in (("WORLD_SIZE", "4"), ("LOCAL_WORLD_SIZE", "2"), ("RANK", "0"), ("LOCAL_RANK", "0"),
+                   ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port()))):
+        monkeypatch.setenv(kk, vv)
+    monkeypatch.setattr(dist, "_PEERS", None)
+    with pytest.raises(RuntimeError, match="loopback"):
+        dist.init_from_env()
+
+
 def test_wrong_key_and_strangers_cannot_join_and_frames_are_capped():
     """Rank 0's accept loop against: a peer with the wrong key, a peer that sends garbage, then the real rank 1.
     Only the last one is admitted; afterwards an over-long frame header is refused."""

@@ -36,9 +36,10 @@ def test_snmf_k160_vs_reference_golden(pm):
 
 
 @pytest.mark.parametrize("name", ["bigk_nmfals_300x200_k72", "bigk_nmfals_260x300_k130"])
-def test_nmfals_beyond_64_vs_reference_golden(pm, name):
-    """nmfals.py itself (exact-QP stand-in for cvxopt, gen_golden.load_reference_nmfals); k = 130 also
-    crosses the 128-base block boundary of the products around the QPs."""
+def test_nmfals_beyond_64_data_flow_pin_with_stub_cvxopt(pm, name):
+    """DATA-FLOW pin: nmfals.py itself (exact-QP stand-in for cvxopt, gen_golden.load_reference_nmfals); k = 130 also
+    crosses the 128-base block boundary of the products around the QPs.  Numbers: the nnls_300x200_k72 /
+    nnls_260x300_k130 fixtures (real pymf/nmfnnls.py) in tests/test_gpu_als_sparse.py."""
     g, mdl = _run_golden(pm, "NMFALS", name)
     close(mdl.ferr, g["ferr"], rtol=6e-7, what="mdl.ferr")
     assert rel_fro(mdl.W, g["W"], what="mdl.W") < 9e-5 and rel_fro(mdl.H, g["H"], what="mdl.H") < 1e-4

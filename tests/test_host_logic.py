@@ -242,3 +242,79 @@ def test_failed_w_step_leaves_the_previous_factors_like_the_reference():
     np.testing.assert_allclose(mdl.W, Wr, rtol=1e-6)
     np.testing.assert_allclose(mdl.H, Hr, rtol=1e-6)
     assert np.isfinite(mdl.W).all()
+
+
+def test_success_then_failing_one_call_factorize_keeps_a_consistent_pair():
+    """Advisor (round 3): after a successful lazy factorize() W and H live on the device alone; a factorize() that
+    raises afterwards must not declare the untouched (older) host arrays current.  SNMF (a class whose W step may
+    fail): the pair before the failing call survives -- W through the device snapshot, H through the flush that
+    precedes such a call.  NMF: factors that lived on the device alone keep doing so."""
+    import oracle
+
+    class Ctx(_CountingCtx):
+        fail_next = False
+
+        def snapshot_w(self):
+            self.Wsnap = self.W.copy()
+
+        def restore_w(self):
+            self.W = self.Wsnap.copy()
+
+        def factorize(self, niter, *a, **kw):
+            if self.fail_next:
+                self.W[:] = np.nan                      # what a singular H H^T leaves behind on the device
+                self.H[:] = np.nan
+                raise np.linalg.LinAlgError("Singular matrix")
+            return _CountingCtx.factorize(self, niter, *a, **kw)
+
+    rs = np.random.RandomState(11)
+    V = rs.rand(30, 10).astype(np.float32)
+    for cls in (pymf_amd.SNMF, pymf_amd.NMF):
+        mdl = cls(V, num_bases=3)
+        mdl._ctx = Ctx(30, 10, 3)
+        W0, H0 = rs.rand(30, 3), rs.rand(3, 10)
+        mdl.W, mdl.H = W0.copy(), H0.copy()
+        mdl.factorize(niter=2, compute_err=False)                     # success: both factors device-only now
+        assert mdl._host_stale == {"W", "H"}
+        Wr, Hr = W0.copy(), H0.copy()
+        for _ in range(2):
+            oracle.nmf_update_w(V.astype(np.float64), Wr, Hr)
+            oracle.nmf_update_h(V.astype(np.float64), Wr, Hr)
+        mdl._ctx.fail_next = True
+        with pytest.raises(np.linalg.LinAlgError):
+            mdl.factorize(niter=3, compute_err=False)
+        if cls is pymf_amd.SNMF:
+            np.testing.assert_allclose(mdl.W, Wr, rtol=1e-6)          # call 1's result, not W0
+            np.testing.assert_allclose(mdl.H, Hr, rtol=1e-6)          # ... and not H0
+            # and the next call computes from that pair
+            mdl._ctx.fail_next = False
+            mdl.factorize(niter=0, compute_err=False)
+            np.testing.assert_allclose(mdl._ctx.H, Hr.astype(np.float32), rtol=1e-6)
+        else:
+            # nothing better than the device copies exists: they stay the current ones (never W0 / H0 again)
+            assert mdl._host_stale == {"W", "H"}
+            assert not np.array_equal(mdl.__dict__["_W"], Wr)         # host array untouched, and not declared current
+            assert mdl._w_fp is not None or "W" in mdl._host_stale
+
+
+def test_copies_share_no_bookkeeping_with_the_original():
+    import copy
+    mdl = _model_with_double(seed=6)
+    mdl.factorize(niter=1, compute_err=False)
+    clone = copy.copy(mdl)
+    assert clone._host_stale is not mdl._host_stale and clone._handed is not mdl._handed
+    mdl.factorize(niter=1, compute_err=False)                         # stale again on the original only
+    assert clone._host_stale == set() and clone._ctx is None
+
+
+def test_float64_data_warns_once_per_object():
+    import warnings
+    mdl = _model_with_double(seed=8)
+    mdl.data = mdl.data.astype(np.float64)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        mdl.factorize(niter=1, compute_err=False)
+        mdl.check_data = True
+        mdl.factorize(niter=1, compute_err=False)
+    hits = [r for r in rec if issubclass(r.category, pymf_amd.nmf.PrecisionWarning)]
+    assert len(hits) == 1 and "float32" in str(hits[0].message)

@@ -42,8 +42,28 @@ def test_oracle_matches_reference_golden(name):
     assert o.W.dtype == g["W"].dtype and o.H.dtype == g["H"].dtype
 
 
+@pytest.mark.parametrize("name", ["nnls_130x90_k33", "nnls_cfg3s", "nnls_300x200_k72", "nnls_260x300_k130"])
+def test_nmfals_oracle_matches_the_real_nmfnnls_reference(name):
+    """Round 4: pymf/nmfnnls.py -- the reference's own class, REAL scipy.optimize.nnls, no stand-in -- on
+    the inputs of the nmfals_* / bigk_nmfals_* fixtures: identical objective (nmfnnls.py:69-80 vs nmfals.py:70-97), so
+    these pin the NMFALS oracle's NUMBERS at cfg3's width and num_bases and beyond 64 / 128 bases; each must also
+    agree with its stub-cvxopt sibling (which pins nmfals.py's data flow)."""
+    g = load_golden(name)
+    o = NMFALSOracle(g["V"], num_bases=int(g["k"]))
+    o.W, o.H = g["W0"].copy(), g["H0"].copy()
+    o.factorize(niter=int(g["niter"]))
+    assert len(o.ferr) == len(g["ferr"])
+    assert rel_fro(o.W, g["W"]) < 1e-7 and rel_fro(o.H, g["H"]) < 1e-7     # Lawson-Hanson on (A, b) vs exact active set on the Gram matrix
+    np.testing.assert_allclose(o.ferr, g["ferr"], rtol=1e-7)
+    sib = {"nnls_130x90_k33": "nmfals_130x90_k33", "nnls_cfg3s": "nmfals_cfg3s",
+           "nnls_300x200_k72": "bigk_nmfals_300x200_k72", "nnls_260x300_k130": "bigk_nmfals_260x300_k130"}[name]
+    h = load_golden(sib)
+    assert np.array_equal(h["W0"], g["W0"]) and np.array_equal(h["V"], g["V"])
+    assert rel_fro(h["W"], g["W"]) < 1e-7 and rel_fro(h["H"], g["H"]) < 1e-7
+
+
 @pytest.mark.parametrize("name", ["nmfals_24x18_k4", "nmfals_reftest", "nmfals_130x90_k33", "nmfals_cfg3s"])
-def test_nmfals_oracle_matches_nmfals_py_itself(name):
+def test_nmfals_oracle_data_flow_pin_against_nmfals_py_with_stub_cvxopt(name):
     """Goldens from pymf/nmfals.py ITSELF (nmfals.py:70-97) driven through an exact-QP stand-in for
     cvxopt (gen_golden.load_reference_nmfals): pins the restatement's data flow -- -W.T / -H signs,
     float64 forcing, column scatter :75, row scatter :90 -- not cvxopt's interior-point digits."""
