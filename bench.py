@@ -138,7 +138,11 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0):
             oracle.nmf_update_w(V, W32, H32)
             oracle.nmf_update_h(V, W32, H32)
         it, dt = _time_loop(step64, budget_s * 0.7)
+        # the float64-default factors after 1 + it iterations from W0 / H0: what the device is compared with at FULL size
+        # (main(): `parity_full_size`); the timing loop is the parity run -- nothing is thrown away
+        keep = {"iters": 1 + it, "W": W.copy(), "H": H.copy()}
         it32, dt32 = _time_loop(step32, budget_s * 0.3)
+        out["_oracle_factors"] = keep
         out.update(value=it / dt, value_all_fp32=it32 / dt32,
                    sample="oracle NMF (reference op order, float64 W/H, float32 V) at FULL size %dx%d k=%d: "
                           "1 warm-up + %d iterations in %.2f s; all-float32 variant: %d iterations in %.2f s; %s"
@@ -211,11 +215,17 @@ def main():
     ap.add_argument("--snmf-gram", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="SNMF: -1 library default (Gram-space loop), 0 one pass over V per iteration")
     ap.add_argument("--debug-share-gpu", action="store_true",
-                    help="plumbing check on a 1-GPU box: every rank uses device 0 and its own 1-rank RCCL "
-                         "communicator (rows still sharded, barriers still used); NOT a measurement")
+                    help="plumbing check on a 1-GPU box: every rank uses device 0, the per-iteration sums cross the ranks "
+                         "through the one-shot IPC all-reduce (RCCL refuses two ranks on one GPU); NOT a measurement")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="pmf_set_option(NAME, VALUE) on the bench context (A/B measurements of tuning knobs)")
     args = ap.parse_args()
 
     from pymf_amd import _lib, dist
+    if args.debug_share_gpu:
+        # ranks sharing GPU 0 cannot form an RCCL communicator ("Duplicate GPU detected"): the per-iteration sums take the
+        # one-shot IPC all-reduce (two processes, one GPU), anything larger the host transport
+        os.environ["PYMF_DIST_TRANSPORT"] = "ipc"
     w = dist.init_from_env()
     if w.size != args.gpus and w.rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, w.size),
@@ -225,10 +235,14 @@ def main():
     algo = getattr(_lib, "ALGO_" + algo_name)
     lo, hi = w.row_range(m)
     if args.debug_share_gpu:
-        ctx = _lib.Context(algo, hi - lo, n, k, device=0, rank=0, nranks=1, nccl_id=_lib.nccl_unique_id())
+        ctx = _lib.Context(algo, hi - lo, n, k, device=0)
     else:
         ctx = _lib.Context(algo, hi - lo, n, k, device=w.local_rank, rank=w.rank,
                            nranks=w.size, nccl_id=w.nccl_id)
+    for ov in args.option:
+        ctx.set_option(ov.split("=")[0], int(ov.split("=")[1]))
+    if w.size > 1:
+        dist.setup_collectives(ctx)          # RCCL, with the one-shot IPC all-reduce in front of it where it passes its self-test
     data = "synthetic"
     nnz_local = 0
     host = {}                    # host copies for the class-level measurement (1 rank, numpy fill)
@@ -271,6 +285,7 @@ def main():
 
     # ---- disclosed pre-conditioning (untimed, reported as "preroll_ms" / "preroll_iters") ----
     preroll_iters, preroll_ms = 0, 0.0
+    state_dependent = algo_name == "NMFALS"      # the cost of an ALS iteration depends on how settled the active sets are
     if args.preroll_ms > 0:
         ctx.factorize(2, compute_err=False)
         # every iteration carries a collective: ALL ranks must run the same count (the slowest rank's estimate)
@@ -279,6 +294,12 @@ def main():
         ctx.factorize(preroll_iters, compute_err=False)
         preroll_ms = ctx.last_loop_ms()
         preroll_iters += 2
+        if state_dependent and "W0" in host:
+            # BASELINE.md section 3 / SURVEY 8(d): warm-up and timed iterations start from the SEEDED W0 / H0.  The pre-roll
+            # only brings the chip to its clock; the factors go back to the seeded start, so `value` includes the expensive
+            # first iterations (every row QP still changing its active set) -- the settled rate is reported beside it.
+            ctx.set_w(host["W0"])
+            ctx.set_h(host["H0"])
 
     # ---- warm-up (untimed) ----
     if args.warmup > 0:
@@ -302,6 +323,38 @@ def main():
     launch_ms = np.sort(all_ms)
     first_ms = [round(float(x), 4) for x in all_ms[:5]]
     ctx.profile_enable(False)
+    # NMFALS: the rate once the active sets have settled (about 300 iterations from the seeded start), same K steps
+    settled, qp_counts = None, None
+    if state_dependent:
+        more = max(0, 300 - (args.warmup + args.steps))
+        if more:
+            ctx.factorize(more, compute_err=False)
+        ctx.synchronize()
+        dist.barrier()
+        t5 = time.perf_counter()
+        _, done_q, _ = ctx.factorize(args.steps, compute_err=False)
+        ctx.synchronize()
+        d5 = time.perf_counter() - t5
+        dist.barrier()
+        d5 = dist.allreduce_max(d5)
+        settled = {"iters_per_sec": done_q / d5, "ms_per_step": d5 / max(done_q, 1) * 1e3, "steps": done_q,
+                   "after_iterations": args.warmup + args.steps + more}
+        # COUNTING PASS (same run, outside every timed region): the deterministic loop once more from the seeded start on the
+        # counting instantiation of the QP kernel (it costs the kernel 8 %, so the timed loops carry no counters) -- the
+        # counts of exactly the W half steps of the warm-up + timed region, and of the settled K steps
+        if "W0" in host and "quad" in stats["name"]:
+            ctx.set_w(host["W0"])
+            ctx.set_h(host["H0"])
+            ctx.set_option("nnqp_count", 1)
+            ctx.nnqp_counters(reset=True)
+            ctx.factorize(args.warmup + args.steps, compute_err=False)
+            qp_counts = ctx.nnqp_counters(reset=True)
+            if more:
+                ctx.factorize(more, compute_err=False)
+            ctx.nnqp_counters(reset=True)
+            ctx.factorize(args.steps, compute_err=False)
+            settled["qp_counts"] = ctx.nnqp_counters(reset=True)
+            ctx.set_option("nnqp_count", 0)
 
     # secondary: the API-default compute_err=True rate (not the headline value; the reference has no
     # error on sparse data, nmf.py:109-112)
@@ -321,8 +374,8 @@ def main():
     # row QP).  Beside it: the first iterations from the random start, where every row QP still changes its set.
     rate_from_start = None
     if algo_name == "NMFALS" and "W0" in host:
-        ctx.set_w(host.pop("W0"))
-        ctx.set_h(host.pop("H0"))
+        ctx.set_w(host["W0"])
+        ctx.set_h(host["H0"])
         ns0 = max(2, min(args.steps, 10))
         ctx.synchronize()
         dist.barrier()
@@ -380,7 +433,15 @@ def main():
             class_rate["note"] = ("the class runs the library's default SNMF loop: Gram-space iterations, W = V M written ONCE per "
                                   "factorize() -- compare with config.gram_space_loop_w_once_per_factorize, not with `value`")
         try:
-            mdl.factorize(niter=2, compute_err=False)
+            # FIRST call of a fresh object with pre-set factors: context creation, digests, upload of data / W / H, loop
+            kf = 50
+            t3 = time.perf_counter()
+            mdl.factorize(niter=kf, compute_err=False)
+            first_call = dict((k_, round(float(v_), 3)) for k_, v_ in mdl.last_call_ms.items())
+            first_call.update(steps=kf, wall_ms=round((time.perf_counter() - t3) * 1e3, 3),
+                              note="fresh pymf_amd.%s(V, k) with W, H assigned, factorize(%d, compute_err=False): ctx = context "
+                                   "creation, upload = digests + host->device copies of data, W, H, loop = device loop" % (algo_name, kf))
+            class_rate["first_call"] = first_call
             for key, chk in (("iters_per_sec", True), ("iters_per_sec_check_data_off", False)):
                 mdl.check_data = chk
                 d3, ov = None, None
@@ -416,10 +477,12 @@ def main():
                 traffic = json.load(open(tpath)).get("%s@%dx%dx%d/%d" % (stats["name"], m, n, k, w.size))
             except Exception:
                 traffic = None
-        if algo_name == "SNMF":
-            collective = "ncclAllReduce(V^T V), once per factorize()" if w.size > 1 else "none"
+        if w.size == 1:
+            collective = "none"
+        elif algo_name == "SNMF":
+            collective = "sum of V^T V once per factorize(); transports: " + ctx.collective_name
         else:
-            collective = "ncclAllReduce(W^T V | W^T W), %d B/iter" % (4 * k * (n + k)) if w.size > 1 else "none"
+            collective = "sum of (W^T V | W^T W), %d B/iter; transports: %s" % (4 * k * (n + k), ctx.collective_name)
         out = {
             "metric": "factorize_iters_per_sec",
             "value": args.steps / dt,
@@ -434,7 +497,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if algo_name == "NMFALS" else "f32",
+            "dtype": "f32 MFMA contractions + f64 QP solves" if algo_name == "NMFALS" else "f32",
             "data": data,
             "config": {"workload": "%s (BASELINE.json configs[%d]): %s %dx%d, k=%d, rows sharded over %d GPU(s), "
                                    "compute_err=False" % (args.config, cfg_index, cfg_desc, m, n, k, w.size),
@@ -442,6 +505,9 @@ def main():
                        "collective": collective,
                        "compute_err_true_iters_per_sec": rate_err,
                        "class_factorize": class_rate,
+                       "first_call": (class_rate or {}).get("first_call"),
+                       "settled": settled,
+                       "settled_iters_per_sec": settled["iters_per_sec"] if settled else None,
                        "from_random_start": rate_from_start},
             "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                          "traffic": traffic,
@@ -463,35 +529,51 @@ def main():
                          "kernel_share_of_timed_region": stats["launches"] * mean_s / dt if dt > 0 else 0.0},
         }
         if algo_name == "NMFALS":
-            # The QP kernel runs float64 VALU code: neither HBM nor MFMA bounds it.  Against the 78.6 TFLOP/s float64
-            # vector peak: the FMA flop of k_nnqp_quad per problem in this bench's state -- B f once (2 * 64 * 64), then per
-            # pass the correction over N and the product with the solution (2 * 64 * ns each), the LDL^T of inv(HA)[N,N]
-            # (2 ns^3 / 3) and the two triangular solves (2 * 2 ns^2) -- with the RECORDED sizes of that state: ns = 8
-            # unknowns, 1.9 passes (tools/quad_counts.py on a counting build, profiles/r03_experiments.md) and the recorded
-            # VALU instruction count of a W-step launch (rocprofv3 SQ_INSTS_VALU, profiles/r03_pmc_cfg3_nnqp_quad.txt:
-            # 1.16e8 per launch = 442 per problem).
+            # The QP kernel runs float64 VALU code: neither HBM nor MFMA bounds it.  Against the 78.6 TFLOP/s float64 vector
+            # peak: the FMA flop k_nnqp_quad EXECUTES, from the counts of this run's counting pass (the warm-up + timed
+            # iterations repeated from the seeded start; pmf_nnqp_counters: wave tasks of 4 problems, passes, sum over the passes of the largest system
+            # among a wave's four problems = the size ns its frame-padded elimination runs over).  Per problem: y0 = B f once
+            # (2 * 64 * 64), then per pass the correction over the small set and the product with the solution (2 * 64 * ns
+            # each), the LDL^T of the ns x ns block (2 ns^3 / 3) and the two triangular solves (2 * 2 ns^2).
             qps = float(hi - lo)
             quad = "quad" in stats["name"]
-            if quad and k == 64:
-                ns, passes = 8.0, 1.9
-                fma_flop = (2.0 * 64.0 * 64.0 + passes * (4.0 * 64.0 * ns + 2.0 * ns ** 3 / 3.0 + 4.0 * ns * ns)) * qps
-                valu_instr = 1.16e8 * qps / 262144.0
-                src = "profiles/r03_pmc_cfg3_nnqp_quad.txt (SQ_INSTS_VALU of k_nnqp_quad in this bench's state)"
+            if quad and qp_counts is not None:
+                nl = max(stats["launches"] + args.warmup, 1)        # W half steps the counters cover
+                fma_flop, tasks, passes, nssum = 0.0, 0, 0, 0
+                for fr in ("frame16", "frame32"):
+                    cnt = qp_counts[fr]
+                    if cnt["passes"] == 0:
+                        continue
+                    ns = cnt["sum_largest_system"] / float(cnt["passes"])
+                    fma_flop += 4.0 * (cnt["wave_tasks"] * 2.0 * 64.0 * 64.0 +
+                                       cnt["passes"] * (4.0 * 64.0 * ns + 2.0 * ns ** 3 / 3.0 + 4.0 * ns * ns))
+                    tasks += cnt["wave_tasks"]; passes += cnt["passes"]; nssum += cnt["sum_largest_system"]
+                fma_flop /= nl
+                src = ("counting pass of this run: the same %d W half steps (warm-up + timed) repeated from the seeded start on the "
+                       "counting instantiation of the kernel (pmf_nnqp_counters)" % nl)
+                out["roofline"]["qp_counts"] = dict(qp_counts, w_half_steps=nl,
+                                                    passes_per_wave_task=passes / float(max(tasks, 1)),
+                                                    mean_largest_system=nssum / float(max(passes, 1)))
             else:                                 # lane-per-variable kernel: DESIGN.md 3.4, profiles/r02_pmc_summary.csv
                 fma_flop = 2.0 * 2.24e5 * qps * (k / 64.0) ** 3
-                valu_instr = 16.6e3 * qps * (k / 64.0) ** 2
-                src = "profiles/r02_pmc_summary.csv (16.6 k VALU instructions per QP at k = 64, k_nnqp)"
+                src = "modelled: profiles/r02_pmc_summary.csv (k_nnqp, 2.24e5 FMA per QP at k = 64)"
             if mean_s > 0:
                 out["roofline"].update(bound="valu_f64", achieved=fma_flop / mean_s / 1e12, peak=78.6, unit="TFLOP/s",
-                                       frac=fma_flop / mean_s / 1e12 / 78.6)
-                out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": valu_instr,
-                                                 "achieved_Ginstr_per_s": valu_instr / mean_s / 1e9,
-                                                 "peak_Ginstr_per_s": 1024 * 2.4 / 4.0,
-                                                 "frac": valu_instr / mean_s / 1e9 / (1024 * 2.4 / 4.0),
-                                                 "source": src}
-            out["roofline"]["note"] = ("float64 VALU kernel: `achieved` counts the FMA flop of the solves (recorded instruction counts, "
-                                       "live launch time of the 16-slot-frame launch and the 32-slot one behind it); at three / two waves per SIMD the kernel is bound by the dependent chains of its "
-                                       "factorisations and triangular solves, not by issue slots (valu_issue.frac)")
+                                       frac=fma_flop / mean_s / 1e12 / 78.6, flops_per_launch=fma_flop,
+                                       executed_flops_per_launch=fma_flop, executed_TFLOPs=fma_flop / mean_s / 1e12)
+                out["roofline"]["flop_source"] = src
+                if quad and (m, n, k, w.size) == (262144, 1024, 64, 1):
+                    # VALU issue slots: a RECORDED instruction count (rocprofv3 SQ_INSTS_VALU of a settled W-step launch on
+                    # exactly this shape: 1.16e8 = 442 per problem) -- a model for any other state, labelled as such
+                    valu_instr = 1.16e8
+                    out["roofline"]["valu_issue_modelled"] = {"wave_instructions_per_launch_recorded": valu_instr,
+                                                              "achieved_Ginstr_per_s": valu_instr / mean_s / 1e9,
+                                                              "peak_Ginstr_per_s": 1024 * 2.4 / 4.0,
+                                                              "frac": valu_instr / mean_s / 1e9 / (1024 * 2.4 / 4.0),
+                                                              "source": "profiles/r03_pmc_cfg3_nnqp_quad.txt (settled state); not counted in this run"}
+            out["roofline"]["note"] = ("float64 VALU kernel: `achieved` = executed FMA flop of the row QPs (live device counts) / live launch "
+                                       "time of the 16-slot-frame launch plus the 32-slot one behind it; the kernel is bound by the dependent "
+                                       "chains of its factorisations and triangular solves at two / three waves per SIMD, not by flops")
         if args.config == "cfg5":
             out["config"]["nnz_local"] = nnz_local
             out["config"]["gram_space_loop_w_once_per_factorize"] = gram_loop
@@ -500,7 +582,27 @@ def main():
                                      "iteration, as the reference's update_w does" if stats["name"].startswith("k_csr_w")
                                      else "one pass over the CSR rows per iteration")
         if w.size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, m, n, k)
+            cb = cpu_baseline(args.config, m, n, k)
+            fac = cb.pop("_oracle_factors", None)
+            out["cpu_baseline"] = cb
+            if fac is not None and args.fill == "numpy":
+                # FULL-SIZE parity: the device from the same W0 / H0 for the same number of iterations as the
+                # float64-default oracle just ran for its timing -- every row of W, all of H
+                np.random.seed(42)
+                rs = np.random.mtrand._rand
+                ctx.set_w(gen_rows(rs, m, k, 0, m))
+                ctx.set_h(np.random.random((k, n)))
+                _, done_p, _ = ctx.factorize(fac["iters"], compute_err=False)
+                Wd, Hd = ctx.get_w(), ctx.get_h()
+                out["parity_full_size"] = {
+                    "iters": int(done_p),
+                    "relW": float(np.linalg.norm(Wd - fac["W"]) / np.linalg.norm(fac["W"])),
+                    "relH": float(np.linalg.norm(Hd - fac["H"]) / np.linalg.norm(fac["H"])),
+                    "max_abs_W": float(np.max(np.abs(Wd - fac["W"]))),
+                    "tolerance": 2e-5,
+                    "against": "oracle (NumPy restatement of nmf.py:122-132, float64 W/H, float32 V) at %dx%d, k=%d, same "
+                               "seeded W0/H0, same iteration count; ||X_gpu - X_ref||_F / ||X_ref||_F" % (m, n, k)}
+                del Wd, Hd, fac
         print(json.dumps(out), flush=True)
     ctx.close()
     dist.shutdown()

@@ -87,11 +87,21 @@ int pmf_set_v_csr_f32(pmf_ctx* ctx, const int64_t* indptr, const int32_t* indice
  * the values depend only on (seed, global row, column)); row0 = first global row. */
 int pmf_fill_v_uniform(pmf_ctx* ctx, uint64_t seed, int64_t row0);
 
+/* The same for a float64 host array (the reference's default dtype, nmf.py:117,120): the bytes go up as they are and are
+ * rounded to the device's float32 ON the device (no host-side conversion pass). */
+int pmf_set_v_dense_f64(pmf_ctx* ctx, const double* V, int64_t ld);
+
 /* W: m_local x k row-major (ld = k).  H: k x n row-major (ld = n). Host buffers. */
 int pmf_set_w_f32(pmf_ctx* ctx, const float* W);
 int pmf_get_w_f32(pmf_ctx* ctx, float* W);
 int pmf_set_h_f32(pmf_ctx* ctx, const float* H);
 int pmf_get_h_f32(pmf_ctx* ctx, float* H);
+/* ... and for float64 host arrays -- what self.W / self.H are by default (nmf.py:117,120): rounded to / widened from the
+ * device's float32 on the device, so that neither direction needs a conversion pass over m x k on the host. */
+int pmf_set_w_f64(pmf_ctx* ctx, const double* W);
+int pmf_get_w_f64(pmf_ctx* ctx, double* W);
+int pmf_set_h_f64(pmf_ctx* ctx, const double* H);
+int pmf_get_h_f64(pmf_ctx* ctx, double* H);
 int pmf_fill_w_uniform(pmf_ctx* ctx, uint64_t seed, int64_t row0);
 int pmf_fill_h_uniform(pmf_ctx* ctx, uint64_t seed);
 
@@ -171,6 +181,8 @@ int pmf_kernel_stats(pmf_ctx* ctx, const char** name, int64_t* launches, double*
 int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
 
 /* Tuning knobs (results agree to rounding whatever they say).  Known names:
+ *   "oneshot_allreduce" 1 / 0: small cross-rank sums on the one-shot IPC all-reduce (after pmf_ipc_import) or on the
+ *                context's other transport.
  *   "snmf_gram"  SNMF loops with both updates on iterate in Gram space -- P = M^T (V^T V), S = P M on
  *                k x n sized data, W materialised once after the last iteration -- instead of one pass
  *                over V per iteration: -1 automatic (default: CSR data always, dense data from about
@@ -210,6 +222,26 @@ int pmf_set_option(pmf_ctx* ctx, const char* name, int64_t value);
 typedef int (*pmf_host_allreduce_fn)(void* user, void* buf, int64_t count, int32_t is_f64);
 int pmf_set_host_allreduce(pmf_ctx* ctx, pmf_host_allreduce_fn fn, void* user);
 
+/* One-shot all-reduce for the small per-iteration sums (the reduction over m of pymf/nmf.py:124-125 is what
+ * the row sharding splits): every rank owns a receive area that all peers map through HIP IPC; ONE kernel per rank writes
+ * its partial of (W^T V | W^T W) into every peer's area, raises a flag there, waits for the peers' flags and adds the N
+ * partials in rank order -- bit-identical sums on all ranks, no ring / tree hops.  Payloads up to 256 KiB take it; larger
+ * ones (the n x n float64 V^T V of the Gram-space SNMF loop, NNDSVD's Gram matrix) stay on RCCL / the host transport.
+ *   pmf_ipc_export(ctx, rank, nranks, handle_out)   allocate + export this rank's area: PMF_IPC_HANDLE_BYTES bytes
+ *   (hand every rank's handle to every rank by any means, in rank order)
+ *   pmf_ipc_import(ctx, handles, nranks)            map the peers' areas; from here on small sums take the one-shot path
+ * 2 <= nranks <= 8, one node (ranks on different GPUs of one xGMI hive, or -- for plumbing checks -- sharing a GPU).
+ * pmf_collective_name: which transports this context's cross-rank sums use and how often each ran. */
+#define PMF_IPC_HANDLE_BYTES 64
+int pmf_ipc_export(pmf_ctx* ctx, int32_t rank, int32_t nranks, void* handle_out);
+int pmf_ipc_import(pmf_ctx* ctx, const void* handles, int32_t nranks);
+/* The one-shot path against the context's other transport (RCCL / host) on rank- and round-dependent payloads, `rounds`
+ * times (both slots get reused): *ok = 1 iff all rounds agreed and no wait ran out.  Every rank calls it at the same
+ * point; the caller combines the verdicts and switches the path off on ALL ranks if any disagreed
+ * (pmf_set_option(ctx, "oneshot_allreduce", 0)). */
+int pmf_ipc_selftest(pmf_ctx* ctx, int32_t rounds, int32_t* ok);
+const char* pmf_collective_name(pmf_ctx* ctx);
+
 /* Forget everything derived from V (||V||^2, cached partial sums): for streamed `data` that the caller
  * rebound or edited between calls. */
 int pmf_invalidate_v(pmf_ctx* ctx);
@@ -228,6 +260,13 @@ int pmf_kernel_exec_flops(pmf_ctx* ctx, double* executed_flops_per_launch);
 /* The individual launch durations behind pmf_kernel_stats' mean, in launch order: out_ms[0..min(cap,*count))
  * (ms, HIP events on the library's stream); *count = launches recorded since the last pmf_profile_enable. */
 int pmf_kernel_launch_ms(pmf_ctx* ctx, double* out_ms, int64_t cap, int64_t* count);
+
+/* NMFALS / NMFNNLS on the sixteen-lanes-per-problem kernel (pymf/nmfals.py:85-97, the row QPs of update_w): running totals
+ * since the last reset, counted on the device by the kernel itself -- out8[0..3] for the 16-slot frame, out8[4..7] for the
+ * 32-slot frame: wave tasks (4 problems each), passes (one solve per problem each), the sum over the passes of the largest
+ * system among the wave's four problems (the size the frame-padded elimination runs over), problems solved on that frame.
+ * bench.py's roofline block is built from them (live counts instead of recorded constants). */
+int pmf_nnqp_counters(pmf_ctx* ctx, int64_t* out8, int32_t reset);
 
 int pmf_synchronize(pmf_ctx* ctx);
 

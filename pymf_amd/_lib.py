@@ -22,6 +22,7 @@ ALGO_NMF, ALGO_NMFALS, ALGO_SNMF, ALGO_BNMF, ALGO_RNMF = 0, 1, 2, 3, 4
 COMPUTE_W, COMPUTE_H, COMPUTE_ERR = 1, 2, 4
 STREAM_RESID = 8
 NCCL_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 
 # every symbol include/pymf_hip.h declares: (name, restype, argtypes)
 _c = ctypes
@@ -35,12 +36,17 @@ SYMBOLS = [
     ("pmf_ctx_destroy", _c.c_int, [_ctx]),
     ("pmf_last_error", _c.c_char_p, [_ctx]),
     ("pmf_set_v_dense_f32", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64]),
+    ("pmf_set_v_dense_f64", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64]),
     ("pmf_set_v_csr_f32", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64]),
     ("pmf_fill_v_uniform", _c.c_int, [_ctx, _c.c_uint64, _c.c_int64]),
     ("pmf_set_w_f32", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_get_w_f32", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_set_h_f32", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_get_h_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_set_w_f64", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_get_w_f64", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_set_h_f64", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_get_h_f64", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_fill_w_uniform", _c.c_int, [_ctx, _c.c_uint64, _c.c_int64]),
     ("pmf_fill_h_uniform", _c.c_int, [_ctx, _c.c_uint64]),
     ("pmf_update_w", _c.c_int, [_ctx]),
@@ -64,11 +70,16 @@ SYMBOLS = [
     ("pmf_host_checksum", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("pmf_set_option", _c.c_int, [_ctx, _c.c_char_p, _c.c_int64]),
     ("pmf_set_host_allreduce", _c.c_int, [_ctx, _c.c_void_p, _c.c_void_p]),
+    ("pmf_ipc_export", _c.c_int, [_ctx, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    ("pmf_ipc_import", _c.c_int, [_ctx, _c.c_void_p, _c.c_int32]),
+    ("pmf_ipc_selftest", _c.c_int, [_ctx, _c.c_int32, _c.POINTER(_c.c_int32)]),
+    ("pmf_collective_name", _c.c_char_p, [_ctx]),
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
     ("pmf_snapshot_w", _c.c_int, [_ctx]),
     ("pmf_restore_w", _c.c_int, [_ctx]),
     ("pmf_kernel_exec_flops", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
+    ("pmf_nnqp_counters", _c.c_int, [_ctx, _c.POINTER(_c.c_int64), _c.c_int32]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
     ("pmf_path_name", _c.c_char_p, [_ctx]),
 ]
@@ -176,9 +187,12 @@ class Context(object):
 
     def set_v_dense(self, V):
         V = np.asarray(V)
+        assert V.shape == (self.m, self.n)
+        if V.dtype == np.float64 and V.flags.c_contiguous:       # rounded on the device: no host conversion pass
+            self._chk(self._lib.pmf_set_v_dense_f64(self._h, V.ctypes.data, V.shape[1]))
+            return
         if V.dtype != np.float32 or not V.flags.c_contiguous:
             V = _f32c(V)
-        assert V.shape == (self.m, self.n)
         self._chk(self._lib.pmf_set_v_dense_f32(self._h, V.ctypes.data, V.shape[1]))
 
     def set_v_csr(self, indptr, indices, vals):
@@ -198,15 +212,20 @@ class Context(object):
     def fill_h_uniform(self, seed):
         self._chk(self._lib.pmf_fill_h_uniform(self._h, seed))
 
+    def _set_factor(self, A, shape, f32_fn, f64_fn):
+        A = np.asarray(A)
+        assert A.shape == shape, (A.shape, shape)
+        if A.dtype == np.float64 and A.flags.c_contiguous:       # the reference's default dtype: rounded on the device
+            self._chk(f64_fn(self._h, A.ctypes.data))
+        else:
+            A = _f32c(A)
+            self._chk(f32_fn(self._h, A.ctypes.data))
+
     def set_w(self, W):
-        W = _f32c(W)
-        assert W.shape == (self.m, self.k)
-        self._chk(self._lib.pmf_set_w_f32(self._h, W.ctypes.data))
+        self._set_factor(W, (self.m, self.k), self._lib.pmf_set_w_f32, self._lib.pmf_set_w_f64)
 
     def set_h(self, H):
-        H = _f32c(H)
-        assert H.shape == (self.k, self.n)
-        self._chk(self._lib.pmf_set_h_f32(self._h, H.ctypes.data))
+        self._set_factor(H, (self.k, self.n), self._lib.pmf_set_h_f32, self._lib.pmf_set_h_f64)
 
     def get_w(self):
         W = np.empty((self.m, self.k), dtype=np.float32)
@@ -217,6 +236,25 @@ class Context(object):
         H = np.empty((self.k, self.n), dtype=np.float32)
         self._chk(self._lib.pmf_get_h_f32(self._h, H.ctypes.data))
         return H
+
+    def _get_into(self, out, shape, f32_fn, f64_fn):
+        """Write a factor straight into the caller's array when that is a C-contiguous float32 / float64 array of the
+        right shape (float64: widened on the device); returns False when it is not (the caller copies)."""
+        if type(out) is not np.ndarray or out.shape != shape or not out.flags.c_contiguous or not out.flags.writeable:
+            return False
+        if out.dtype == np.float64:
+            self._chk(f64_fn(self._h, out.ctypes.data))
+        elif out.dtype == np.float32:
+            self._chk(f32_fn(self._h, out.ctypes.data))
+        else:
+            return False
+        return True
+
+    def get_w_into(self, out):
+        return self._get_into(out, (self.m, self.k), self._lib.pmf_get_w_f32, self._lib.pmf_get_w_f64)
+
+    def get_h_into(self, out):
+        return self._get_into(out, (self.k, self.n), self._lib.pmf_get_h_f32, self._lib.pmf_get_h_f64)
 
     def update_w(self):
         self._chk(self._lib.pmf_update_w(self._h))
@@ -328,6 +366,26 @@ class Context(object):
         self._host_ar_cb = HOST_ALLREDUCE_FN(_cb)      # keep the trampoline alive
         self._chk(self._lib.pmf_set_host_allreduce(self._h, ctypes.cast(self._host_ar_cb, ctypes.c_void_p), None))
 
+    def enable_ipc_allreduce(self, rank, nranks, allgather_bytes):
+        """Set up the one-shot all-reduce (pmf_ipc_export / pmf_ipc_import): `allgather_bytes(b) -> [b_0 .. b_{N-1}]`
+        hands every rank's IPC handle to every rank (pymf_amd.dist.allgather_bytes)."""
+        buf = ctypes.create_string_buffer(IPC_HANDLE_BYTES)
+        self._chk(self._lib.pmf_ipc_export(self._h, int(rank), int(nranks), buf))
+        parts = allgather_bytes(buf.raw)
+        assert len(parts) == nranks and all(len(p_) == IPC_HANDLE_BYTES for p_ in parts)
+        allh = ctypes.create_string_buffer(b"".join(parts), IPC_HANDLE_BYTES * nranks)
+        self._chk(self._lib.pmf_ipc_import(self._h, allh, int(nranks)))
+
+    def ipc_selftest(self, rounds=6):
+        """True iff the one-shot all-reduce reproduced the other transport's sums `rounds` times (pmf_ipc_selftest)."""
+        ok = ctypes.c_int32(0)
+        self._chk(self._lib.pmf_ipc_selftest(self._h, int(rounds), ctypes.byref(ok)))
+        return bool(ok.value)
+
+    @property
+    def collective_name(self):
+        return (self._lib.pmf_collective_name(self._h) or b"").decode()
+
     def invalidate_v(self):
         self._chk(self._lib.pmf_invalidate_v(self._h))
 
@@ -344,6 +402,13 @@ class Context(object):
         n = ctypes.c_int64(0)
         self._chk(self._lib.pmf_kernel_launch_ms(self._h, out.ctypes.data, int(cap), ctypes.byref(n)))
         return out[:min(int(n.value), int(cap))]
+
+    def nnqp_counters(self, reset=False):
+        """Live counts of k_nnqp_quad over the W half steps since the last reset (pmf_nnqp_counters)."""
+        out = (ctypes.c_int64 * 8)()
+        self._chk(self._lib.pmf_nnqp_counters(self._h, out, 1 if reset else 0))
+        keys = ("wave_tasks", "passes", "sum_largest_system", "problems")
+        return {"frame16": dict(zip(keys, (int(x) for x in out[0:4]))), "frame32": dict(zip(keys, (int(x) for x in out[4:8])))}
 
     def synchronize(self):
         self._chk(self._lib.pmf_synchronize(self._h))

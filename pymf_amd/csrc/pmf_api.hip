@@ -35,6 +35,7 @@
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
 #include "pmf_topk.h"
+#include "pmf_ipc.h"
 
 namespace {
 
@@ -105,10 +106,14 @@ struct pmf_ctx {
   int64_t defer_cap = 0;
   int* dNbig = nullptr;         // [2 sites][3 + 2]: rotating counters of k_nnqp_quad (QuadCtl: nbig x 3, dcount x 2)
   int64_t quad_calls[2] = {0, 0};
+  unsigned long long* dQstat = nullptr;   // k_nnqp_quad, W half steps: [2 frames][4] running totals (pmf_nnqp_counters)
   double* dY0 = nullptr;        // k_nnqp_wave: inv(HA) f of every problem of a half step
   int64_t y0_cap = 0;
   int opt_nnqp_wave = 1;        // pmf_set_option("nnqp_wave"): 64 < num_bases <= 128 on the wave-per-problem block-pivoting kernel
   int opt_nnqp_frame16 = 1;     // pmf_set_option("nnqp_frame16"): the 16-slot frame first (three waves per SIMD)
+  int opt_nnqp_count = 0;       // pmf_set_option("nnqp_count"): the counting instantiations of k_nnqp_quad (pmf_nnqp_counters)
+  void* dStage = nullptr;       // staging area of the host <-> device transport (upload_rows / download_rows)
+  size_t stage_cap = 0;
   float* dWsnap = nullptr;      // pmf_snapshot_w: the W before a step that may fail
   bool wsnap_valid = false;
   int opt_nndsvd_topk = -1;     // pmf_set_option("nndsvd_topk"): -1 by size, 1 the filtered subspace iteration, 0 full Jacobi
@@ -151,6 +156,13 @@ struct pmf_ctx {
   uint32_t st_flags = 0;
   int64_t st_rows_seen = 0;
   int st_tiles = 0;
+  // one-shot all-reduce over IPC-mapped receive areas (pmf_ipc.h): payloads <= PMF_IPC_MAX_BYTES
+  IpcPeers ipc{};                            // ipc.nranks > 1: ready
+  bool ipc_exported = false;
+  int ipc_nranks_ready = 0;                  // ranks mapped by pmf_ipc_import (ipc.nranks = 0 while the path is switched off)
+  unsigned ipc_seq = 0;
+  int* dIpcErr = nullptr;
+  int64_t ipc_calls = 0, rccl_calls = 0, host_calls = 0;   // which transport the cross-rank sums took (pmf_collective_name)
   pmf_host_allreduce_fn host_ar = nullptr;   // host transport for the cross-rank sums (pmf_set_host_allreduce)
   void* host_ar_user = nullptr;
   std::vector<unsigned char> ar_buf;
@@ -365,7 +377,20 @@ int reduce_slabs(pmf_ctx* c, int nslabs) {
 // caller installed a host transport (pmf_set_host_allreduce: plumbing checks where the ranks cannot form
 // an RCCL communicator, e.g. several ranks sharing one GPU), a blocking round trip through the host.
 int allreduce_sum(pmf_ctx* c, void* p, size_t count, bool f64) {
+  const size_t nbytes = count * (f64 ? sizeof(double) : sizeof(float));
+  if (c->ipc.nranks > 1 && nbytes <= PMF_IPC_MAX_BYTES && count > 0) {
+    // one kernel: every rank writes its partial into every peer's receive area and adds the N partials in rank order
+    const unsigned seq = ++c->ipc_seq;
+    const int64_t vec = (int64_t)(count + 1023) / 1024;                         // ~1024 elements per workgroup
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vec, PMF_IPC_MAX_WGS));
+    if (f64) hipLaunchKernelGGL((k_ipc_allreduce<double>), dim3(grid), dim3(256), 0, c->stream, (double*)p, (int64_t)count, c->ipc, seq, c->dIpcErr);
+    else hipLaunchKernelGGL((k_ipc_allreduce<float>), dim3(grid), dim3(256), 0, c->stream, (float*)p, (int64_t)count, c->ipc, seq, c->dIpcErr);
+    HIPCHK(c, hipGetLastError());
+    ++c->ipc_calls;
+    return PMF_OK;
+  }
   if (c->host_ar) {
+    ++c->host_calls;
     const size_t bytes = count * (f64 ? sizeof(double) : sizeof(float));
     c->ar_buf.resize(bytes);
     HIPCHK(c, hipMemcpyAsync(c->ar_buf.data(), p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -376,12 +401,27 @@ int allreduce_sum(pmf_ctx* c, void* p, size_t count, bool f64) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PMF_OK;
   }
-  if (c->comm)
+  if (c->comm) {
+    ++c->rccl_calls;
     NCCLCHK(c, ncclAllReduce(p, p, count, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
+  }
   return PMF_OK;
 }
 
-bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != nullptr; }
+bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != nullptr || c->ipc.nranks > 1; }
+
+// a peer that never raised its flags (k_ipc_allreduce gave up after about a second of polling)
+int ipc_check(pmf_ctx* c) {
+  if (c->ipc.nranks <= 1 || !c->dIpcErr) return PMF_OK;
+  int e = 0;
+  HIPCHK(c, hipMemcpyAsync(&e, c->dIpcErr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (e) {
+    HIPCHK(c, hipMemsetAsync(c->dIpcErr, 0, sizeof(int), c->stream));
+    return fail(c, PMF_ENCCL, "one-shot all-reduce: a peer rank did not arrive (its flags were not raised within the polling limit)");
+  }
+  return PMF_OK;
+}
 
 int allreduce_ps(pmf_ctx* c) { return allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false); }
 
@@ -1570,7 +1610,7 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
   PMFCHK(nnqp_scratch(c, &qp));
   if (stat) stat_begin(c, SITE_NNQP_W);
   int rc = PMF_OK;
-  QuadCtl ctl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  QuadCtl ctl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const bool frames = quad && c->opt_nnqp_frame16;
   if (frames) {
     // The 16-slot frame pays when most problems fit it (settled active sets: three waves per SIMD instead of two).  Whether
@@ -1596,9 +1636,13 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
     ctl.nbig_next = base + (int)((t + 1) % 3);
     ctl.dcount = base + 3 + (int)(t & 1);
     ctl.dcount_next = base + 3 + (int)((t + 1) & 1);
+    if (stat && c->opt_nnqp_count) {                  // the W half step's live counts (counting instantiations)
+      if (!c->dQstat) PMFCHK(dalloc(c, &c->dQstat, 8));
+      ctl.stats = c->dQstat;
+    }
   }
   if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm,
-                                  frames ? &ctl : nullptr);
+                                  frames ? &ctl : nullptr, stat && c->opt_nnqp_count != 0);
   if (wave) {
     if (c->y0_cap < nprob) {                         // y0 = inv(HA) f of every problem (k_nnqp_y0): [nprob][KP] float64
       if (c->dY0) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->dY0)); c->dY0 = nullptr; }
@@ -1760,16 +1804,81 @@ int do_frobenius(pmf_ctx* c, double* out) {
   return PMF_OK;
 }
 
-int upload_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64_t sld, int64_t rows,
-                  int64_t cols) {
-  HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dld * sizeof(float), src, (size_t)sld * sizeof(float),
-                             (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, c->stream));
+// Staging area for the host <-> device transport (grown on demand, at most kStageBytes at a time)
+constexpr size_t kStageBytes = (size_t)256 << 20;
+int stage_reserve(pmf_ctx* c, size_t bytes) {
+  if (c->stage_cap >= bytes) return PMF_OK;
+  if (c->dStage) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->dStage)); c->dStage = nullptr; c->stage_cap = 0; }
+  HIPCHK(c, hipMalloc(&c->dStage, bytes));
+  c->stage_cap = bytes;
+  return PMF_OK;
+}
+
+// Host [rows][cols] (leading dimension sld, float32 or float64) -> device [rows][dld] float32, zero padded.  Contiguous host
+// rows go up as they are in ONE hipMemcpyAsync per chunk (56 GB/s from pageable memory; hipMemcpy2DAsync: 17) and are padded /
+// rounded by k_unpack_rows on the device; only a host array with a leading dimension of its own takes the pitched copy.
+template <typename T>
+int upload_rows(pmf_ctx* c, float* dst, int64_t dld, const T* src, int64_t sld, int64_t rows, int64_t cols) {
+  constexpr bool f32 = sizeof(T) == sizeof(float);
+  if (rows <= 0 || cols <= 0) return PMF_OK;
+  if (f32 && sld == cols && dld == cols) {                    // nothing to pad, nothing to round
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  }
+  if (f32 && sld != cols) {                                   // a pitched host array
+    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dld * sizeof(float), src, (size_t)sld * sizeof(float),
+                               (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  }
+  const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t)(kStageBytes / ((size_t)cols * sizeof(T)))));
+  PMFCHK(stage_reserve(c, (size_t)chunk_rows * cols * sizeof(T)));
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+    const int64_t nr = std::min(chunk_rows, rows - r0);
+    if (sld == cols)
+      HIPCHK(c, hipMemcpyAsync(c->dStage, src + r0 * sld, (size_t)nr * cols * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    else
+      HIPCHK(c, hipMemcpy2DAsync(c->dStage, (size_t)cols * sizeof(T), src + r0 * sld, (size_t)sld * sizeof(T), (size_t)cols * sizeof(T),
+                                 (size_t)nr, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)std::min<int64_t>((nr * dld + 255) / 256, 8192);
+    hipLaunchKernelGGL((k_unpack_rows<T>), dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const T*>(c->dStage), nr, cols, dst + r0 * dld, dld);
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PMF_OK;
 }
 
-int download_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64_t sld, int64_t rows,
-                    int64_t cols) {
+int upload_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64_t sld, int64_t rows, int64_t cols) {
+  return upload_rows<float>(c, dst, dld, src, sld, rows, cols);
+}
+
+// device [rows][sld] float32 -> host [rows][cols] contiguous float32 / float64 (the rounding to the host array's float64 on
+// the device: np.copyto(float64, float32) of a 1 048 576 x 64 W is 0.1 s in one host thread)
+template <typename T>
+int download_rows(pmf_ctx* c, T* dst, const float* src, int64_t sld, int64_t rows, int64_t cols) {
+  constexpr bool f32 = sizeof(T) == sizeof(float);
+  if (rows <= 0 || cols <= 0) return PMF_OK;
+  if (f32 && sld == cols) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)rows * cols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  }
+  const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t)(kStageBytes / ((size_t)cols * sizeof(T)))));
+  PMFCHK(stage_reserve(c, (size_t)chunk_rows * cols * sizeof(T)));
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+    const int64_t nr = std::min(chunk_rows, rows - r0);
+    const unsigned grid = (unsigned)std::min<int64_t>((nr * cols + 255) / 256, 8192);
+    hipLaunchKernelGGL((k_pack_rows<T>), dim3(grid), dim3(256), 0, c->stream, src + r0 * sld, sld, nr, cols, reinterpret_cast<T*>(c->dStage));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst + r0 * cols, c->dStage, (size_t)nr * cols * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));             // the staging area is reused by the next chunk
+  }
+  return PMF_OK;
+}
+
+int download_padded(pmf_ctx* c, float* dst, int64_t dld, const float* src, int64_t sld, int64_t rows, int64_t cols) {
+  if (dld == cols) return download_rows<float>(c, dst, src, sld, rows, cols);
   HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dld * sizeof(float), src, (size_t)sld * sizeof(float),
                              (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1986,13 +2095,19 @@ int pmf_ctx_destroy(pmf_ctx* c) {
   (void)hipSetDevice(c->device);   // teardown: there is nobody to report a failing release to
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->ipc_exported) {
+    for (int r = 0; r < c->ipc_nranks_ready; ++r)
+      if (r != c->ipc.me && c->ipc.area[r]) (void)hipIpcCloseMemHandle(c->ipc.area[r]);
+    if (c->ipc.area[c->ipc.me]) (void)hipFree(c->ipc.area[c->ipc.me]);
+  }
+  if (c->dIpcErr) (void)hipFree(c->dIpcErr);
   for (void* p : {(void*)c->dV, (void*)c->dW, (void*)c->dH, (void*)c->dG, (void*)c->dPS, (void*)c->dSlab,
                   (void*)c->dW1, (void*)c->dGinvT, (void*)c->dD, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
@@ -2103,6 +2218,43 @@ int pmf_set_w_f32(pmf_ctx* c, const float* W) {
   c->have_w = true; c->ps_valid = false; c->w_implicit = false;
   return PMF_OK;
 }
+int pmf_set_w_f64(pmf_ctx* c, const double* W) {
+  if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f64: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(zero_padding(c, c->dW, c->KP, c->mp, c->m, c->k));
+  PMFCHK(upload_rows<double>(c, c->dW, c->KP, W, c->k, c->m, c->k));
+  c->have_w = true; c->ps_valid = false; c->w_implicit = false;
+  return PMF_OK;
+}
+int pmf_get_w_f64(pmf_ctx* c, double* W) {
+  PMFCHK(need(c, false, true, false));
+  if (!W) return fail(c, PMF_EINVAL, "W is NULL");
+  PMFCHK(materialize_w(c));
+  return download_rows<double>(c, W, c->dW, c->KP, c->m, c->k);
+}
+int pmf_set_h_f64(pmf_ctx* c, const double* H) {
+  if (!c || !H) return fail(c, PMF_EINVAL, "pmf_set_h_f64: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(zero_padding(c, c->dH, c->np, c->KP, c->k, c->n));
+  PMFCHK(upload_rows<double>(c, c->dH, c->np, H, c->n, c->k, c->n));
+  c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;
+  return PMF_OK;
+}
+int pmf_get_h_f64(pmf_ctx* c, double* H) {
+  PMFCHK(need(c, false, false, true));
+  if (!H) return fail(c, PMF_EINVAL, "H is NULL");
+  return download_rows<double>(c, H, c->dH, c->np, c->k, c->n);
+}
+int pmf_set_v_dense_f64(pmf_ctx* c, const double* V, int64_t ld) {
+  if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f64: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(ensure_dv(c));
+  PMFCHK(upload_rows<double>(c, c->dV, c->np, V, ld, c->m, c->n));
+  c->have_v = true; c->v_csr = false; c->csr_dense = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
+  PMFCHK(local_vnorm(c));
+  return PMF_OK;
+}
+
 int pmf_get_w_f32(pmf_ctx* c, float* W) {
   PMFCHK(need(c, false, true, false));
   if (!W) return fail(c, PMF_EINVAL, "W is NULL");
@@ -2127,18 +2279,20 @@ int pmf_update_w(pmf_ctx* c) {
   PMFCHK(need(c, true, true, true));
   PMFCHK(do_update_w(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  PMFCHK(ipc_check(c));
   return check_singular(c);
 }
 int pmf_update_h(pmf_ctx* c) {
   PMFCHK(need(c, true, true, true));
   PMFCHK(do_update_h(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return PMF_OK;
+  return ipc_check(c);
 }
 int pmf_frobenius(pmf_ctx* c, double* out) {
   PMFCHK(need(c, true, true, true));
   if (!out) return fail(c, PMF_EINVAL, "out is NULL");
-  return do_frobenius(c, out);
+  PMFCHK(do_frobenius(c, out));
+  return ipc_check(c);
 }
 
 int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, double* ferr,
@@ -2169,7 +2323,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   const bool gram = cw && ch && snmf_gram_ok(c, niter);
   if (gram) PMFCHK(ensure_vgram(c));
   choose_stat_site(c, gram);
-  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !use_csr(c) && c->nb == 1)) && ce) || h_only) && !c->host_ar;   // NMF, BNMF, SNMF on the fused kernel
+  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !use_csr(c) && c->nb == 1)) && ce) || h_only) && !(c->host_ar && c->ipc.nranks <= 1);   // NMF, BNMF, SNMF on the fused kernel
   constexpr int kHostIters = 1, kChunk = 32;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
@@ -2298,6 +2452,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   c->last_loop_ms = ms;
   if (ce) for (int q = done; q < niter; ++q) ferr[q] = 0.0;   // as np.zeros(niter) leaves them (nmf.py:179-180)
   if (iters_done) *iters_done = done;
+  PMFCHK(ipc_check(c));
   return check_singular(c);
 }
 
@@ -2530,6 +2685,19 @@ extern "C" int pmf_debug_quad_counts(unsigned long long* out, int reset) {
 }
 #endif
 
+int pmf_nnqp_counters(pmf_ctx* c, int64_t* out8, int32_t reset) {
+  if (!c || !out8) return PMF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c->dQstat) {
+    HIPCHK(c, hipMemcpyAsync(h, c->dQstat, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIPCHK(c, hipMemsetAsync(c->dQstat, 0, sizeof(h), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  for (int q = 0; q < 8; ++q) out8[q] = (int64_t)h[q];
+  return PMF_OK;
+}
+
 int pmf_last_loop_ms(pmf_ctx* c, double* ms) {
   if (!c || !ms) return PMF_EINVAL;
   *ms = c->last_loop_ms;
@@ -2658,9 +2826,20 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     choose_stat_site(c, false);
     return PMF_OK;
   }
+  if (std::strcmp(name, "oneshot_allreduce") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "oneshot_allreduce: 0 or 1");
+    if (value == 1 && c->ipc_nranks_ready <= 1) return fail(c, PMF_EINVAL, "oneshot_allreduce: not set up (pmf_ipc_export / pmf_ipc_import)");
+    c->ipc.nranks = value ? c->ipc_nranks_ready : 0;
+    return PMF_OK;
+  }
   if (std::strcmp(name, "nnqp_wave") == 0) {
     if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "nnqp_wave: 0 or 1");
     c->opt_nnqp_wave = (int)value;
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "nnqp_count") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "nnqp_count: 0 or 1");
+    c->opt_nnqp_count = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "nnqp_frame16") == 0) {
@@ -2703,6 +2882,111 @@ int pmf_set_host_allreduce(pmf_ctx* c, pmf_host_allreduce_fn fn, void* user) {
   c->host_ar_user = user;
   c->ps_valid = false; c->vnorm_valid = false; c->trace_ready = false; c->c_valid = false;
   return PMF_OK;
+}
+
+// ---- one-shot all-reduce over IPC-mapped receive areas (pmf_ipc.h) ----
+int pmf_ipc_export(pmf_ctx* c, int32_t rank, int32_t nranks, void* handle_out) {
+  static_assert(sizeof(hipIpcMemHandle_t) <= PMF_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  if (!c || !handle_out || nranks < 2 || nranks > PMF_IPC_MAX_RANKS || rank < 0 || rank >= nranks)
+    return fail(c, PMF_EINVAL, "pmf_ipc_export: 2 <= nranks <= 8, 0 <= rank < nranks");
+  if (c->ipc_exported) return fail(c, PMF_EINVAL, "pmf_ipc_export: already exported");
+  HIPCHK(c, hipSetDevice(c->device));
+  void* area = nullptr;
+  const size_t bytes = pmf_ipc_area_bytes(nranks);
+  // fine-grained device memory: stores of a peer on another GPU must become visible WHILE this rank's kernel polls
+  hipError_t e = hipExtMallocWithFlags(&area, bytes, hipDeviceMallocFinegrained);
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess && hipIpcGetMemHandle(&h, area) != hipSuccess) { (void)hipFree(area); area = nullptr; e = hipErrorUnknown; }
+  if (e != hipSuccess) {                       // (a runtime that cannot export fine-grained memory: ordinary device memory)
+    (void)hipGetLastError();
+    HIPCHK(c, hipMalloc(&area, bytes));
+    HIPCHK(c, hipIpcGetMemHandle(&h, area));
+  }
+  HIPCHK(c, hipMemsetAsync(area, 0, bytes, c->stream));
+  if (!c->dIpcErr) PMFCHK(dalloc(c, &c->dIpcErr, 1));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memset(handle_out, 0, PMF_IPC_HANDLE_BYTES);
+  std::memcpy(handle_out, &h, sizeof(h));
+  c->ipc = IpcPeers{};
+  c->ipc.area[rank] = static_cast<char*>(area);
+  c->ipc.me = rank;
+  c->ipc.nranks = 0;                          // ready only after pmf_ipc_import
+  c->ipc_exported = true;
+  c->ipc_seq = 0;
+  return PMF_OK;
+}
+
+int pmf_ipc_import(pmf_ctx* c, const void* handles, int32_t nranks) {
+  if (!c || !handles || !c->ipc_exported || nranks < 2 || nranks > PMF_IPC_MAX_RANKS || c->ipc.me >= nranks)
+    return fail(c, PMF_EINVAL, "pmf_ipc_import: call pmf_ipc_export first; handles = nranks x PMF_IPC_HANDLE_BYTES in rank order");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int r = 0; r < nranks; ++r) {
+    if (r == c->ipc.me) continue;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, static_cast<const char*>(handles) + (size_t)r * PMF_IPC_HANDLE_BYTES, sizeof(h));
+    void* p = nullptr;
+    HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    c->ipc.area[r] = static_cast<char*>(p);
+  }
+  c->ipc.nranks = nranks;
+  c->ipc_nranks_ready = nranks;
+  return PMF_OK;
+}
+
+// The one-shot path against the context's other transport (RCCL or the host callback) on rank- and round-dependent
+// payloads of the per-iteration size; several rounds, so that both slots are reused.  *ok = 1 iff every round agreed and
+// no wait ran out.  The caller combines the ranks' verdicts and switches the path off everywhere when any rank saw a
+// difference (pmf_set_option("oneshot_allreduce", 0)): an all-reduce that has never run on the machine at hand does not
+// get to carry the iteration on trust.
+int pmf_ipc_selftest(pmf_ctx* c, int32_t rounds, int32_t* ok) {
+  if (!c || !ok) return PMF_EINVAL;
+  *ok = 0;
+  if (c->ipc_nranks_ready <= 1) return fail(c, PMF_EINVAL, "pmf_ipc_selftest: no one-shot all-reduce set up (pmf_ipc_import)");
+  if (!c->comm && !c->host_ar) return fail(c, PMF_EINVAL, "pmf_ipc_selftest: needs a second transport to compare with");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t count = std::min<size_t>((size_t)ps_elems(c), PMF_IPC_MAX_BYTES / sizeof(float));
+  float *dA = nullptr, *dB = nullptr;
+  HIPCHK(c, hipMalloc(&dA, count * sizeof(float)));
+  HIPCHK(c, hipMalloc(&dB, count * sizeof(float)));
+  std::vector<float> x(count), a(count), b(count);
+  bool good = true;
+  int rc = PMF_OK;
+  for (int t = 0; t < rounds && rc == PMF_OK; ++t) {
+    for (size_t i = 0; i < count; ++i) x[i] = (float)((c->ipc.me + 1) * (t + 1)) + 0.001f * (float)(i % 977);
+    const size_t cnt = t % 3 == 2 ? std::max<size_t>(1, count / 3) : count;      // (a shorter payload now and then)
+    if (hipMemcpyAsync(dA, x.data(), cnt * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(dB, x.data(), cnt * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = PMF_EHIP; break; }
+    c->ipc.nranks = c->ipc_nranks_ready;
+    rc = allreduce_sum(c, dA, cnt, false);
+    c->ipc.nranks = 0;                                 // the other transport
+    if (rc == PMF_OK) rc = allreduce_sum(c, dB, cnt, false);
+    c->ipc.nranks = c->ipc_nranks_ready;
+    if (rc != PMF_OK) break;
+    if (hipMemcpyAsync(a.data(), dA, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(b.data(), dB, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { rc = PMF_EHIP; break; }
+    if (ipc_check(c) != PMF_OK) { good = false; break; }
+    for (size_t i = 0; i < cnt; ++i)
+      if (!(std::fabs(a[i] - b[i]) <= 1e-5f * std::fabs(b[i]))) { good = false; break; }
+  }
+  (void)hipFree(dA); (void)hipFree(dB);
+  PMFCHK(rc);
+  *ok = good ? 1 : 0;
+  return PMF_OK;
+}
+
+const char* pmf_collective_name(pmf_ctx* c) {
+  if (!c) return "";
+  static thread_local std::string s;
+  const bool ipc = c->ipc.nranks > 1;
+  s = ipc ? "one-shot IPC all-reduce (payloads <= 256 KiB: every rank writes into every peer's receive area, sums in rank order)" : "";
+  if (c->comm) s += std::string(ipc ? " + " : "") + "ncclAllReduce (RCCL)" + (ipc ? " for larger payloads" : "");
+  if (c->host_ar) s += std::string(s.empty() ? "" : " + ") + "host transport (pmf_set_host_allreduce)" + (ipc ? " for larger payloads" : "");
+  if (s.empty()) s = "none";
+  char buf[96];
+  snprintf(buf, sizeof(buf), " [calls: ipc %lld, rccl %lld, host %lld]", (long long)c->ipc_calls, (long long)c->rccl_calls, (long long)c->host_calls);
+  s += buf;
+  return s.c_str();
 }
 
 int pmf_invalidate_v(pmf_ctx* c) {

@@ -154,8 +154,16 @@ struct QuadCtl {
   int* nbig;              // this call's count
   const int* nbig_prev;   // the previous call's
   int* nbig_next;         // the next call's: zeroed likewise
+  unsigned long long* stats;   // or NULL: [2 frames][4] running totals of this site -- wave tasks, passes, sum over the passes of the
+                               // largest system among the wave's four problems (what the frame-padded elimination runs over), problems
+                               // solved here (bench.py's roofline block reads them live: pmf_nnqp_counters); one atomic per wave
 };
-template <int QN, int NW>
+// COUNT: the instantiation behind pmf_set_option("nnqp_count", 1) -- it keeps QuadCtl::stats (a counting pass costs 8 % of
+// the kernel's time: the production loop carries no counters).  (y0 = B f of all problems as ONE float64-MFMA product ahead
+// of the kernel -- k_nnqp_y0, as k_nnqp_wave has it -- was measured and dropped: the product and the 134 MB it writes and
+// this kernel reads back cost more than the loop over B's rows below, 0.493 -> 0.526 ms per W half step at cfg3,
+// profiles/r04_experiments.md.)
+template <int QN, int NW, bool COUNT>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const double* __restrict__ Horig, const double* __restrict__ Hd,
                                                       const double* __restrict__ Bd,
                                                       int KP, int k, const float* __restrict__ F, int64_t f_sk,
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
   const int klive = __popcll(kmask);
 
   const int64_t nwaves = (int64_t)gridDim.x * NW;
+  unsigned st_tasks = 0, st_passes = 0, st_ns = 0, st_solved = 0;
   for (int64_t base = ((int64_t)blockIdx.x * NW + wv) * QPW; base < ntot; base += nwaves * QPW) {
     const int64_t slot = base + q;
     const bool valid = slot < ntot;
@@ -300,6 +309,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
 #endif
       ntmax = __builtin_amdgcn_readfirstlane(ntmax);
       (void)ntmax;                                   // (diagnostic builds count it: the product over P that is no longer formed)
+      if constexpr (COUNT) {
+        ++st_passes;
+        st_ns += (unsigned)(QN - jstart);
+      }
       {
         const int offP = comp ? 0 : shift, offN = comp ? shift : 0;   // the S list right-aligned at byte 32, the other at 0
 #pragma unroll
@@ -525,20 +538,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
         if (v < k) X[(int64_t)v * x_sk + prob * x_sp] = (float)(((pm >> v) & 1ull) ? x[s] : 0.0);
       }
     }
+    if constexpr (COUNT) {
+      ++st_tasks;
+      st_solved += (unsigned)__popcll(__ballot(valid && !deferred && r == 0));
+    }
     if (QN < 32 && ctl.dlist != nullptr && deferred && r == 0) ctl.dlist[atomicAdd(ctl.dcount, 1)] = (int)prob;
     // counted by the launch that sees the problem first (the listed ones were counted when they were put on the list)
     if (nbig != nullptr && valid && ever_big && r == 0 && (QN < 32 || ctl.dlist == nullptr || all_big)) atomicAdd(nbig, 1);
   }
+  if (COUNT && ctl.stats != nullptr && lane == 0 && st_tasks != 0) {
+    unsigned long long* st = ctl.stats + (QN < 32 ? 0 : 4);
+    atomicAdd(st + 0, (unsigned long long)st_tasks); atomicAdd(st + 1, (unsigned long long)st_passes);
+    atomicAdd(st + 2, (unsigned long long)st_ns); atomicAdd(st + 3, (unsigned long long)st_solved);
+  }
 }
 
-template <int QN, int NW>
+template <int QN, int NW, bool COUNT>
 static inline int launch_nnqp_quad_t(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
                                      int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, const QuadCtl& ctl) {
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[pmf_current_device()];
   const size_t smem = nnqp_quad_smem_bytes<QN, NW>();
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nnqp_quad<QN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nnqp_quad<QN, NW, COUNT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return PMF_EHIP;
     attr_done = true;
   }
@@ -546,19 +568,23 @@ static inline int launch_nnqp_quad_t(hipStream_t s, int KP, int k, const double*
   const int64_t cap = NW == 4 ? 512 : 256;             // two workgroups of 4 waves, or one of 12, per CU
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_nnqp_quad<QN, NW>), dim3((unsigned)blocks), dim3(64 * NW), smem, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm,
+  hipLaunchKernelGGL((k_nnqp_quad<QN, NW, COUNT>), dim3((unsigned)blocks), dim3(64 * NW), smem, s, Horig, Hd, Bd, KP, k, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm,
                      ctl);
   return PMF_OK;
 }
 
 // ctl == nullptr: every problem on the 32-slot frame (one launch).  Else: the 16-slot frame first (three waves per SIMD),
-// then the 32-slot frame for the problems it listed.
+// then the 32-slot frame for the problems it listed.  count: the counting instantiations (QuadCtl::stats).
 static inline int launch_nnqp_quad(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
-                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, const QuadCtl* ctl = nullptr) {
+                                   int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, const QuadCtl* ctl = nullptr,
+                                   bool count = false) {
   if (ctl) {
-    const int rc = launch_nnqp_quad_t<16, 12>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl);
+    const int rc = count ? launch_nnqp_quad_t<16, 12, true>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl)
+                         : launch_nnqp_quad_t<16, 12, false>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl);
     if (rc != PMF_OK) return rc;
-    return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl);
+    return count ? launch_nnqp_quad_t<32, 4, true>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl)
+                 : launch_nnqp_quad_t<32, 4, false>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, *ctl);
   }
-  return launch_nnqp_quad_t<32, 4>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm, QuadCtl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+  return launch_nnqp_quad_t<32, 4, false>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm,
+                                          QuadCtl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 }

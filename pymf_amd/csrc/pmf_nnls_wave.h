@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_nnqp_y0(const double* __restrict__ Bd, 
 }
 
 template <int NWV>   // waves (problems) per workgroup (1: see below)
-__global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_nnqp_wave(const double* __restrict__ Horig, const double* __restrict__ Hd,
+__global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restrict__ Horig, const double* __restrict__ Hd,
                                                   const double* __restrict__ Bd, int KP, int k,
                                                   const float* __restrict__ F, int64_t f_sk, int64_t f_sp,
                                                   float* __restrict__ X, int64_t x_sk, int64_t x_sp, int64_t nprob,

@@ -488,6 +488,29 @@ __global__ void k_fill_uniform(float* __restrict__ X, int64_t ld, int64_t rows, 
   X[r * ld + c] = u01_from(seed, (uint64_t)((row0 + r) * cols_global + c));
 }
 
+// ---- host <-> device transport of V / W / H (pmf_set_*_f32 / _f64, pmf_get_*_f64) ----------------------------------
+// The bytes cross PCIe as the host holds them -- ONE contiguous copy (56 GB/s from pageable memory on this part; a pitched
+// hipMemcpy2DAsync reaches 17) -- and the zero padding to [.][dld] and the float64 -> float32 rounding happen here, at HBM
+// speed, instead of in a single host thread (np.ascontiguousarray(float64 -> float32) of a 1 048 576 x 64 W: 0.2 s).
+// dst [rows][dld] float32 (columns >= cols are written as zero), src [rows][cols] contiguous T.
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpack_rows(const T* __restrict__ src, int64_t rows, int64_t cols, float* __restrict__ dst, int64_t dld) {
+  const int64_t total = rows * dld;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / dld, c = e - r * dld;
+    dst[e] = c < cols ? (float)src[r * cols + c] : 0.f;
+  }
+}
+// dst [rows][cols] contiguous T, src [rows][sld] float32
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_rows(const float* __restrict__ src, int64_t sld, int64_t rows, int64_t cols, T* __restrict__ dst) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / cols, c = e - r * cols;
+    dst[e] = (T)src[r * sld + c];
+  }
+}
+
 // ---- streamed V (pmf_stream_*): accumulators that live across the tiles of one pass ----------
 // acc[e] (+)= sum over slabs of slab[c][e]  (float64; first != 0 starts a new pass)
 __global__ __launch_bounds__(256) void k_reduce_slabs_acc(const float* __restrict__ slab, int nslabs, int64_t E,

@@ -63,13 +63,45 @@ def world():
 
 
 def transport():
-    """How the per-iteration sums cross the ranks: "rccl" (default: ncclAllReduce over xGMI inside
-    libpymf_hip) or "host" (env PYMF_DIST_TRANSPORT=host: through this module's TCP star and
-    pmf_set_host_allreduce -- for plumbing checks where several ranks share one GPU; slow)."""
+    """How the per-iteration sums cross the ranks: "rccl" (default: ncclAllReduce over xGMI inside libpymf_hip, with the
+    one-shot IPC all-reduce in front of it for payloads up to 256 KiB when it passes its self-test -- oneshot()), "host"
+    (env PYMF_DIST_TRANSPORT=host: through this module's TCP star and pmf_set_host_allreduce -- plumbing checks where
+    several ranks share one GPU; slow) or "ipc" (the host transport with the one-shot IPC all-reduce in front of it: how
+    the one-shot kernel is exercised by two processes on ONE GPU, where RCCL refuses to form a communicator)."""
     t = os.environ.get("PYMF_DIST_TRANSPORT", "rccl").lower()
-    if t not in ("rccl", "host"):
-        raise ValueError("PYMF_DIST_TRANSPORT must be 'rccl' or 'host'")
+    if t not in ("rccl", "host", "ipc"):
+        raise ValueError("PYMF_DIST_TRANSPORT must be 'rccl', 'host' or 'ipc'")
     return t
+
+
+def oneshot():
+    """Put the one-shot IPC all-reduce in front of RCCL?  Yes for 2..8 ranks of ONE node (env PYMF_DIST_ONESHOT=0 says
+    no); it still has to reproduce RCCL's sums in Context.ipc_selftest() on every rank before it carries anything."""
+    if os.environ.get("PYMF_DIST_ONESHOT", "1") == "0" or _WORLD is None or not (2 <= _WORLD.size <= 8):
+        return False
+    return int(os.environ.get("LOCAL_WORLD_SIZE", str(_WORLD.size)) or _WORLD.size) == _WORLD.size
+
+
+def setup_collectives(ctx):
+    """After a multi-rank Context exists on every rank: the transports behind its cross-rank sums.  Collective (every
+    rank calls it at the same point).  Returns Context.collective_name."""
+    w, t = _WORLD, transport()
+    if w is None or w.size == 1:
+        return getattr(ctx, "collective_name", "none")
+    if t in ("host", "ipc"):
+        ctx.set_host_allreduce(allreduce_sum_array)
+    if t == "ipc" or (t == "rccl" and oneshot()):
+        try:
+            ctx.enable_ipc_allreduce(w.rank, w.size, allgather_bytes)
+            ok = ctx.ipc_selftest()
+        except Exception:                      # (export / import refused: every rank still takes part in the vote below)
+            ok = False
+        if allreduce_max(0.0 if ok else 1.0) > 0.0:
+            try:
+                ctx.set_option("oneshot_allreduce", 0)
+            except Exception:
+                pass
+    return getattr(ctx, "collective_name", "")
 
 
 # ---- framing ---------------------------------------------------------------------------------
@@ -220,7 +252,7 @@ def init_from_env(make_nccl_id=None, timeout=None):
     key = _key(addr, mport, size, bind_ip)
     _WORLD = World(rank, size, local_rank, None)
     _PEERS = _serve(bind_ip, base, size, key, timeout) if rank == 0 else _join(bind_ip, base, rank, key, timeout)
-    if make_nccl_id is None and transport() == "host":
+    if make_nccl_id is None and transport() in ("host", "ipc"):
         return _WORLD                                  # no RCCL communicator will be created
     if make_nccl_id is None:
         from . import _lib

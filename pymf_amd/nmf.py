@@ -24,6 +24,7 @@ current host arrays.
 import logging
 import os
 import sys
+import time
 import warnings
 
 import numpy as np
@@ -35,11 +36,10 @@ __all__ = ["NMF"]
 
 
 def _is_sparse(x):
-    try:
-        import scipy.sparse
-        return scipy.sparse.issparse(x)
-    except Exception:        # pragma: no cover
-        return False
+    # (an object can only be a scipy.sparse matrix if somebody has imported scipy.sparse: importing it here costs a first
+    # factorize() of dense data 0.1 s)
+    sp = sys.modules.get("scipy.sparse")
+    return sp is not None and sp.issparse(x)
 
 
 def _fingerprint(a):
@@ -134,6 +134,13 @@ class NMF(object):
         self._defer_pull = False
         self._in_loop = False
         self._loop_data_checked = False
+        #: wall-clock ms of the last factorize() call's parts: ctx (context creation), init (lazy init_w / init_h),
+        #: upload (digests + host -> device copies of data, W, H), loop (device loop), total
+        self.last_call_ms = {}
+
+    def _tick(self, key, t0):
+        d = self.__dict__.setdefault("last_call_ms", {})
+        d[key] = d.get(key, 0.0) + (time.perf_counter() - t0) * 1e3
 
     # ---- W / H: plain attributes to the user, lazily refreshed from the device in the hook loop ----
     def _factor_get(self, name):
@@ -203,18 +210,21 @@ class NMF(object):
 
     def _context(self):
         if self._ctx is None:
+            t0 = time.perf_counter()
             w = self._world()
-            if w.size > 1 and _dist.transport() == "host":
-                # ranks that cannot form an RCCL communicator (e.g. sharing one GPU): the sums of
-                # (W^T V | W^T W) cross the ranks through the host (pmf_set_host_allreduce)
+            if w.size > 1 and _dist.transport() in ("host", "ipc"):
+                # ranks that cannot form an RCCL communicator (e.g. sharing one GPU): the sums of (W^T V | W^T W) cross
+                # the ranks through the host (pmf_set_host_allreduce) -- "ipc": through the one-shot IPC all-reduce
                 dev = w.local_rank % max(1, _lib.device_count())
                 self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
                                          self._num_bases, device=dev)
-                self._ctx.set_host_allreduce(_dist.allreduce_sum_array)
             else:
                 self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
                                          self._num_bases, device=w.local_rank, rank=w.rank,
                                          nranks=w.size, nccl_id=w.nccl_id)
+            if w.size > 1:
+                _dist.setup_collectives(self._ctx)
+            self._tick("ctx", t0)
         return self._ctx
 
     def invalidate_data(self):
@@ -281,6 +291,13 @@ class NMF(object):
 
     def _sync_to_device(self, with_data=True):
         ctx = self._context()
+        t0 = time.perf_counter()
+        try:
+            return self._sync_to_device_timed(ctx, with_data)
+        finally:
+            self._tick("upload", t0)
+
+    def _sync_to_device_timed(self, ctx, with_data):
         if with_data and (not self._in_loop or not self._loop_data_checked):
             # inside factorize()'s hook loop `data` is checked once, by the first shipped hook that runs
             self._loop_data_checked = True
@@ -315,15 +332,17 @@ class NMF(object):
         ctx = self._context()
         self._host_stale.discard(name)
         if name == "W":
-            w = ctx.get_w()
             cur = self.__dict__["_W"]
             if self._REBIND_W:
+                w = ctx.get_w()
                 self.__dict__["_W"] = w.astype(cur.dtype, copy=False) if cur.dtype != np.float32 else w
-            else:
-                np.copyto(cur, w, casting="same_kind")          # in place, nmf.py:131-132
+            elif not (hasattr(ctx, "get_w_into") and ctx.get_w_into(cur)):   # in place, nmf.py:131-132 (float64: widened on the device)
+                np.copyto(cur, ctx.get_w(), casting="same_kind")
             self._w_fp = _fingerprint(self.__dict__["_W"])
         else:
-            np.copyto(self.__dict__["_H"], ctx.get_h(), casting="same_kind")  # in place, nmf.py:125-126
+            cur = self.__dict__["_H"]
+            if not (hasattr(ctx, "get_h_into") and ctx.get_h_into(cur)):     # in place, nmf.py:125-126
+                np.copyto(cur, ctx.get_h(), casting="same_kind")
             self._h_fp = _fingerprint(self.__dict__["_H"])
 
     def _pull(self, ctx, want_w, want_h):
@@ -458,10 +477,13 @@ class NMF(object):
         else:
             self._logger.setLevel(logging.ERROR)
 
+        t_call = time.perf_counter()
+        self.last_call_ms = {}
         if not self._has('W'):                                 # nmf.py:173-174
             self.init_w()
         if not self._has('H'):                                 # nmf.py:176-177
             self.init_h()
+        self._tick("init", t_call)
 
         if compute_err:                                        # nmf.py:179-180
             self.ferr = np.zeros(niter)
@@ -493,6 +515,9 @@ class NMF(object):
                 raise
         self._last_iters = done
         self._pull(ctx, compute_w and done > 0, compute_h and done > 0)
+        if hasattr(ctx, "last_loop_ms"):
+            self.last_call_ms["loop"] = ctx.last_loop_ms()
+        self._tick("total", t_call)
 
         for i in range(done):                                  # nmf.py:189-194
             if compute_err:

@@ -20,6 +20,13 @@ import pymf_amd                          # noqa: E402
 import oracle                            # noqa: E402
 
 FAKE = "--fake" in sys.argv
+DIGEST = "--digest" in sys.argv        # print digests of the factors: the one-shot IPC all-reduce vs the host transport, bit for bit
+
+
+def digest(name, a):
+    if DIGEST:
+        import hashlib
+        print("digest %s %s" % (name, hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()))
 
 
 class FakeContext(object):
@@ -118,6 +125,9 @@ def main():
     check("NMF ferr", mdl.ferr, ref.ferr, tolf)
     hs = dist.allgather_bytes(np.ascontiguousarray(mdl.H).tobytes())
     assert all(h == hs[0] for h in hs), "H must be bit-identical on every rank"
+    digest("NMF W", mdl.W); digest("NMF H", mdl.H); digest("NMF ferr", mdl.ferr)
+    if not FAKE:
+        print("collective %s" % mdl._ctx.collective_name)
     # single hooks and the error under the multi-rank world
     mdl.update_w(); ref.update_w()
     mdl.update_h(); ref.update_h()
@@ -141,6 +151,7 @@ def main():
     assert len(set(lens)) == 1 and lens[0] < 300, lens
     fs = dist.allgather_bytes(np.ascontiguousarray(e.ferr, dtype=np.float64).tobytes())
     assert all(f == fs[0] for f in fs), "ferr must be bit-identical on every rank"
+    digest("early-exit ferr", e.ferr)
 
     if not FAKE:
         # ---- SNMF (mixed-sign data) ----
@@ -154,6 +165,7 @@ def main():
         check("SNMF W", gather_rows(s.W), so.W, 5e-5)
         check("SNMF H", s.H, so.H, 2e-5)
         check("SNMF ferr", s.ferr, so.ferr, 2e-5)
+        digest("SNMF W", s.W); digest("SNMF H", s.H)
         # ---- RNMF: init_h normalises the columns of W over ALL ranks' rows ----
         from pymf_amd.rnmf import RNMF
         Vr = V.copy()
@@ -167,6 +179,7 @@ def main():
         check("RNMF W", gather_rows(r.W), ro.W, 2e-3)
         check("RNMF H", r.H, ro.H, 2e-3)
         check("RNMF ferr", r.ferr, ro.ferr, 2e-4)
+        digest("RNMF W", r.W); digest("RNMF H", r.H)
         # ---- NNDSVD: Gram matrix and split norms summed over the ranks ----
         nd = pymf_amd.NNDSVD(V[lo:hi], num_bases=6)
         nd.factorize()

@@ -107,6 +107,25 @@ def test_class_level_multi_rank_path_on_one_gpu():
     _spawn_workers("_dist_class_worker.py", 2, extra_env={"PYMF_DIST_TRANSPORT": "host", "LOCAL_RANK": "0"})
 
 
+@pytest.mark.gpu
+def test_one_shot_ipc_allreduce_two_processes_on_one_gpu():
+    """the one-shot all-reduce (pmf_ipc.h: every rank writes its partial of (W^T V | W^T W) into
+    every peer's IPC-mapped receive area and adds the N partials in rank order) with two PROCESSES sharing GPU 0 --
+    RCCL refuses that set-up ("Duplicate GPU detected").  The class-level worker must reproduce the unsharded oracle,
+    keep H bit-identical across the ranks, leave an early-exiting loop at the same iteration on both ranks, AND give
+    the same bits as the host transport (both add in rank order): the worker prints digests that are compared here."""
+    outs_ipc = _spawn_workers("_dist_class_worker.py", 2, extra_args=["--digest"],
+                              extra_env={"PYMF_DIST_TRANSPORT": "ipc", "LOCAL_RANK": "0"})
+    outs_host = _spawn_workers("_dist_class_worker.py", 2, extra_args=["--digest"],
+                               extra_env={"PYMF_DIST_TRANSPORT": "host", "LOCAL_RANK": "0"})
+    for a, b in zip(outs_ipc, outs_host):
+        da = [l for l in a.splitlines() if l.startswith("digest ")]
+        db = [l for l in b.splitlines() if l.startswith("digest ")]
+        assert da and da == db, (da, db)
+        assert any("one-shot IPC all-reduce" in l and "ipc 0," not in l for l in a.splitlines() if l.startswith("collective ")), a
+        assert all("one-shot" not in l for l in b.splitlines() if l.startswith("collective ")), b
+
+
 # ---- who may join the rendezvous (pymf_amd/dist.py: bind, challenge-response, frame cap) ----------------
 def test_non_loopback_rendezvous_needs_a_secret(monkeypatch):
     from pymf_amd import dist

@@ -936,6 +936,41 @@ def _synthetic_rows(seed, rows, ncols):
     return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0))
 
 
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg2"])
+def test_full_size_update_w_rows_and_h_vs_the_oracle(pm, cfg):
+    """the BASELINE shapes AT FULL SIZE against the oracle itself (not HIP against HIP).  After ONE
+    update_w on the full matrix every 4097th row of W is compared with oracle.nmf_update_w (nmf.py:128-132, float64) on
+    exactly those rows -- the W rule is row-local, and the counter-based V can be rebuilt row by row on the host.  The
+    update_h that follows needs all rows: its oracle value (nmf.py:122-126) is formed in float64 from the device's new
+    W and the rebuilt V in row chunks -- every row of the matrix takes part."""
+    import oracle
+    from pymf_amd import _lib
+    m, n, k = (1048576, 256, 64) if cfg == "cfg4" else (65536, 512, 32)
+    a = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    a.fill_v_uniform(1234); a.fill_w_uniform(42); a.fill_h_uniform(43)
+    rows = np.arange(0, m, 4097)
+    H0 = a.get_h().astype(np.float64)
+    W0s = a.get_w()[rows].astype(np.float64)
+    Vs = _synthetic_rows(1234, rows, n)
+    a.update_w()
+    W1 = a.get_w()
+    Wref = W0s.copy()
+    oracle.nmf_update_w(Vs, Wref, H0.copy())
+    assert rel_fro(W1[rows], Wref, what="%s full size: sampled rows of W after one update_w vs oracle.nmf_update_w" % cfg) < 2e-6
+    a.update_h()
+    H1 = a.get_h()
+    # oracle H step from the device's W (float64 accumulation over ALL rows, V rebuilt chunk by chunk)
+    P = np.zeros((k, n))
+    W1d = W1.astype(np.float64)
+    for r0 in range(0, m, 65536):
+        r1 = min(m, r0 + 65536)
+        P += W1d[r0:r1].T.dot(_synthetic_rows(1234, np.arange(r0, r1), n).astype(np.float64))
+    S = W1d.T.dot(W1d)
+    Href = H0 * P / (S.dot(H0) + 1e-9)                       # nmf.py:122-126
+    assert rel_fro(H1, Href, what="%s full size: H after update_h vs the float64 rule over all rows" % cfg) < 2e-6
+    a.close()
+
+
 def test_full_size_properties_cfg2(pm):
     """cfg2 (NMF 65,536 x 512, k = 32, the two-waves-per-block fused kernel): monotone objective, fused
     one-pass == two-pass tiled hooks, trace-identity error == direct residual, non-negativity."""

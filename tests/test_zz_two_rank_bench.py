@@ -15,9 +15,10 @@ sys.path.insert(0, ROOT)
 @pytest.mark.gpu
 def test_two_rank_bench_line_on_one_gpu():
     """The N > 1 harness end to end on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py
-    --gpus 2 --debug-share-gpu` (both ranks on device 0, each with its own 1-rank RCCL communicator: rows still
-    sharded, barriers and the max over ranks still used).  Rank 0 prints ONE line; both ranks' own step times are
-    in it and agree (same work, same GPU), and `value` is K over the slowest."""
+    --gpus 2 --debug-share-gpu` (both ranks on device 0; rows sharded, (W^T V | W^T W) summed across the two PROCESSES by
+    the one-shot IPC all-reduce in every iteration -- RCCL refuses two ranks on one GPU --, barriers and the max over
+    ranks used).  Rank 0 prints ONE line; both ranks' own step times are in it and agree (same work, same GPU), `value`
+    is K over the slowest, and the line says which collective ran."""
     import json
     import socket
     import subprocess
@@ -56,3 +57,4 @@ def test_two_rank_bench_line_on_one_gpu():
     assert abs(a - b) <= 0.5 * max(a, b), j["rank_ms_per_step"]       # two processes time-slicing one GPU
     assert abs(j["ms_per_step"] - max(a, b)) < 1e-9 and abs(j["value"] - 1e3 / max(a, b)) < 1e-6 * j["value"]
     assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None
+    assert "one-shot IPC all-reduce" in j["config"]["collective"] and "ipc 0," not in j["config"]["collective"], j["config"]["collective"]
