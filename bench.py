@@ -579,8 +579,9 @@ def main():
             out["config"]["gram_space_loop_w_once_per_factorize"] = gram_loop
             out["config"]["one_pass_csr_kernel_iters_per_sec"] = rate_pass_per_iter
             out["config"]["loop"] = ("k x n sized Gram-space iteration (P = M^T (V^T V), S = P M) + W = V M written in EVERY "
-                                     "iteration, as the reference's update_w does" if stats["name"].startswith("k_csr_w")
-                                     else "one pass over the CSR rows per iteration")
+                                     "iteration, as the reference's update_w does; the write of iteration i runs on a stream of its "
+                                     "own beside the k x n sized kernels of iteration i + 1 (option snmf_w_pipe; 0 = stream order)"
+                                     if stats["name"].startswith("k_csr_w") else "one pass over the CSR rows per iteration")
         if w.size == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.config, m, n, k)
             fac = cb.pop("_oracle_factors", None)

@@ -183,6 +183,12 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
 /* Tuning knobs (results agree to rounding whatever they say).  Known names:
  *   "oneshot_allreduce" 1 / 0: small cross-rank sums on the one-shot IPC all-reduce (after pmf_ipc_import) or on the
  *                context's other transport.
+ *   "snmf_w_pipe" snmf_gram = 2 on CSR data: the W = V M write of iteration i runs on a stream of its own beside the k x n
+ *                sized kernels of iteration i + 1 (they never read W; M is double buffered); the value is the number of
+ *                workgroup slots the write launch leaves free so that those kernels can be placed while it runs (default
+ *                32); 0: everything in stream order.  Bit-identical results.
+ *   "nnqp_count" 1: the W half steps of NMFALS / NMFNNLS run the COUNTING instantiation of the sixteen-lanes-per-problem
+ *                kernel (pmf_nnqp_counters; it costs the kernel 8 %); 0 (default): no counters in the loop.
  *   "snmf_gram"  SNMF loops with both updates on iterate in Gram space -- P = M^T (V^T V), S = P M on
  *                k x n sized data, W materialised once after the last iteration -- instead of one pass
  *                over V per iteration: -1 automatic (default: CSR data always, dense data from about

@@ -78,6 +78,14 @@ struct pmf_ctx {
   bool c_valid = false;         // dC holds the all-rank V^T V of the current V
   int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible, 2 = 1 + W written in every iteration
   bool w_implicit = false;      // the loop ran in Gram space: dW is stale, W = V M with the M at hand (materialize_w)
+  // snmf_gram = 2 on CSR data: W = V M of iteration i is written on a stream of its own BESIDE the k x n sized kernels of
+  // iteration i + 1 (they never read W); M is double buffered (dW1, dW1 + np KP) and the write launch leaves a few
+  // workgroup slots free so that the small kernels can be placed while it runs (w_pipe_* below, materialize_w)
+  hipStream_t w_stream = nullptr;
+  hipEvent_t ev_mt[2] = {nullptr, nullptr}, ev_w[2] = {nullptr, nullptr};
+  bool ev_w_pending[2] = {false, false};
+  int64_t w_pipe_it = 0;        // writes enqueued so far: buffer parity
+  int opt_w_pipe = 32;          // pmf_set_option("snmf_w_pipe"): workgroup slots the write launch leaves free; 0 = in stream order
   float* dD = nullptr;          // RNMF: D = S - V (rnmf.py:102,111), [mp][np]
   bool s_valid = false;         // RNMF: D has been formed (update_s ran)
   double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
@@ -206,7 +214,7 @@ int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 int ensure_dv(pmf_ctx* c);
 
 int csr_ps(pmf_ctx* c);
-int csr_w(pmf_ctx* c);
+int csr_w(pmf_ctx* c, hipStream_t stream, const float* Mbuf, int reserve);
 int materialize_w(pmf_ctx* c);
 
 template <typename T>
@@ -442,7 +450,7 @@ FusedCtl take_fused_ctl(pmf_ctx* c) {
 
 // ---- CSR (SNMF) ----------------------------------------------------------------------------
 template <int NT>
-int launch_csr_w_blocks(pmf_ctx* c) {
+int launch_csr_w_blocks(pmf_ctx* c, hipStream_t stream, const float* Mbuf, int reserve) {
   const size_t mbytes = (size_t)c->np * c->KP * sizeof(float);
   const int in_lds = mbytes <= 128 * 1024;
   const size_t smem = in_lds ? mbytes : 0;
@@ -458,21 +466,43 @@ int launch_csr_w_blocks(pmf_ctx* c) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   const int64_t nblk = c->mp / 16;
   const int per_cu = smem <= 80 * 1024 ? 2 : 1;     // workgroups of 16 waves per CU
-  const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nblk + 15) / 16, (int64_t)cus * per_cu));
-  hipLaunchKernelGGL((k_csr_w_blocks<NT>), dim3(wgs), dim3(1024), smem, c->stream, c->dIndptr, c->dIndices, c->dVals,
-                     nblk, c->np, c->dW1, c->dW, in_lds);
+  const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nblk + 15) / 16, (int64_t)cus * per_cu - reserve));
+  hipLaunchKernelGGL((k_csr_w_blocks<NT>), dim3(wgs), dim3(1024), smem, stream, c->dIndptr, c->dIndices, c->dVals,
+                     nblk, c->np, Mbuf, c->dW, in_lds);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
 
-int csr_w(pmf_ctx* c) {   // W = V M, M = H^T inv(H H^T) (np x KP) in dW1 (snmf_inverse formed it)
+// W = V M, M = H^T inv(H H^T) (np x KP) in dW1 (snmf_inverse formed it) -- or, for the pipelined write, in Mbuf on `stream`
+int csr_w(pmf_ctx* c, hipStream_t stream = nullptr, const float* Mbuf = nullptr, int reserve = 0) {
+  if (!stream) stream = c->stream;
+  if (!Mbuf) Mbuf = c->dW1;
   switch (c->NT) {
-    case 1: return launch_csr_w_blocks<1>(c);
-    case 2: return launch_csr_w_blocks<2>(c);
-    case 4: return launch_csr_w_blocks<4>(c);
-    case 8: return launch_csr_w_blocks<8>(c);
+    case 1: return launch_csr_w_blocks<1>(c, stream, Mbuf, reserve);
+    case 2: return launch_csr_w_blocks<2>(c, stream, Mbuf, reserve);
+    case 4: return launch_csr_w_blocks<4>(c, stream, Mbuf, reserve);
+    case 8: return launch_csr_w_blocks<8>(c, stream, Mbuf, reserve);
   }
   return fail(c, PMF_EINVAL, "bad NT");
+}
+
+// The pipelined W write of the snmf_gram = 2 loop on CSR data.
+bool w_pipe_on(const pmf_ctx* c) { return c->opt_snmf_gram == 2 && use_csr(c) && c->opt_w_pipe > 0 && (size_t)2 * c->np * c->KP <= (size_t)std::max<int64_t>(c->mp, c->np) * c->KP; }
+float* w_pipe_mbuf(pmf_ctx* c, int64_t it) { return c->dW1 + (size_t)(it & 1) * c->np * c->KP; }
+int w_pipe_init(pmf_ctx* c) {
+  if (c->w_stream) return PMF_OK;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->w_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_mt[b], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_w[b], hipEventDisableTiming));
+  }
+  return PMF_OK;
+}
+// every write enqueued on the side stream has finished before anything later on the main stream runs
+int w_pipe_join(pmf_ctx* c) {
+  for (int b = 0; b < 2; ++b)
+    if (c->ev_w_pending[b]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_w[b], 0)); c->ev_w_pending[b] = false; }
+  return PMF_OK;
 }
 
 int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by the CSR scatter
@@ -1423,9 +1453,35 @@ int snmf_gram_iteration(pmf_ctx* c) {
   c->trace_ready = false;
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(launch_inverse(c));
+  const bool pipe = w_pipe_on(c);
+  float* mcsr = c->dW1;
+  if (pipe) {                  // M of this iteration goes into the buffer the write before last has finished reading
+    PMFCHK(w_pipe_init(c));
+    const int b = (int)(c->w_pipe_it & 1);
+    if (c->ev_w_pending[b]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_w[b], 0)); c->ev_w_pending[b] = false; }
+    mcsr = w_pipe_mbuf(c, c->w_pipe_it);
+  }
   hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dH, (int64_t)np, np, KP,
-                     c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? c->dW1 : (float*)nullptr, c->dMTd, c->stop_arg);
+                     c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? mcsr : (float*)nullptr, c->dMTd, c->stop_arg);
   HIPCHK(c, hipGetLastError());
+  if (pipe) {                  // W = V M on the side stream, beside everything that follows here (nothing below reads W)
+    const int b = (int)(c->w_pipe_it & 1);
+    HIPCHK(c, hipEventRecord(c->ev_mt[b], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->w_stream, c->ev_mt[b], 0));
+    if (c->profile && c->stat.site == SITE_MATERIALIZE) {     // the launch's own HIP events, on the stream it runs on
+      KernelStat& st = c->stat;
+      if (st.used + 2 > st.ev.size()) for (int q = 0; q < 2; ++q) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) st.ev.push_back(e); }
+      if (st.used + 2 <= st.ev.size()) (void)hipEventRecord(st.ev[st.used], c->w_stream);
+    }
+    PMFCHK(csr_w(c, c->w_stream, mcsr, c->opt_w_pipe));
+    if (c->profile && c->stat.site == SITE_MATERIALIZE && c->stat.used + 2 <= c->stat.ev.size()) {
+      (void)hipEventRecord(c->stat.ev[c->stat.used + 1], c->w_stream);
+      c->stat.used += 2;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_w[b], c->w_stream));
+    c->ev_w_pending[b] = true;
+    ++c->w_pipe_it;
+  }
   // P = M^T C  (KP x np), float64 kept for S, float32 into (P | S)
   hipLaunchKernelGGL((k_dgemm_mfma<false>), dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dMTd,
                      (int64_t)np, c->dC, (int64_t)np, np, c->dPd, (int64_t)np, c->dPS, ldp, c->stop_arg);
@@ -1434,15 +1490,16 @@ int snmf_gram_iteration(pmf_ctx* c) {
   hipLaunchKernelGGL((k_dgemm_mfma<true>), dim3((unsigned)(KP / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dPd,
                      (int64_t)np, c->dMTd, (int64_t)np, np, (double*)nullptr, (int64_t)0, c->dPS + np, ldp, c->stop_arg);
   HIPCHK(c, hipGetLastError());
-  c->w_implicit = true;       // dW is stale from here on: W = V M with the M just formed
+  c->w_implicit = !pipe;      // dW is stale from here on: W = V M with the M just formed (pipelined: being written already)
   c->ps_valid = true;         // (P | S) of that W, all ranks (C is all-reduced)
-  if (c->opt_snmf_gram == 2) PMFCHK(materialize_w(c));   // W rewritten in every iteration, as the reference's update_w does
+  if (c->opt_snmf_gram == 2 && !pipe) PMFCHK(materialize_w(c));   // W rewritten in every iteration, as the reference's update_w does
   c->ps_valid = true;
   return h_step_from_ps(c);
 }
 
 // W = V M for the M the last Gram-space iteration formed (dMT dense / dW1 CSR).
 int materialize_w(pmf_ctx* c) {
+  PMFCHK(w_pipe_join(c));     // (a pipelined write still in flight on the side stream)
   if (!c->w_implicit) return PMF_OK;
   c->w_implicit = false;
   stat_begin(c, SITE_MATERIALIZE);
@@ -2112,6 +2169,8 @@ int pmf_ctx_destroy(pmf_ctx* c) {
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->w_stream) { (void)hipStreamSynchronize(c->w_stream); (void)hipStreamDestroy(c->w_stream); }
+  for (hipEvent_t e : {c->ev_mt[0], c->ev_mt[1], c->ev_w[0], c->ev_w[1]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->stat.ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -2835,6 +2894,13 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (std::strcmp(name, "nnqp_wave") == 0) {
     if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "nnqp_wave: 0 or 1");
     c->opt_nnqp_wave = (int)value;
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "snmf_w_pipe") == 0) {
+    if (value < 0 || value > 256) return fail(c, PMF_EINVAL, "snmf_w_pipe: 0 (off) .. 256 workgroup slots left free by the W write");
+    HIPCHK(c, hipSetDevice(c->device));
+    PMFCHK(w_pipe_join(c));
+    c->opt_w_pipe = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "nnqp_count") == 0) {

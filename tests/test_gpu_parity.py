@@ -924,6 +924,41 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
 
 
 # ---- BASELINE's other configs at FULL size: size-independent properties (cfg4's are above) ----------
+def test_pipelined_w_write_of_the_csr_gram_loop_is_bit_identical(pm):
+    """snmf_gram = 2 on CSR data writes W = V M in every iteration (snmf.py:67-70 does); since round 4 that write runs on
+    a stream of its own beside the k x n sized kernels of the NEXT iteration (option snmf_w_pipe: workgroup slots the
+    write leaves free; 0 = stream order).  Same kernels, same operands (M double buffered): W and H must not change by
+    a bit, whatever the iteration count's parity, and the context must stay usable hook by hook afterwards."""
+    import scipy.sparse as sp
+    from pymf_amd import _lib
+    m, n, k = 70000, 128, 128
+    rs = np.random.RandomState(5)
+    Vs = sp.random(m, n, density=0.01, format="csr", dtype=np.float32, random_state=rs)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    H0 = (rs.random_sample((k, n)) + 0.1).astype(np.float32)
+    outs = {}
+    for pipe in (0, 16, 3):
+        for niter in (1, 4):
+            c = _lib.Context(_lib.ALGO_SNMF, m, n, k)
+            c.set_v_csr(Vs.indptr, Vs.indices, Vs.data)
+            c.set_w(W0); c.set_h(H0)
+            c.set_option("snmf_gram", 2)
+            c.set_option("snmf_w_pipe", pipe)
+            _, done, _ = c.factorize(niter, compute_err=False)
+            assert done == niter
+            _, done, _ = c.factorize(1, compute_err=False)          # a second call: buffers and events carry over
+            r = [c.get_w(), c.get_h()]
+            c.update_w(); c.update_h()
+            r += [c.get_w(), c.get_h()]
+            outs[(pipe, niter)] = r
+            c.close()
+    for niter in (1, 4):
+        for pipe in (16, 3):
+            for a, b in zip(outs[(0, niter)], outs[(pipe, niter)]):
+                np.testing.assert_array_equal(a, b)
+    assert np.isfinite(outs[(16, 4)][0]).all()
+
+
 def _synthetic_rows(seed, rows, ncols):
     """Host replica of the library's counter-based U[0,1) fill (u01_from in pmf_dev.h: splitmix64 finaliser
     of seed + golden * (row * ncols + col + 1)) for the given global rows."""
