@@ -366,15 +366,17 @@ class Context(object):
         self._host_ar_cb = HOST_ALLREDUCE_FN(_cb)      # keep the trampoline alive
         self._chk(self._lib.pmf_set_host_allreduce(self._h, ctypes.cast(self._host_ar_cb, ctypes.c_void_p), None))
 
-    def enable_ipc_allreduce(self, rank, nranks, allgather_bytes):
-        """Set up the one-shot all-reduce (pmf_ipc_export / pmf_ipc_import): `allgather_bytes(b) -> [b_0 .. b_{N-1}]`
-        hands every rank's IPC handle to every rank (pymf_amd.dist.allgather_bytes)."""
+    def ipc_export(self, rank, nranks):
+        """This rank's IPC handle of its receive area (pmf_ipc_export), IPC_HANDLE_BYTES bytes."""
         buf = ctypes.create_string_buffer(IPC_HANDLE_BYTES)
         self._chk(self._lib.pmf_ipc_export(self._h, int(rank), int(nranks), buf))
-        parts = allgather_bytes(buf.raw)
-        assert len(parts) == nranks and all(len(p_) == IPC_HANDLE_BYTES for p_ in parts)
-        allh = ctypes.create_string_buffer(b"".join(parts), IPC_HANDLE_BYTES * nranks)
-        self._chk(self._lib.pmf_ipc_import(self._h, allh, int(nranks)))
+        return buf.raw
+
+    def ipc_import(self, handles):
+        """Map the peers' receive areas: `handles` = every rank's handle in rank order (pmf_ipc_import)."""
+        assert all(len(p_) == IPC_HANDLE_BYTES for p_ in handles)
+        allh = ctypes.create_string_buffer(b"".join(handles), IPC_HANDLE_BYTES * len(handles))
+        self._chk(self._lib.pmf_ipc_import(self._h, allh, len(handles)))
 
     def ipc_selftest(self, rounds=6):
         """True iff the one-shot all-reduce reproduced the other transport's sums `rounds` times (pmf_ipc_selftest)."""

@@ -16,8 +16,9 @@
 //   * no barrier across workgroups or ranks beyond those flags: slice g of rank a only ever waits for slice g of the
 //     peers.  Two slots suffice: a rank can be at most one exchange ahead of a peer (it cannot finish exchange s + 1
 //     before that peer has raised its flags of s + 1, i.e. has finished reading s).
-// A wait is bounded (PMF_IPC_WAIT_TICKS: 30 s -- ranks may be seconds apart on the host side, e.g. one still reading its
-// data); a peer that never arrives raises *err instead of hanging the GPU.
+// A wait is bounded (wait_ticks of the 100 MHz counter; PMF_IPC_WAIT_TICKS = 30 s in the loops -- ranks may be seconds
+// apart on the host side, e.g. one still reading its data --, 2 s in the self-test); a peer that never arrives raises
+// *err instead of hanging the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,7 +39,8 @@ struct IpcPeers {
 
 // T = float or double; p[count] is this rank's partial on entry and the all-rank sum on exit.
 template <typename T>
-__global__ __launch_bounds__(256) void k_ipc_allreduce(T* __restrict__ p, int64_t count, IpcPeers pr, unsigned seq, int* __restrict__ err) {
+__global__ __launch_bounds__(256) void k_ipc_allreduce(T* __restrict__ p, int64_t count, IpcPeers pr, unsigned seq, int* __restrict__ err,
+                                                       unsigned long long wait_ticks) {
   const int g = blockIdx.x, tid = threadIdx.x;
   const int N = pr.nranks, me = pr.me, slot = (int)(seq & 1u);
   const int64_t per = ((count + gridDim.x - 1) / gridDim.x + 3) & ~(int64_t)3;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void k_ipc_allreduce(T* __restrict__ p, int64_
     const unsigned long long t0 = wall_clock64();            // the 100 MHz constant-rate counter
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > PMF_IPC_WAIT_TICKS) { ok = 0; break; }
+      if (wall_clock64() - t0 > wait_ticks) { ok = 0; break; }
     }
   }
   __syncthreads();

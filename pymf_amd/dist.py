@@ -91,12 +91,29 @@ def setup_collectives(ctx):
     if t in ("host", "ipc"):
         ctx.set_host_allreduce(allreduce_sum_array)
     if t == "ipc" or (t == "rccl" and oneshot()):
+        # Every rank makes the SAME sequence of exchanges here whatever fails locally -- a rank that skipped one would leave
+        # the others waiting: export (local) -> all-gather of the handles (an empty one = "could not") -> import (local) ->
+        # vote -> self-test against the other transport (all ranks, all rounds) -> vote.
+        handle = b""
         try:
-            ctx.enable_ipc_allreduce(w.rank, w.size, allgather_bytes)
-            ok = ctx.ipc_selftest()
-        except Exception:                      # (export / import refused: every rank still takes part in the vote below)
-            ok = False
-        if allreduce_max(0.0 if ok else 1.0) > 0.0:
+            handle = ctx.ipc_export(w.rank, w.size)
+        except Exception:
+            handle = b""
+        parts = allgather_bytes(handle)
+        ok = len(parts) == w.size and all(len(p) == len(parts[0]) and len(p) > 0 for p in parts)
+        if ok:
+            try:
+                ctx.ipc_import(parts)
+            except Exception:
+                ok = False
+        ok = allreduce_max(0.0 if ok else 1.0) == 0.0
+        if ok:
+            try:
+                ok = bool(ctx.ipc_selftest())
+            except Exception:
+                ok = False
+            ok = allreduce_max(0.0 if ok else 1.0) == 0.0
+        if not ok:
             try:
                 ctx.set_option("oneshot_allreduce", 0)
             except Exception:

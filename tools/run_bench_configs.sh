@@ -2,12 +2,12 @@
 # usage: tools/run_bench_configs.sh <out tag>   -- every BASELINE config through bench.py, then the same
 # commands under rocprofv3 --kernel-trace --stats (summaries for profiles/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r03}
+tag=${1:-r04}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 declare -A ARGS=( [cfg4]="--steps 20 --warmup 5" [cfg2]="--config cfg2 --steps 200 --warmup 5" \
-                  [cfg3]="--config cfg3 --steps 10 --warmup 2" [cfg5]="--config cfg5 --steps 20 --warmup 5" )
+                  [cfg3]="--config cfg3 --steps 50 --warmup 3" [cfg5]="--config cfg5 --steps 20 --warmup 5" )
 for c in cfg4 cfg2 cfg3 cfg5; do
   python3 $R/bench.py --gpus 1 ${ARGS[$c]} > $O/$c.json 2> $O/$c.err
   tail -c 400 $O/$c.err
