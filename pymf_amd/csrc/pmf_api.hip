@@ -453,8 +453,6 @@ FusedCtl take_fused_ctl(pmf_ctx* c) {
 template <int NT>
 int launch_csr_w_blocks(pmf_ctx* c, hipStream_t stream, const float* Mbuf, int reserve) {
   const size_t mbytes = (size_t)c->np * c->KP * sizeof(float);
-  const int in_lds = mbytes <= 128 * 1024;
-  const size_t smem = in_lds ? mbytes : 0;
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
@@ -466,8 +464,21 @@ int launch_csr_w_blocks(pmf_ctx* c, hipStream_t stream, const float* Mbuf, int r
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   const int64_t nblk = c->mp / 16;
+  const int64_t nwg_full = (nblk + 15) / 16;          // one workgroup (16 waves) per 16 blocks = 256 rows = one contiguous piece of W
+  // Round 4 (tools/csrw_lab.hip): a NON-persistent grid -- every workgroup writes ONE contiguous 256-row piece of W and
+  // leaves, the pieces swept through memory in dispatch order -- with M read from L2 (64 KiB, resident; no LDS image to
+  // stage per workgroup) stores at 6.75 TB/s where 512 persistent workgroups striding through W reach 5.4 (a pure store
+  // stream of that strided shape: 5.1-5.6; hipMemsetAsync: 6.45).  Taken when the grid is several waves of workgroups deep.
+  if (nwg_full >= (int64_t)8 * cus && mbytes <= (size_t)1 << 20) {
+    hipLaunchKernelGGL((k_csr_w_blocks<NT>), dim3((unsigned)nwg_full), dim3(1024), 0, stream, c->dIndptr, c->dIndices, c->dVals,
+                       nblk, c->np, Mbuf, c->dW, 0);
+    HIPCHK(c, hipGetLastError());
+    return PMF_OK;
+  }
+  const int in_lds = mbytes <= 128 * 1024;
+  const size_t smem = in_lds ? mbytes : 0;
   const int per_cu = smem <= 80 * 1024 ? 2 : 1;     // workgroups of 16 waves per CU
-  const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nblk + 15) / 16, (int64_t)cus * per_cu - reserve));
+  const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nwg_full, (int64_t)cus * per_cu - reserve));
   hipLaunchKernelGGL((k_csr_w_blocks<NT>), dim3(wgs), dim3(1024), smem, stream, c->dIndptr, c->dIndices, c->dVals,
                      nblk, c->np, Mbuf, c->dW, in_lds);
   HIPCHK(c, hipGetLastError());
@@ -2042,12 +2053,6 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   pmf_ctx* c = new (std::nothrow) pmf_ctx();
   if (!c) return fail(nullptr, PMF_ENOMEM, "host allocation failed");
   c->algo = algo; c->m = m_local; c->n = n; c->k = k; c->device = device; c->rank = rank; c->nranks = nranks;
-  if (const char* e = std::getenv("PMF_COLGEMM_STREAM")) c->opt_colgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("colgemm_stream")
-  if (const char* e = std::getenv("PMF_RESID_RESIDENT")) c->opt_resid_resident = std::atoi(e) != 0;
-  if (const char* e = std::getenv("PMF_ROWGEMM_STREAM")) c->opt_rowgemm_stream = std::atoi(e) != 0;   // as pmf_set_option("rowgemm_stream")
-  if (const char* e = std::getenv("PMF_NNQP_WAVE")) c->opt_nnqp_wave = std::atoi(e) != 0;   // as pmf_set_option("nnqp_wave")
-  if (const char* e = std::getenv("PMF_NNQP_FRAME16")) c->opt_nnqp_frame16 = std::atoi(e) != 0;   // as pmf_set_option("nnqp_frame16")
-  if (const char* e = std::getenv("PMF_NNQP_QUAD")) c->opt_nnqp_quad = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);   // as pmf_set_option("nnqp_quad")
   c->mp = round_up(m_local, 64);
   c->np = (int)round_up(n, 64);
   c->NT = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;

@@ -191,6 +191,10 @@ __global__ __launch_bounds__(256) void k_csr_gram_sum(const double* __restrict__
 // bases each, so every store is a 16-byte-per-lane, 1-KiB-per-instruction contiguous piece of W.  M
 // (np x KP) sits in LDS when it fits (64 KiB at n = k = 128: conflict-free float4 row reads) and is read
 // through L2 otherwise.  1024-thread workgroups: 16 waves share one M image, 256 rows in flight per CU.
+// Round 4: for matrices many workgroups deep the launch is NOT persistent -- one workgroup per 256 rows, M through L2
+// (m_in_lds = 0, no image to stage): each workgroup writes one contiguous 128 KiB piece of W and leaves, the pieces
+// following each other through memory in dispatch order: 6.75 TB/s at cfg5 against 5.4 for 512 persistent workgroups
+// striding through W (tools/csrw_lab.hip; pure store streams of the two shapes: 5.9-6.5 / 5.1-5.6 TB/s).
 template <int NT>
 __global__ __launch_bounds__(1024) void k_csr_w_blocks(const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,

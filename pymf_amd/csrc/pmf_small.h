@@ -106,12 +106,16 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
       const int q = tid + 1024 * u, r = q >> 4, c4 = q & 15;
       if (q < KP * 16) hreg[u] = *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
     }
+    // (an opaque zero in the row index: otherwise the 2 x 4 row pointers of this wave's P values are hoisted out of the
+    // panel loop as eight 64-bit registers that live through the whole kernel -- the scratch of the 128-base instantiations)
+    int z = 0;
+    asm volatile("" : "+v"(z));
 #pragma unroll
     for (int h = 0; h < HTW; ++h) {
       const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i] : 0.f;
+        pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r + z) * ldp + c0 + 16 * ct + i] : 0.f;
     }
   };
 #pragma unroll
@@ -162,7 +166,10 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
       f32x4 den[4];                                   // 4 independent chains, one per element of a 16-byte group
 #pragma unroll
       for (int e = 0; e < 4; ++e) den[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+      // (at 128 bases the fully unrolled loop hoists all 8 x (4 + 4) LDS reads above the MFMAs: 68-92 bytes of scratch at
+      // the 128-register budget of a 16-wave workgroup; four steps at a time stay in registers)
+      constexpr int TUN = NT >= 8 ? 4 : NT;
+#pragma unroll TUN
       for (int t = 0; t < NT; ++t) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(ss + (16 * mt + i) * LDS_S + 16 * t + 4 * kq);
 #pragma unroll

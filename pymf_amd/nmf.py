@@ -259,7 +259,7 @@ class NMF(object):
             self._warned_f64 = True
             warnings.warn("%s: float64 data is rounded to float32 on the device (fp32 MFMA arithmetic; the "
                           "reference would compute in float64, nmf.py:122-132) -- tolerances: DESIGN.md section 4"
-                          % type(self).__name__, PrecisionWarning, stacklevel=4)
+                          % type(self).__name__, PrecisionWarning, stacklevel=6)
 
     def _upload_sparse(self, ctx):
         raise TypeError("scipy.sparse data is not supported by %s (the reference fails "
