@@ -108,15 +108,16 @@ def test_class_level_multi_rank_path_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_one_shot_ipc_allreduce_two_processes_on_one_gpu():
+@pytest.mark.parametrize("size", [2, 4])
+def test_one_shot_ipc_allreduce_processes_on_one_gpu(size):
     """the one-shot all-reduce (pmf_ipc.h: every rank writes its partial of (W^T V | W^T W) into
-    every peer's IPC-mapped receive area and adds the N partials in rank order) with two PROCESSES sharing GPU 0 --
+    every peer's IPC-mapped receive area and adds the N partials in rank order) with two and with FOUR processes sharing GPU 0 --
     RCCL refuses that set-up ("Duplicate GPU detected").  The class-level worker must reproduce the unsharded oracle,
     keep H bit-identical across the ranks, leave an early-exiting loop at the same iteration on both ranks, AND give
     the same bits as the host transport (both add in rank order): the worker prints digests that are compared here."""
-    outs_ipc = _spawn_workers("_dist_class_worker.py", 2, extra_args=["--digest"],
+    outs_ipc = _spawn_workers("_dist_class_worker.py", size, extra_args=["--digest"],
                               extra_env={"PYMF_DIST_TRANSPORT": "ipc", "LOCAL_RANK": "0"})
-    outs_host = _spawn_workers("_dist_class_worker.py", 2, extra_args=["--digest"],
+    outs_host = _spawn_workers("_dist_class_worker.py", size, extra_args=["--digest"],
                                extra_env={"PYMF_DIST_TRANSPORT": "host", "LOCAL_RANK": "0"})
     for a, b in zip(outs_ipc, outs_host):
         da = [l for l in a.splitlines() if l.startswith("digest ")]

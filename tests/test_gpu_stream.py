@@ -216,3 +216,60 @@ def test_streamed_snmf_and_nmfals_vs_reference_golden(pm, cls_name, name, rows):
     assert rel_fro(mdl.W, res.W, what="streamed vs resident W") < tol
     assert rel_fro(mdl.H, res.H, what="streamed vs resident H") < tol
     assert abs(mdl.frobenius_norm() - res.frobenius_norm()) <= 1e-4 * res.frobenius_norm()
+
+
+# ---- host <-> device transport (round 4): float64 arrays cross as they are and are rounded / widened on the device -------
+def test_float64_transport_equals_host_side_conversion():
+    """pmf_set_w_f64 / pmf_set_h_f64 / pmf_set_v_dense_f64 round on the device what np.astype(float32) rounds on the host
+    (round to nearest even both): the device copies must be bit-identical; pmf_get_*_f64 widens exactly; a pitched host
+    array (leading dimension > n) and ragged shapes (padding columns / rows) go through the same paths."""
+    import ctypes
+    from pymf_amd import _lib
+    rs = np.random.RandomState(3)
+    for (m, n, k) in ((1000, 200, 33), (4096, 256, 64), (77, 50, 7)):
+        V64 = rs.random_sample((m, n)) - 0.25
+        W64 = rs.random_sample((m, k)) * 3.0
+        H64 = rs.random_sample((k, n)) + 1e-3
+        a = _lib.Context(_lib.ALGO_SNMF, m, n, k)        # SNMF: mixed-sign data allowed
+        b = _lib.Context(_lib.ALGO_SNMF, m, n, k)
+        a.set_v_dense(V64); a.set_w(W64); a.set_h(H64)                                   # float64 paths
+        b.set_v_dense(V64.astype(np.float32)); b.set_w(W64.astype(np.float32)); b.set_h(H64.astype(np.float32))
+        np.testing.assert_array_equal(a.get_w(), b.get_w())
+        np.testing.assert_array_equal(a.get_h(), b.get_h())
+        np.testing.assert_array_equal(a.get_w(), W64.astype(np.float32))
+        assert a.frobenius() == b.frobenius()                                            # same V, W, H on the device
+        # widening on the device == widening on the host; written into the caller's array in place
+        Wout = np.full((m, k), np.nan)
+        Hout = np.full((k, n), np.nan)
+        assert a.get_w_into(Wout) and a.get_h_into(Hout)
+        np.testing.assert_array_equal(Wout, W64.astype(np.float32).astype(np.float64))
+        np.testing.assert_array_equal(Hout, H64.astype(np.float32).astype(np.float64))
+        W32o = np.empty((m, k), dtype=np.float32)
+        assert a.get_w_into(W32o) and np.array_equal(W32o, b.get_w())
+        assert not a.get_w_into(np.empty((m, k + 1)))                                    # wrong shape: the caller copies
+        assert not a.get_w_into(np.empty((m, 2 * k))[:, ::2])                            # not contiguous
+        # a pitched float32 host array through the C ABI itself (ld > n)
+        wide = np.zeros((m, n + 13), dtype=np.float32)
+        wide[:, :n] = V64.astype(np.float32)
+        lib = _lib.load()
+        assert lib.pmf_set_v_dense_f32(b._h, wide.ctypes.data, n + 13) == 0
+        assert a.frobenius() == b.frobenius()
+        # ... and the float64 one
+        wide64 = np.zeros((m, n + 5))
+        wide64[:, :n] = V64
+        assert lib.pmf_set_v_dense_f64(b._h, wide64.ctypes.data, n + 5) == 0
+        assert a.frobenius() == b.frobenius()
+        a.close(); b.close()
+
+
+def test_first_call_timings_are_reported():
+    import pymf_amd
+    rs = np.random.RandomState(4)
+    V = rs.random_sample((2048, 256)).astype(np.float32)
+    mdl = pymf_amd.NMF(V, num_bases=16)
+    mdl.W, mdl.H = rs.random_sample((2048, 16)), rs.random_sample((16, 256))
+    mdl.factorize(niter=3, compute_err=False)
+    t = mdl.last_call_ms
+    assert set(t) >= {"ctx", "init", "upload", "loop", "total"} and t["total"] >= t["loop"] > 0.0 and t["upload"] > 0.0
+    mdl.factorize(niter=3, compute_err=False)
+    assert "ctx" not in mdl.last_call_ms or mdl.last_call_ms["ctx"] == 0.0            # the context exists already
