@@ -159,6 +159,15 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   const int b0 = gw * blk_per + (gw < blk_extra ? gw : blk_extra);
   const int nb = blk_per + (gw < blk_extra ? 1 : 0);
   const int nb_wg = blk_per + (blk_extra > 0 ? 1 : 0);   // SPLIT 2: barrier trips, same for every wave
+  // Up to 16 bases the kernel is HBM-bound (4.5-4.9 TB/s), and there it pays to INTERLEAVE the blocks: wave gw takes blocks
+  // gw, gw + nw, gw + 2 nw, ... -- at any moment the chip works on nw adjacent blocks, a window that sweeps through V and
+  // W -- instead of a contiguous range of its own (1 048 576 x 384, k = 16: 0.350 -> 0.333 ms; x 256: 0.237 -> 0.234; the
+  // MFMA-bound instantiations do not care: 1 048 576 x 256, k = 64 0.6199 / 0.6184, the 131 072-row shard 0.1035 / 0.1039,
+  // cfg2 0.0593 / 0.0594 -- tools/interleave_ab.py, profiles/r04_experiments.md -- and keep their summation order).
+  constexpr bool interleave = NT == 1;
+  const int nw_all = (int)gridDim.x * (SPLIT == 2 ? 2 : 4);
+  const int bfirst = interleave ? gw : b0;
+  const int bstep = interleave ? nw_all : 1;
 
   // LDS-DMA geometry: one instruction = 4 rows x 256 B; lane L fills physical chunk (L & 15)
   // of row 4q + (L >> 4), so it fetches logical chunk (L & 15) ^ row.  Per-lane BYTE offsets
@@ -175,13 +184,13 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   const char* Wb = reinterpret_cast<const char*>(W);
   auto issue_v = [&](int blk, int p, int q) {      // V rows of block blk, panel p, DMA q
 #ifdef PMF_ABLATE_DMA      // timing-only diagnostic build: outputs are wrong
-    if (blk != b0) return;
+    if (blk != bfirst) return;
 #endif
     PMF_GLDS16(Vb + ((size_t)blk * (16 * NP * 4) + (hp + p) * 256) + voff[q], sV + p * 1024 + q * 256);
   };
   auto issue_w = [&](int blk, int q) {
 #ifdef PMF_ABLATE_DMA
-    if (blk != b0) return;
+    if (blk != bfirst) return;
 #endif
     PMF_GLDS16(Wb + (size_t)blk * (16 * KP * 4) + woff[q], sW + q * 256);
   };
@@ -199,12 +208,12 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   if (nb > 0) {
     if (!SNMF) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) issue_w(b0, q);
+      for (int q = 0; q < 4; ++q) issue_w(bfirst, q);
     }
 #pragma unroll
     for (int p = 0; p < (SPREAD ? NPANEL - 1 : NPANEL); ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) issue_v(b0, p, q);
+      for (int q = 0; q < 4; ++q) issue_v(bfirst, p, q);
   }
 
   // ---- H and G into LDS by LDS-DMA as well (whole workgroup, once): 4 rows x 256 B per
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       __syncthreads();                                  // the exchange area is free again
       if (b >= nb) { __syncthreads(); continue; }       // a pair without this block only keeps step
     }
-    const int blk = b0 + b;
+    const int blk = bfirst + b * bstep;
     const bool more = (b + 1 < nb);
     PMF_STAMP(ts0);
 
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (more) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) issue_w(blk + 1, q);
+        for (int q = 0; q < 4; ++q) issue_w(blk + bstep, q);
       }
     }
     PMF_STAMP(ts3);
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
           P[mt][4 * p + nt] = mfma16(wn[mt][j], bf[buf][nt], P[mt][4 * p + nt]);
       if (SPREAD) {
         // panel p-1 was fully read one panel ago (its last reads fed step 4p-1's MFMAs)
-        if (p >= 1 && more) issue_v(blk + 1, p - 1, j);
+        if (p >= 1 && more) issue_v(blk + bstep, p - 1, j);
       }
       if (s + 1 < NSN) {
         __builtin_amdgcn_sched_group_barrier(0x008, NT >= 2 ? 2 : 1, 0);      // MFMA
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (more) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) issue_v(blk + 1, p, q);
+          for (int q = 0; q < 4; ++q) issue_v(blk + bstep, p, q);
         }
       }
     }
