@@ -287,13 +287,14 @@ def main():
     preroll_iters, preroll_ms = 0, 0.0
     state_dependent = algo_name == "NMFALS"      # the cost of an ALS iteration depends on how settled the active sets are
     if args.preroll_ms > 0:
-        ctx.factorize(2, compute_err=False)
+        ctx.factorize(2, compute_err=False)          # (one-time work of a first call -- V^T V of the Gram-space loop, buffers -- ...)
+        ctx.factorize(2, compute_err=False)          # ... stays out of the per-iteration estimate
         # every iteration carries a collective: ALL ranks must run the same count (the slowest rank's estimate)
         per = dist.allreduce_max(max(ctx.last_loop_ms() / 2.0, 1e-3))
         preroll_iters = int(min(max(args.preroll_ms / per, 1), 20000))
         ctx.factorize(preroll_iters, compute_err=False)
         preroll_ms = ctx.last_loop_ms()
-        preroll_iters += 2
+        preroll_iters += 4
         if state_dependent and "W0" in host:
             # BASELINE.md section 3 / SURVEY 8(d): warm-up and timed iterations start from the SEEDED W0 / H0.  The pre-roll
             # only brings the chip to its clock; the factors go back to the seeded start, so `value` includes the expensive
