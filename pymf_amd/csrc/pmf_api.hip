@@ -1877,6 +1877,7 @@ int do_frobenius(pmf_ctx* c, double* out) {
 constexpr size_t kStageBytes = (size_t)256 << 20;
 int stage_reserve(pmf_ctx* c, size_t bytes) {
   if (c->stage_cap >= bytes) return PMF_OK;
+  bytes = std::max<size_t>(bytes, (size_t)4 << 20);          // (H and other k x n sized arrays: one allocation serves them all)
   if (c->dStage) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->dStage)); c->dStage = nullptr; c->stage_cap = 0; }
   HIPCHK(c, hipMalloc(&c->dStage, bytes));
   c->stage_cap = bytes;
