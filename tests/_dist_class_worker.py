@@ -166,6 +166,20 @@ def main():
         check("SNMF H", s.H, so.H, 2e-5)
         check("SNMF ferr", s.ferr, so.ferr, 2e-5)
         digest("SNMF W", s.W); digest("SNMF H", s.H)
+        # ---- NMFALS (nmfals.py:70-97): the row QPs are local to a rank, the column QPs run on the all-reduced
+        # (W^T V | W^T W) on every rank -- H must come out bit-identical everywhere ----
+        np.random.seed(400 + w.rank)
+        a = pymf_amd.NMFALS(V[lo:hi], num_bases=8)
+        a.factorize(niter=3)
+        np.random.seed(400)
+        ao = oracle.NMFALSOracle(V, num_bases=8)
+        ao.factorize(niter=3)
+        check("NMFALS W", gather_rows(a.W), ao.W, 1e-4)
+        check("NMFALS H", a.H, ao.H, 1e-4)
+        check("NMFALS ferr", a.ferr, ao.ferr, 1e-5)
+        ha = dist.allgather_bytes(np.ascontiguousarray(a.H).tobytes())
+        assert all(h == ha[0] for h in ha), "NMFALS: H must be bit-identical on every rank"
+        digest("NMFALS W", a.W); digest("NMFALS H", a.H)
         # ---- RNMF: init_h normalises the columns of W over ALL ranks' rows ----
         from pymf_amd.rnmf import RNMF
         Vr = V.copy()
