@@ -22,6 +22,7 @@ class SNMF(NMF):
 
     def _upload_sparse(self, ctx):
         csr = self.data.tocsr()
+        self._warn_if_float64(csr.data)
         csr.sum_duplicates()
         ctx.set_v_csr(csr.indptr, csr.indices, csr.data)
 
