@@ -1640,16 +1640,16 @@ bool nnqp_use_quad(const pmf_ctx* c, int64_t nprob) {
 bool nnqp_use_wave(const pmf_ctx* c) { return c->opt_nnqp_wave && c->k > 64 && c->k <= 128; }
 
 // What a half step's QPs need from HA = dGd alone, on stream s: the uniqueness flag and, for k_nnqp_quad,
-// B = inv(HA with its dead variables patched out).  k x k sized kernels, 36 + 2 + 18 us at k = 64.
+// B = inv(HA with its dead variables patched out), one k x k sized launch.
 int nnqp_prepare(pmf_ctx* c, hipStream_t s, bool quad) {
   if (quad) {
     // the inverse's own pivots are the uniqueness test (k_inverse_spd_mfma's spd_flag): no k_spd_unique launch
     if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
     if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));     // B, and HA with dead variables patched out
+    // (dead bases are patched out by the inverse kernel itself, which also writes the patched HA: one launch, not two)
     double* Hp = c->dBinv + (size_t)c->KP * c->KP;
-    hipLaunchKernelGGL(k_nnqp_patch_dead, dim3((unsigned)std::max(1, c->KP * c->KP / 1024)), dim3(256), 0, s, c->dGd, c->KP, c->k, Hp);
-    if (c->k <= 64) hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
-    else hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, s, Hp, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm);
+    if (c->k <= 64) hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, c->dGd, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm, Hp);
+    else hipLaunchKernelGGL((k_inverse_spd_mfma<8>), dim3(1), dim3(1024), 0, s, c->dGd, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm, Hp);
     HIPCHK(c, hipGetLastError());
     return PMF_OK;
   }

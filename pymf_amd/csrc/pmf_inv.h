@@ -91,7 +91,11 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
                                                                              double* __restrict__ Ginv64,
                                                                              const int* __restrict__ stop,
                                                                              int* __restrict__ singular = nullptr,
-                                                                             int* __restrict__ spd_flag = nullptr) {
+                                                                             int* __restrict__ spd_flag = nullptr,
+                                                                             double* __restrict__ Gpatched = nullptr) {
+  // Gpatched (may be null; NMFALS): DEAD variables -- a basis that has died out: diagonal entry <= 1e-12 of the largest --
+  // are replaced by the identity before the elimination (they never become passive in the QP kernels), and the patched
+  // matrix is written to Gpatched [ld][ld] for those kernels: what k_nnqp_patch_dead did in a launch of its own.
   // spd_flag (may be null): 1 iff every pivot of the (unpivoted) elimination stayed above 1e-8 of its diagonal entry --
   // the blocked Gauss-Jordan meets exactly the pivots of the unblocked LDL^T (the diagonal tile of a step is the Schur
   // complement of the blocks before it), and the unit-diagonal scaling makes them ratios already: k_spd_unique's test
@@ -111,11 +115,21 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bi = wv / CW, j0 = 4 * (wv % CW);
   const int g = lane >> 4, cc = lane & 15;
+  __shared__ double sdiag[KP];
+  for (int i = tid; i < KP; i += 64 * NBLK * CW) sdiag[i] = i < k ? Gd[(int64_t)i * ld + i] : 0.0;
+  if (tid == 0) dflag = 0;
+  __syncthreads();
+  double dead_below = -1.0;                    // (without Gpatched: nothing is dead, as before)
+  if (Gpatched != nullptr) {
+    double dm = 0.0;
+    for (int i = 0; i < k; ++i) dm = fmax(dm, sdiag[i]);       // every thread for itself: LDS broadcasts
+    dead_below = 1e-12 * dm;
+  }
   for (int i = tid; i < KP; i += 64 * NBLK * CW) {
-    const double gii = i < k ? Gd[(int64_t)i * ld + i] : 1.0;
+    const bool live = i < k && (Gpatched == nullptr || sdiag[i] > dead_below);
+    const double gii = live ? sdiag[i] : 1.0;
     sc[i] = gii > 0.0 ? 1.0 / sqrt(gii) : 1.0;
   }
-  if (tid == 0) dflag = 0;
   __syncthreads();
   f64x4 c[4];
 #pragma unroll
@@ -123,7 +137,10 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * bi + g + 4 * r, col = 16 * (j0 + t) + cc;
-      c[t][r] = (row < k && col < k) ? Gd[(int64_t)row * ld + col] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
+      const bool live = row < k && col < k && (Gpatched == nullptr || (sdiag[row] > dead_below && sdiag[col] > dead_below));
+      const double gv = live ? Gd[(int64_t)row * ld + col] : (row == col ? 1.0 : 0.0);
+      if (Gpatched != nullptr && row < ld && col < ld) Gpatched[(int64_t)row * ld + col] = gv;
+      c[t][r] = live ? gv * sc[row] * sc[col] : gv;
     }
   const int nsteps = (k + 15) / 16;            // blocks beyond k are identity: nothing to eliminate
 
@@ -155,6 +172,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
     const bool owns_diag = (bi >> 2) == (wv % CW);               // tile (bi, bi) is one of this wave's four
     const bool la_wave = la < nsteps && bi == la && owns_diag;
     if (owns_diag && bi != p) {                // R_j = D A_pj for j = bi (both operands are in LDS: any wave could)
+      if (la_wave) __builtin_amdgcn_s_setprio(3);   // the step's critical chain: R_la -> tile (la, la) -> its inversion
       const f64x4 apj = load_tile(pold[p & 1][bi]);
       f64x4 rj = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -171,6 +189,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
           }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&dflag, la, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_s_setprio(0);
       }
       store_tile(pR[bi], rj);
     }
@@ -180,7 +199,9 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
     if (bi == p) {                             // these waves have no update to do in this step ...
       if (j0 == 0 && la < nsteps) {            // ... so one of them inverts the look-ahead tile
         while (__hip_atomic_load(&dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != la) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_setprio(3);
         const double pm = inv16_wave(dsrc, dD[la & 1], line, lane);
+        __builtin_amdgcn_s_setprio(0);
         if (lane == 0) pivmin[la] = pm;
       }
 #pragma unroll

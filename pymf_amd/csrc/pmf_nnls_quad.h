@@ -109,26 +109,9 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
   }
 }
 
-// Hp = HA with every DEAD variable (zero row and column: a basis that has died out) replaced by the identity, so
-// that B = inv(Hp) exists; such variables never become passive (k_nnqp rejects them when it borders).
-__global__ __launch_bounds__(256) void k_nnqp_patch_dead(const double* __restrict__ Hd, int KP, int k, double* __restrict__ Hp) {
-  __shared__ double dg[256];               // (one thread walking the k diagonal entries one after the other took 12.5 us)
-  double dm = 0.0;
-  for (int t = threadIdx.x; t < k; t += 256) dm = fmax(dm, Hd[(int64_t)t * KP + t]);
-  dg[threadIdx.x] = dm;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) dg[threadIdx.x] = fmax(dg[threadIdx.x], dg[threadIdx.x + o]);
-    __syncthreads();
-  }
-  const double dead_below = 1e-12 * dg[0];
-  // (any number of workgroups: each finds the largest diagonal entry for itself and patches a slice)
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < KP * KP; e += gridDim.x * 256) {
-    const int c = e / KP, t = e % KP;
-    const bool dc = c >= k || !(Hd[(int64_t)c * KP + c] > dead_below), dt = t >= k || !(Hd[(int64_t)t * KP + t] > dead_below);
-    Hp[e] = (dc || dt) ? (c == t ? 1.0 : 0.0) : Hd[e];
-  }
-}
+// (Hp = HA with every DEAD variable -- zero row and column: a basis that has died out -- replaced by the identity, so that
+// B = inv(Hp) exists, is formed by k_inverse_spd_mfma itself since round 4: pmf_inv.h, `Gpatched`; such variables never
+// become passive -- k_nnqp rejects them when it borders.)
 
 #ifdef PMF_QUAD_COUNT
 #define PMF_QSTAMP(idx) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) atomicAdd(&g_quad_t[idx], t_ - tq_); tq_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)

@@ -335,11 +335,23 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
       // next panel of this tile; after the last one, panel 0 of the next tile (or, on the very last, itself once more)
       const float* An = p + 1 < npan ? Arow + 64 * (p + 1) : (more ? Arow_n : Arow + 64 * p);
       __syncthreads();
+      // B fragments of step t + 1 are read from LDS under the MFMAs of step t (the scheduling fences below would otherwise
+      // put each step's four reads, and their latency, in front of its first MFMA)
+      // (up to 64 bases: at 128 the second set of fragments is 32 registers too many beside the epilogues)
+      constexpr bool BPRE = NT <= 4;
+      f32x4 b4[BPRE ? 2 : 1][NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b4[0][nt] = lds_read4(cb, 16 * nt + i, kq);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        f32x4 b4[NT];
+        if (BPRE && t < 3) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b4[nt] = lds_read4(cb, 16 * nt + i, 4 * t + kq);
+          for (int nt = 0; nt < NT; ++nt) b4[(t + 1) & 1][nt] = lds_read4(cb, 16 * nt + i, 4 * (t + 1) + kq);
+        }
+        if (!BPRE && t > 0) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b4[0][nt] = lds_read4(cb, 16 * nt + i, 4 * t + kq);
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
           fan[rb][t] = *reinterpret_cast<const f32x4*>(An + (int64_t)(16 * rb) * lda + 16 * t);
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_stream(const float* __restri
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = mfma16(fa[rb][t][e], b4[nt][e], acc[rb][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[rb][nt] = mfma16(fa[rb][t][e], b4[BPRE ? (t & 1) : 0][nt][e], acc[rb][nt]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
