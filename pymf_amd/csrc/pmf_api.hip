@@ -1623,7 +1623,12 @@ int snmf_update_h(pmf_ctx* c) {
 int nnqp_warm_flag(pmf_ctx* c, hipStream_t s) {   // dWarm[0] = 1 iff the QPs over the current dGd have unique minimisers
   if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
   if (c->k <= 64) {
-    hipLaunchKernelGGL(k_spd_unique, dim3(1), dim3(64), 0, s, c->dGd, c->KP, c->k, c->dWarm);
+    // the blocked Gauss-Jordan of k_inverse_spd_mfma meets exactly the pivots of the unpivoted LDL^T, as ratios to the diagonal
+    // already (unit-diagonal scaling), dead bases patched out: its `spd_flag` IS the uniqueness test -- 17 us where the
+    // one-wave elimination of k_spd_unique (rounds 2-3) took 28; the inverse itself is a by-product nobody reads here
+    if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));
+    hipLaunchKernelGGL((k_inverse_spd_mfma<4>), dim3(1), dim3(256), 0, s, c->dGd, c->KP, c->k, c->dBinv, (const int*)nullptr, (int*)nullptr, c->dWarm,
+                       c->dBinv + (size_t)c->KP * c->KP);
   } else {
     if (!c->dInvA) PMFCHK(dalloc(c, &c->dInvA, (size_t)c->KP * c->KP));
     hipLaunchKernelGGL(k_spd_unique_big, dim3(1), dim3(1024), 0, s, c->dGd, c->KP, c->k, c->dInvA, c->dWarm);

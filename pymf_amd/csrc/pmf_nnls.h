@@ -6,7 +6,7 @@
 // (nmfals.py:74,89).  HA is shared by all problems of a half step, only f differs.
 //
 // X holds the previous iterate on entry; when *warm_flag != 0 its support seeds the passive set.
-// k_spd_unique sets the flag iff HA, apart from dead (zero) rows, is well conditioned -- then the
+// The flag (k_inverse_spd_mfma's `spd_flag`) is set iff HA, apart from dead (zero) rows, is well conditioned -- then the
 // minimiser is unique and the starting point cannot change it; a rank-deficient HA (the reference
 // test's rank-3 data with 4 bases) keeps the cold start, the path the reference's solver walks.
 // One wave per problem, lane t <-> variable t (k <= 64), everything in float64 as the
@@ -33,69 +33,9 @@ __global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int
   Gd[q] = v;
 }
 
-// flag[0] = 1 iff the unpivoted LDL^T of HA (dead variables, diag <= 1e-12 max diag, left out) keeps
-// every pivot above 1e-8 of its diagonal entry.  One wave, row t of the matrix in lane t's registers, every
-// index a constant of the program text (static_for): a step broadcasts row j entry by entry (v_readlane from a
-// fixed lane and register) -- 11 us instead of the 102 us of the LDS version with a barrier per pivot, which the
-// sixteen-lanes-per-problem QP kernel had turned into a tenth of an NMFALS iteration.
-template <int A_, int B_, typename Fn>
-__device__ __forceinline__ void spd_static_for(Fn&& fn) {
-  if constexpr (A_ < B_) {
-    fn(std::integral_constant<int, A_>{});
-    spd_static_for<A_ + 1, B_>(fn);
-  }
-}
-__device__ __forceinline__ double spd_readlane_f64(double v, int srclane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-  return __hiloint2double(hi, lo);
-}
-__global__ __launch_bounds__(64) void k_spd_unique(const double* __restrict__ Hd, int KP, int k,
-                                                   int* __restrict__ flag) {
-  // Step j needs row j of the running matrix in every lane.  The matrix is symmetric, so entry (j, c) is also entry
-  // (c, j) = register j of lane c: every lane puts its register j into an LDS line (ONE store) and reads the line back
-  // two entries at a time (all lanes the same address: a broadcast) -- (64 - j) / 2 loads instead of the
-  // 2 (64 - j) v_readlane of a row broadcast entry by entry (36 us -> see profiles/r03_experiments.md).
-  __shared__ __attribute__((aligned(16))) double line[2][64];
-  __shared__ double d0s[64];
-  const int t = threadIdx.x;
-  double A[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) A[c] = (t < k && c < k) ? Hd[(int64_t)c * KP + t] : (t == c ? 1.0 : 0.0);   // (symmetric: the coalesced way round)
-  const double d0 = t < k ? Hd[(int64_t)t * KP + t] : 1.0;
-  d0s[t] = d0;
-  double dmax = t < k ? d0 : 0.0;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
-  const bool live_t = t < k && d0 > 1e-12 * dmax;
-  const unsigned long long livem = __ballot(live_t);
-  int ok = 1;
-  spd_static_for<0, 64>([&](auto jc_) {
-    constexpr int j = decltype(jc_)::value;
-    if (j < k && ok && ((livem >> j) & 1ull)) {            // uniform; a dead basis is skipped
-      double* ln = line[j & 1];
-      ln[t] = A[j];                                          // column j = row j
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double piv = spd_readlane_f64(A[j], j);          // (ahead of the line: its reciprocal is under way while the line lands)
-      const double d0j = d0s[j];
-      if (!(piv > 1e-8 * d0j)) {
-        ok = 0;
-      } else {
-        const double l = (t > j && live_t) ? A[j] * pmf_rcp_f64(piv) : 0.0;
-        constexpr int c0 = j & ~1;
-        spd_static_for<c0 / 2, 32>([&](auto cc_) {
-          constexpr int c = 2 * decltype(cc_)::value;
-          const double2 r = *reinterpret_cast<const double2*>(ln + c);
-          if (c >= j) A[c] = fma(-l, r.x, A[c]);
-          A[c + 1] = fma(-l, r.y, A[c + 1]);
-        });
-      }
-    }
-  });
-  if (t == 0) flag[0] = ok;
-}
+// (The uniqueness test -- flag = 1 iff the unpivoted LDL^T of HA, dead variables left out, keeps every pivot above 1e-8 of its
+// diagonal entry -- is a by-product of k_inverse_spd_mfma (pmf_inv.h: `spd_flag`) since round 4; the one-wave kernel of rounds
+// 2-3, k_spd_unique, took 28 us per half step.  Beyond 64 bases: k_spd_unique_big below.)
 
 #ifdef PMF_NNQP_COUNT   // diagnostic build only (tools/nnqp_probe.hip)
 __device__ unsigned long long g_nnqp_cnt[4];   // outer iterations, removals, problems, rejected borders
