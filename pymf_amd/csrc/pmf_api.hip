@@ -90,6 +90,8 @@ struct pmf_ctx {
   bool s_valid = false;         // RNMF: D has been formed (update_s ran)
   double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
   double *dGd = nullptr, *dPart = nullptr, *dScal = nullptr;
+  double* dGramPart = nullptr;  // k_gram_splitk: per-slice partial Gram matrices, [8][KP][KP]
+  unsigned* dGramTickets = nullptr;
   float* dGpart = nullptr;      // k_nmf_h_gram: per-workgroup partial G, [PMF_HGRAM_MAX_WGS][KP][KP]
   double* dT1part = nullptr;    // ... and partial <P, H_new>
   unsigned* dTicket = nullptr;  // ... arrival counter (the kernel resets it)
@@ -144,6 +146,7 @@ struct pmf_ctx {
   int g_parts = 0;              // > 0 (with g_valid): G = sum of that many partials in dGpart, dG is stale
   int trace_parts = 0;          // > 0 (with trace_ready): the trace terms are that many pairs in dT1part
   bool gram_partial_ok = false; // pmf_factorize: the next consumer of G is the fused kernel
+  bool want_hess = false, gd_is_s = false;   // NMFALS H half step: the reduce writes dGd = W^T W itself (reduce_slabs)
   bool ps_valid = false;        // dPS = (W^T V | W^T W) of the CURRENT W, summed over all ranks
   bool num_valid = false;       // dW1 holds Num = V H^T of the current V, H (fixed-H loops, NMF)
   bool fixed_h_loop = false;    // pmf_factorize running compute_w without compute_h for > 1 iteration
@@ -373,11 +376,17 @@ int colgemm(pmf_ctx* c, bool with_v = true) {
 
 int64_t ps_elems(const pmf_ctx* c) { return (int64_t)c->KP * (c->np + c->KP); }
 
+bool multi_rank(const pmf_ctx* c);
+
 int reduce_slabs(pmf_ctx* c, int nslabs) {
   const int64_t E = ps_elems(c);      // multiple of 4 (KP and np are multiples of 16)
+  // NMFALS on one rank: the column QPs' Hessian S = W^T W leaves the same launch in float64 (with more ranks it has to come
+  // from the ALL-REDUCED sums: k_hessian_from_ps behind the collective)
+  const bool hess = c->want_hess && !multi_rank(c);
   hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E / 4 + 63) / 64)), dim3(1024), 0, c->stream,
-                     c->dSlab, nslabs, E, c->dPS);
+                     c->dSlab, nslabs, E, c->dPS, hess ? c->dGd : (double*)nullptr, c->np, c->KP, c->k);
   HIPCHK(c, hipGetLastError());
+  if (hess) c->gd_is_s = true;
   return PMF_OK;
 }
 
@@ -547,8 +556,19 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
   }
   if (c->g_valid) return PMF_OK;
   dim3 grid((unsigned)(c->KP / 16), (unsigned)(c->KP / 16));
-  hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k,
-                     pad_diag, c->dG, c->dGd);
+  const int ks = c->np >= 2048 && c->np % 512 == 0 ? 8 : c->np >= 512 && c->np % 256 == 0 ? 4 : 1;   // column slices (wide H)
+  if (ks > 1 && c->nb == 1) {
+    if (!c->dGramPart) {
+      PMFCHK(dalloc(c, &c->dGramPart, (size_t)8 * c->KP * c->KP));
+      PMFCHK(dalloc(c, &c->dGramTickets, (size_t)(c->KP / 16) * (c->KP / 16)));
+    }
+    grid.z = (unsigned)ks;
+    hipLaunchKernelGGL(k_gram_splitk, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k, pad_diag, c->dG, c->dGd,
+                       c->dGramPart, c->dGramTickets);
+  } else {
+    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k,
+                       pad_diag, c->dG, c->dGd);
+  }
   HIPCHK(c, hipGetLastError());
   c->g_valid = true;
   return PMF_OK;
@@ -1743,11 +1763,17 @@ int als_update_w(pmf_ctx* c) {
 
 int als_update_h(pmf_ctx* c) {
   // HA = W^T W (nmfals.py:78), -FA = W^T V (nmfals.py:73), one QP per column (nmfals.py:74-75)
-  PMFCHK(ensure_ps(c));
+  c->want_hess = c->nb == 1 && !use_csr(c);
+  c->gd_is_s = false;
+  const int prc = ensure_ps(c);
+  c->want_hess = false;
+  PMFCHK(prc);
   const int64_t ldp = (int64_t)c->np + c->KP;
-  hipLaunchKernelGGL(k_hessian_from_ps, dim3((unsigned)((c->KP * c->KP + 255) / 256)), dim3(256), 0,
-                     c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
-  HIPCHK(c, hipGetLastError());
+  if (!c->gd_is_s) {           // (the sums were cached, or crossed the ranks after the local reduce)
+    hipLaunchKernelGGL(k_hessian_from_ps, dim3((unsigned)((c->KP * c->KP + 255) / 256)), dim3(256), 0,
+                       c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
+    HIPCHK(c, hipGetLastError());
+  }
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
   PMFCHK(solve_nnqps(c, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, false));
   c->g_valid = false; c->num_valid = false;
@@ -2176,7 +2202,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage, (void*)c->dGramPart, (void*)c->dGramTickets})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);

@@ -371,3 +371,49 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
     }
   }
 }
+
+// The same for WIDE H (np >= 512, round 4): the columns are cut into KS slices, one workgroup per (tile, slice) -- a tile of a
+// 64 x 1024 H was 16 dependent L2 round trips per wave, 16 us of an NMFALS iteration -- each leaves its partial tile in
+// `part` [KS][KP][KP]; the LAST slice of a tile to arrive (ticket per tile, reset for the next launch) adds the KS partials in
+// slice order: deterministic.  part: KS * KP * KP doubles, tickets: (KP / 16)^2 zeroed unsigneds.
+__global__ __launch_bounds__(256) void k_gram_splitk(const float* __restrict__ H, int64_t ldh, int np, int KP, int k, double pad_diag,
+                                                     float* __restrict__ Gf, double* __restrict__ Gd, double* __restrict__ part,
+                                                     unsigned* __restrict__ tickets) {
+  __shared__ double wpart[3][4][64];
+  __shared__ unsigned s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ra = blockIdx.x * 16, rb = blockIdx.y * 16, KS = gridDim.z, z = blockIdx.z;
+  const int ksl = np / KS, kq = ksl / 4;                       // columns per slice / per wave (multiples of 16)
+  const float* Hs = H + (size_t)z * ksl + wv * kq;
+  f64x4 acc = tile_dgemm<true, float, float>(Hs, ldh, Hs, ldh, kq, ra, rb, lane);
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wpart[wv - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  const int gb = rb + (lane & 15), g = lane >> 4;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  if (wv == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = ((acc[r] + wpart[0][r][lane]) + wpart[1][r][lane]) + wpart[2][r][lane];
+      part[((size_t)z * KP + (ra + g + 4 * r)) * KP + gb] = v;
+    }
+    __threadfence();
+    if (lane == 0) s_last = (atomicAdd(&tickets[tile], 1u) == (unsigned)KS - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || wv != 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ga = ra + g + 4 * r;
+    double v = 0.0;
+    for (int q = 0; q < KS; ++q) v += part[((size_t)q * KP + ga) * KP + gb];
+    if (ga >= k || gb >= k) v = (ga == gb) ? pad_diag : 0.0;
+    Gf[(int64_t)ga * KP + gb] = (float)v;
+    if (Gd) Gd[(int64_t)ga * KP + gb] = v;
+  }
+  if (lane == 0) tickets[tile] = 0u;                            // ready for the next launch (stream order)
+}

@@ -721,8 +721,11 @@ __global__ __launch_bounds__(256, 2) void k_colgemm_stream(const float* __restri
 // out[e] = sum over slabs of slab[c][e], fixed order, float64 accumulation.
 // One block (1024 threads) = 256 consecutive elements as 64 float4; wave w sums slabs
 // w, w+16, ... (coalesced 1-KiB reads), the 16 partials are combined in wave order.
+// Gd (may be null; NMFALS on one rank): the S = W^T W part of the sums also goes out as the float64 Hessian of the column
+// QPs, [KP][KP] with the identity on the padding (nmfals.py:78) -- k_hessian_from_ps's job without a launch of its own.
 __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__ slab, int nslabs,
-                                                       int64_t E, float* __restrict__ out) {
+                                                       int64_t E, float* __restrict__ out,
+                                                       double* __restrict__ Gd = nullptr, int np = 0, int KP = 0, int k = 0) {
   __shared__ double part[16][64][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;      // float4 index
@@ -743,6 +746,11 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += part[w][lane][wv];
     out[4 * e4 + wv] = (float)t;
+    if (Gd != nullptr) {
+      const int64_t e = 4 * e4 + wv, ldp = (int64_t)np + KP;
+      const int r = (int)(e / ldp), cc = (int)(e % ldp) - np;
+      if (cc >= 0) Gd[(int64_t)r * KP + cc] = (r < k && cc < k) ? (double)(float)t : (r == cc ? 1.0 : 0.0);
+    }
   }
 }
 
