@@ -320,6 +320,7 @@ def main():
     rank_dt = dist.allgather_float(dt)    # every rank's own K steps; `value` uses the slowest
     dt = max(rank_dt)
     stats = ctx.kernel_stats()
+    coll_ms, coll_n = ctx.collective_ms() if w.size > 1 else (0.0, 0)
     all_ms = ctx.kernel_launch_ms()
     launch_ms = np.sort(all_ms)
     first_ms = [round(float(x), 4) for x in all_ms[:5]]
@@ -504,6 +505,8 @@ def main():
                                    "compute_err=False" % (args.config, cfg_index, cfg_desc, m, n, k, w.size),
                        "m": m, "n": n, "k": k, "algo": algo_name, "path": ctx.path_name,
                        "collective": collective,
+                       "collective_mean_ms": coll_ms if coll_n else None,      # HIP events around the per-iteration sum, this rank
+                       "collective_launches": coll_n,
                        "compute_err_true_iters_per_sec": rate_err,
                        "class_factorize": class_rate,
                        "first_call": (class_rate or {}).get("first_call"),

@@ -259,6 +259,10 @@ int pmf_invalidate_v(pmf_ctx* ctx);
 int pmf_snapshot_w(pmf_ctx* ctx);
 int pmf_restore_w(pmf_ctx* ctx);
 
+/* With pmf_profile_enable the per-iteration collective -- the sum of (W^T V | W^T W) over the ranks, what the row sharding of
+ * pymf/nmf.py:124-125 costs -- is bracketed by HIP events as well: mean duration (ms) and count since the last enable. */
+int pmf_collective_ms(pmf_ctx* ctx, double* mean_ms, int64_t* count);
+
 /* The flops one launch of that kernel really executes (pmf_kernel_stats reports SURVEY's algorithmic
  * count): W^T W is symmetric (upper triangle only) and SNMF's W step is reassociated. */
 int pmf_kernel_exec_flops(pmf_ctx* ctx, double* executed_flops_per_launch);

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
     ("pmf_snapshot_w", _c.c_int, [_ctx]),
     ("pmf_restore_w", _c.c_int, [_ctx]),
+    ("pmf_collective_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
     ("pmf_kernel_exec_flops", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_nnqp_counters", _c.c_int, [_ctx, _c.POINTER(_c.c_int64), _c.c_int32]),
@@ -411,6 +412,12 @@ class Context(object):
         self._chk(self._lib.pmf_nnqp_counters(self._h, out, 1 if reset else 0))
         keys = ("wave_tasks", "passes", "sum_largest_system", "problems")
         return {"frame16": dict(zip(keys, (int(x) for x in out[0:4]))), "frame32": dict(zip(keys, (int(x) for x in out[4:8])))}
+
+    def collective_ms(self):
+        """(mean ms, count) of the per-iteration collective's launches since profile_enable() (pmf_collective_ms)."""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        self._chk(self._lib.pmf_collective_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
 
     def synchronize(self):
         self._chk(self._lib.pmf_synchronize(self._h))

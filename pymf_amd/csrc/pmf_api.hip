@@ -179,6 +179,9 @@ struct pmf_ctx {
   void* host_ar_user = nullptr;
   std::vector<unsigned char> ar_buf;
   bool profile = false;
+  std::vector<hipEvent_t> coll_ev;           // event pairs around the per-iteration collective (allreduce_ps)
+  size_t coll_used = 0;
+  bool host_ar_only() const { return host_ar != nullptr && ipc.nranks <= 1 && comm == nullptr; }   // (blocking host round trips: nothing to time on the stream)
   double last_loop_ms = 0.0;
   KernelStat stat;
   std::string err;
@@ -441,7 +444,22 @@ int ipc_check(pmf_ctx* c) {
   return PMF_OK;
 }
 
-int allreduce_ps(pmf_ctx* c) { return allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false); }
+// The per-iteration collective: (W^T V | W^T W) summed over the ranks.  With pmf_profile_enable its launches are bracketed by
+// HIP events of their own (pmf_collective_ms: what the exchange costs an iteration at N > 1, next to the dominant kernel).
+int allreduce_ps(pmf_ctx* c) {
+  const bool timed = c->profile && multi_rank(c) && !c->host_ar_only();
+  if (timed) {
+    if (c->coll_used + 2 > c->coll_ev.size())
+      for (int q = 0; q < 2; ++q) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) c->coll_ev.push_back(e); }
+    if (c->coll_used + 2 <= c->coll_ev.size()) (void)hipEventRecord(c->coll_ev[c->coll_used], c->stream);
+  }
+  const int rc = allreduce_sum(c, c->dPS, (size_t)ps_elems(c), false);
+  if (timed && c->coll_used + 2 <= c->coll_ev.size()) {
+    (void)hipEventRecord(c->coll_ev[c->coll_used + 1], c->stream);
+    c->coll_used += 2;
+  }
+  return rc;
+}
 
 // What a one-pass launch needs to know about the free-running loop around it; hands over (and clears) the
 // pending convergence test.
@@ -2210,6 +2228,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
   if (c->w_stream) { (void)hipStreamSynchronize(c->w_stream); (void)hipStreamDestroy(c->w_stream); }
   for (hipEvent_t e : {c->ev_mt[0], c->ev_mt[1], c->ev_w[0], c->ev_w[1]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->stat.ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->coll_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2801,10 +2820,26 @@ int pmf_last_loop_ms(pmf_ctx* c, double* ms) {
   return PMF_OK;
 }
 
+int pmf_collective_ms(pmf_ctx* c, double* mean_ms, int64_t* count) {
+  if (!c || !mean_ms || !count) return PMF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double sum = 0.0;
+  int64_t n = 0;
+  for (size_t q = 0; q + 1 < c->coll_used; q += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->coll_ev[q], c->coll_ev[q + 1]) == hipSuccess) { sum += ms; ++n; }
+  }
+  *mean_ms = n ? sum / (double)n : 0.0;
+  *count = n;
+  return PMF_OK;
+}
+
 int pmf_profile_enable(pmf_ctx* c, int32_t on) {
   if (!c) return PMF_EINVAL;
   c->profile = on != 0;
   c->stat.used = 0;
+  c->coll_used = 0;
   return PMF_OK;
 }
 

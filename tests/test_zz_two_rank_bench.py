@@ -58,3 +58,4 @@ def test_two_rank_bench_line_on_one_gpu():
     assert abs(j["ms_per_step"] - max(a, b)) < 1e-9 and abs(j["value"] - 1e3 / max(a, b)) < 1e-6 * j["value"]
     assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None
     assert "one-shot IPC all-reduce" in j["config"]["collective"] and "ipc 0," not in j["config"]["collective"], j["config"]["collective"]
+    assert j["config"]["collective_launches"] == 20 and 0.0 < j["config"]["collective_mean_ms"] < 5.0, j["config"]
