@@ -10,7 +10,6 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "pmf_api.hip")
 OUT = os.path.join(HERE, "libpymf_hip.so")
 STAMP = OUT + ".srchash"
 DEPS = sorted(f for f in os.listdir(HERE) if f.endswith((".h", ".hip"))) + \
@@ -44,6 +43,9 @@ def up_to_date():
     return os.path.exists(OUT) and built_hash() == source_hash()
 
 
+UNITS = ["pmf_api.hip", "pmf_nnls_tu.hip"]     # translation units, compiled side by side (no device code crosses them)
+
+
 def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUT
@@ -51,10 +53,27 @@ def build(force=False, verbose=True):
     want = source_hash()
     if os.path.exists(STAMP):
         os.remove(STAMP)
-    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT, "-lrccl"]
+    cflags = [f for f in FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for u in UNITS:
+        obj = os.path.join(HERE, u.replace(".hip", ".o"))
+        cmd = [hipcc] + cflags + ["-c", os.path.join(HERE, u), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=HERE)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            for _, other in procs:
+                if other.poll() is None:
+                    other.kill()
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT, "-lrccl"]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=HERE)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link, cwd=HERE)
+    for o in objs:
+        os.remove(o)
     if source_hash() != want:
         raise RuntimeError("sources changed while libpymf_hip.so was being built: build again")
     with open(STAMP, "w") as f:

@@ -28,9 +28,7 @@
 #include "pmf_tiled.h"
 #include "pmf_fused.h"
 #include "pmf_coop.h"
-#include "pmf_nnls.h"
-#include "pmf_nnls_quad.h"
-#include "pmf_nnls_wave.h"
+#include "pmf_nnls_api.h"   // the sub-problem kernels themselves: pmf_nnls_tu.hip
 #include "pmf_inv.h"
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
@@ -1669,7 +1667,7 @@ int nnqp_warm_flag(pmf_ctx* c, hipStream_t s) {   // dWarm[0] = 1 iff the QPs ov
                        c->dBinv + (size_t)c->KP * c->KP);
   } else {
     if (!c->dInvA) PMFCHK(dalloc(c, &c->dInvA, (size_t)c->KP * c->KP));
-    hipLaunchKernelGGL(k_spd_unique_big, dim3(1), dim3(1024), 0, s, c->dGd, c->KP, c->k, c->dInvA, c->dWarm);
+    pmf_launch_spd_unique_big(s, c->dGd, c->KP, c->k, c->dInvA, c->dWarm);
   }
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
@@ -1704,8 +1702,8 @@ int nnqp_scratch(pmf_ctx* c, double** out) {
   *out = nullptr;
   if (c->k <= 64) return PMF_OK;
   if (!c->dQp) {
-    const int64_t ks = 64 * nnqp_big_vpl(c->k);
-    PMFCHK(dalloc(c, &c->dQp, (size_t)(nnqp_big_blocks(c->k, std::max<int64_t>(c->m, c->n)) * ks * ks)));
+    const int64_t ks = 64 * pmf_nnqp_big_vpl(c->k);
+    PMFCHK(dalloc(c, &c->dQp, (size_t)(pmf_nnqp_big_blocks(c->k, std::max<int64_t>(c->m, c->n)) * ks * ks)));
   }
   *out = c->dQp;
   return PMF_OK;
@@ -1753,7 +1751,7 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
       ctl.stats = c->dQstat;
     }
   }
-  if (quad) rc = launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm,
+  if (quad) rc = pmf_launch_nnqp_quad(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm,
                                   frames ? &ctl : nullptr, stat && c->opt_nnqp_count != 0);
   if (wave) {
     if (c->y0_cap < nprob) {                         // y0 = inv(HA) f of every problem (k_nnqp_y0): [nprob][KP] float64
@@ -1761,9 +1759,9 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
       PMFCHK(dalloc(c, &c->dY0, (size_t)nprob * c->KP));
       c->y0_cap = nprob;
     }
-    rc = launch_nnqp_wave(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, c->dY0);
+    rc = pmf_launch_nnqp_wave(c->stream, c->KP, c->k, c->dGd, c->dBinv + (size_t)c->KP * c->KP, c->dBinv, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, c->dY0);
   }
-  if (rc == PMF_OK) rc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, (quad || wave) ? 1 : 0);
+  if (rc == PMF_OK) rc = pmf_launch_nnqp(c->stream, c->KP, c->k, c->dGd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, c->dWarm, qp, (quad || wave) ? 1 : 0);
   if (stat) stat_end(c, SITE_NNQP_W);
   if (rc != PMF_OK) return fail(c, rc, "nnqp launch failed");
   HIPCHK(c, hipGetLastError());
@@ -1788,8 +1786,7 @@ int als_update_h(pmf_ctx* c) {
   PMFCHK(prc);
   const int64_t ldp = (int64_t)c->np + c->KP;
   if (!c->gd_is_s) {           // (the sums were cached, or crossed the ranks after the local reduce)
-    hipLaunchKernelGGL(k_hessian_from_ps, dim3((unsigned)((c->KP * c->KP + 255) / 256)), dim3(256), 0,
-                       c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
+    pmf_launch_hessian_from_ps(c->stream, c->dPS, ldp, c->np, c->KP, c->k, c->dGd);
     HIPCHK(c, hipGetLastError());
   }
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
@@ -2055,7 +2052,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
     if (c->opt_nnqp_quad && c->k <= 64 && (c->m >= 16384 || c->opt_nnqp_quad == 2)) snprintf(buf, sizeof(buf), "k_nnqp_quad(update_w)");
     else if (c->k <= 64) snprintf(buf, sizeof(buf), "k_nnqp<%d>(update_w)", c->k <= 16 ? 16 : c->k <= 32 ? 32 : 64);
     else if (nnqp_use_wave(c)) snprintf(buf, sizeof(buf), "k_nnqp_wave(update_w)");
-    else snprintf(buf, sizeof(buf), "k_nnqp_big<%d>(update_w)", nnqp_big_vpl(c->k));
+    else snprintf(buf, sizeof(buf), "k_nnqp_big<%d>(update_w)", pmf_nnqp_big_vpl(c->k));
     st.name = buf;
     st.bytes = 4.0 * (3.0 * m * k);               // right-hand sides read, warm start read, solution written
   } else if ((c->algo == PMF_ALGO_NMF) && c->nb == 1) {
@@ -2707,7 +2704,7 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
         } else {
           double* qp = nullptr;
           PMFCHK(nnqp_scratch(c, &qp));
-          const int qrc = launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm, qp);
+          const int qrc = pmf_launch_nnqp(c->stream, c->KP, c->k, c->dGd, Ft, 1, c->KP, Wt, 1, c->KP, rows, c->dWarm, qp, 0);
           if (qrc != PMF_OK) return fail(c, qrc, "nnqp launch (streamed W tile) failed");
           HIPCHK(c, hipGetLastError());
         }
@@ -2792,14 +2789,6 @@ int pmf_nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   return nndsvd_init(c, rank_found);
 }
 
-#ifdef PMF_QUAD_COUNT
-extern "C" int pmf_debug_quad_counts(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_cnt), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_quad_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_quad_cnt), z, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_quad_t), z, 8 * sizeof(unsigned long long)); }
-  return 0;
-}
-#endif
 
 int pmf_nnqp_counters(pmf_ctx* c, int64_t* out8, int32_t reset) {
   if (!c || !out8) return PMF_EINVAL;

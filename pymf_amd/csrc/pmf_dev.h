@@ -68,6 +68,17 @@ __device__ __forceinline__ double pmf_rcp_f64(double d) {
   return x;
 }
 
+// float64 MFMA (v_mfma_f64_16x16x4_f64) and a wave-uniform lane read of a double: shared by pmf_inv.h and the NMFALS kernels
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
 // Sum over the 64 lanes, returned in every lane.  Butterfly inside each row of 16 lanes on DPP
 // (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: register-to-register, a few cycles
 // each -- __shfl_xor goes through the LDS crossbar, ~100 cycles a step), then the four row sums are

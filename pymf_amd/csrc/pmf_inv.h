@@ -23,14 +23,7 @@
 // The matrix is scaled to unit diagonal first (inv(G) = S inv(S G S) S): every pivot is then <= 1,
 // which makes the one-FMA-per-entry form of the 16 x 16 elimination free of cancellation.
 #pragma once
-#include "pmf_dev.h"
-#include "pmf_nnls.h"   // readlane_f64
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
+#include "pmf_dev.h"     // f64x4, mfma_f64, readlane_f64
 
 // Index of element (row, col) of a 16 x 16 tile kept in LDS the way store_tile() below writes it.
 __device__ __forceinline__ int tile_lds_index(int row, int col) {

@@ -44,12 +44,6 @@ __device__ unsigned long long g_nnqp_cnt[4];   // outer iterations, removals, pr
 #define PMF_NNQP_TICK(q) do { } while (0)
 #endif
 
-__device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-  return __hiloint2double(hi, lo);
-}
-
 // min / max over the wave, as wave_sum_f64: DPP butterfly inside the rows of 16, the four row results as scalars
 __device__ __forceinline__ double wave_min_f64(double v) {
   v = fmin(v, dpp_mov_f64<0xB1>(v));

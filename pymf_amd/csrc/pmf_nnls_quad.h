@@ -45,6 +45,7 @@
 #include <type_traits>
 #include "pmf_dev.h"
 #include "pmf_nnls.h"
+#include "pmf_nnls_api.h"   // QuadCtl
 
 constexpr int QLD = 66;            // LDS row stride of the shared matrices in doubles (528 B: rows start on different banks)
 constexpr int QNS = 32;            // largest system a problem factorises
@@ -126,21 +127,6 @@ __device__ unsigned long long g_quad_cnt[16];
 // QN: the frame -- the largest system a problem factorises here (32: every problem, k / 2 <= 32; 16: the form for settled
 // active sets, 12 waves per workgroup around ONE LDS image of HA and B and a third less registers: three waves per SIMD
 // instead of two; a problem that needs more puts itself on a list and is left, untouched, to a QN = 32 launch behind).
-// QuadCtl (all null: every problem on this launch's frame): dlist / dcount -- the problems QN = 16 leaves to the QN = 32 launch
-// behind it, as a compact list (that launch returns before staging anything when the list is empty); nbig_* -- how many
-// problems of a half step START beyond 16 unknowns, this call's count, the previous call's (read) and the next call's
-// (zeroed here: no memset launches between the kernels).
-struct QuadCtl {
-  int* dlist;
-  int* dcount;            // this call's list length
-  int* dcount_next;       // the next call's: zeroed by the first launch of this call
-  int* nbig;              // this call's count
-  const int* nbig_prev;   // the previous call's
-  int* nbig_next;         // the next call's: zeroed likewise
-  unsigned long long* stats;   // or NULL: [2 frames][4] running totals of this site -- wave tasks, passes, sum over the passes of the
-                               // largest system among the wave's four problems (what the frame-padded elimination runs over), problems
-                               // solved here (bench.py's roofline block reads them live: pmf_nnqp_counters); one atomic per wave
-};
 // COUNT: the instantiation behind pmf_set_option("nnqp_count", 1) -- it keeps QuadCtl::stats (a counting pass costs 8 % of
 // the kernel's time: the production loop carries no counters).  (y0 = B f of all problems as ONE float64-MFMA product ahead
 // of the kernel -- k_nnqp_y0, as k_nnqp_wave has it -- was measured and dropped: the product and the 134 MB it writes and

@@ -23,7 +23,6 @@
 #include "pmf_dev.h"
 #include "pmf_nnls.h"
 #include "pmf_nnls_quad.h"   // static_for
-#include "pmf_inv.h"         // mfma_f64
 
 #ifndef PMF_WAVE_NWV
 #define PMF_WAVE_NWV 1

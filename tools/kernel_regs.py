@@ -13,26 +13,36 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def code_object(so):
+def code_objects(so):
+    """Every gfx950 code object of the file (one offload bundle per translation unit)."""
     data = open(so, "rb").read()
-    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    n = struct.unpack_from("<Q", data, i + 24)[0]
-    off = i + 32
-    for _ in range(n):
-        o, s, ts = struct.unpack_from("<QQQ", data, off)
-        off += 24
-        t = data[off:off + ts].decode()
-        off += ts
-        if "gfx950" in t:
-            return data[i + o:i + o + s]
-    raise SystemExit("no gfx950 code object in " + so)
+    out, pos = [], 0
+    while True:
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__", pos)
+        if i < 0:
+            break
+        pos = i + 24
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, s, ts = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            t = data[off:off + ts].decode(errors="replace")
+            off += ts
+            if "gfx950" in t and s > 0:
+                out.append(data[i + o:i + o + s])
+    if not out:
+        raise SystemExit("no gfx950 code object in " + so)
+    return out
 
 
 def kernels(so):
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code_object(so))
-        f.flush()
-        txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
+    txt = ""
+    for co in code_objects(so):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt += subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
     rows = []
     for k in re.split(r"\n\s+- \.agpr_count:", txt)[1:]:
         k = ".agpr_count:" + k
