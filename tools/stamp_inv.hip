@@ -13,13 +13,13 @@ int run(int k) {
   std::vector<double> H((size_t)k*n), G((size_t)KP*KP, 0.0);
   srand(1); for (auto& x : H) x = rand() / (double)RAND_MAX;
   for (int i=0;i<KP;++i) for (int j=0;j<KP;++j){ double s=0; if(i<k&&j<k){ for(int t=0;t<n;++t) s+=H[(size_t)i*n+t]*H[(size_t)j*n+t]; if(i==j) s+=1e-3; } else s = (i==j); G[(size_t)i*KP+j]=s; }
-  double *dG,*dI;
+  double *dG,*dI,*dP; int* dFlag; CK(hipMalloc(&dP,KP*KP*8)); CK(hipMalloc(&dFlag,4));
   CK(hipMalloc(&dG,KP*KP*8)); CK(hipMalloc(&dI,KP*KP*8));
   CK(hipMemcpy(dG,G.data(),KP*KP*8,hipMemcpyHostToDevice));
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep=0; rep<3; ++rep){
     hipEventRecord(e0);
-    for (int it=0; it<200; ++it) hipLaunchKernelGGL((k_inverse_spd_mfma<NBLK>), dim3(1), dim3(64 * NBLK * (NBLK / 4)), 0, 0, dG, KP, k, dI, (const int*)nullptr);
+    for (int it=0; it<200; ++it) hipLaunchKernelGGL((k_inverse_spd_mfma<NBLK>), dim3(1), dim3(64 * NBLK * (NBLK / 4)), 0, 0, dG, KP, k, dI, (const int*)nullptr, (int*)nullptr, dFlag, getenv("INV_PATCH") ? dP : (double*)nullptr);
     hipEventRecord(e1); CK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms,e0,e1);
     printf("k_inverse_spd_mfma<%d>, k = %d: %.2f us per launch (back to back)\n", NBLK, k, ms/200*1e3);
