@@ -152,3 +152,19 @@ def test_every_documented_option_is_known_to_the_library(lib):
     with pytest.raises(_lib.PmfError):
         ctx.set_option("no_such_option", 1)
     ctx.close()
+
+
+def test_a_library_built_from_other_sources_is_refused(monkeypatch):
+    """the driver's box loads the .so that travelled with the snapshot; a binary that does not belong to the
+    sources at hand must not pass silently.  build.py stamps the library with a SHA-256 of csrc/*.h, csrc/*.hip,
+    include/pymf_hip.h and the flags; _lib.load() compares."""
+    from pymf_amd import _lib
+    from pymf_amd.csrc import build as b
+    assert b.up_to_date() and b.built_hash() == b.source_hash()          # the tree under test is consistent
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.delenv("PMF_LIB", raising=False)
+    monkeypatch.setattr(b, "source_hash", lambda: "0" * 64)
+    with pytest.raises(_lib.PmfError, match="not built from the sources at hand"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
