@@ -43,7 +43,7 @@ def up_to_date():
     return os.path.exists(OUT) and built_hash() == source_hash()
 
 
-UNITS = ["pmf_api.hip", "pmf_nnls_tu.hip"]     # translation units, compiled side by side (no device code crosses them)
+UNITS = ["pmf_nnls_quad_tu.hip", "pmf_api.hip", "pmf_nnls_tu.hip", "pmf_fused_tu.hip"]   # slowest first     # translation units, compiled side by side (no device code crosses them)
 
 
 def build(force=False, verbose=True):

@@ -26,8 +26,7 @@
 #include "pmf_dev.h"
 #include "pmf_small.h"
 #include "pmf_tiled.h"
-#include "pmf_fused.h"
-#include "pmf_coop.h"
+#include "pmf_fused_api.h"  // the one-pass kernels themselves: pmf_fused_tu.hip
 #include "pmf_nnls_api.h"   // the sub-problem kernels themselves: pmf_nnls_tu.hip
 #include "pmf_inv.h"
 #include "pmf_csr.h"
@@ -1292,15 +1291,14 @@ int nmf_fused_pass(pmf_ctx* c) {
   if (rn && !c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
   if (c->fused8) {               // the cooperative form (pmf_coop.h)
     stat_begin(c, SITE_FUSED);
-    const int lrc8 = launch_coop(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT, c->np,
+    const int lrc8 = pmf_launch_coop(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT, c->np,
                                  rn ? c->dD : c->dV, c->dW, c->dH, c->dG, c->mp, c->fused_wgs, (float)c->lamb_w, c->dSlab,
                                  c->stop_arg);
     stat_end(c, SITE_FUSED);
     if (lrc8 != PMF_OK) return fail(c, lrc8, "cooperative one-pass kernel launch failed");
     HIPCHK(c, hipGetLastError());
     const int NTP8 = c->np / 16, KT8 = c->KP / 16;
-    hipLaunchKernelGGL(k_reduce_slabs_coop, dim3((unsigned)(4 * c->coop_bt * (NTP8 + KT8))), dim3(1024), 0, c->stream, c->dSlab,
-                       c->fused_wgs, c->coop_bt, NTP8, c->np, c->dPS, c->stop_arg);
+    pmf_launch_reduce_slabs_coop(c->stream, c->dSlab, c->fused_wgs, c->coop_bt, NTP8, KT8, c->np, c->dPS, c->stop_arg);
     HIPCHK(c, hipGetLastError());
     PMFCHK(allreduce_ps(c));
     c->ps_valid = true;
@@ -1308,7 +1306,7 @@ int nmf_fused_pass(pmf_ctx* c) {
   }
   const FusedCtl ctl = take_fused_ctl(c);
   stat_begin(c, SITE_FUSED);
-  const int lrc = launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
+  const int lrc = pmf_launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
                                c->np, rn ? c->dD : c->dV, c->dW, c->dH, Gsrc, c->mp, c->fused_wgs, (float)c->lamb_w,
                                c->dSlab, ctl, ngp);
   stat_end(c, SITE_FUSED);
@@ -1406,8 +1404,8 @@ int snmf_fused_pass(pmf_ctx* c) {
   PMFCHK(snmf_inverse(c));
   const FusedCtl ctl = take_fused_ctl(c);
   stat_begin(c, SITE_FUSED);
-  const int lrc = launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dMT, nullptr, c->mp,
-                               c->fused_wgs, 0.f, c->dSlab, ctl);
+  const int lrc = pmf_launch_fused(c->stream, FUSED_SNMF, c->NT, c->np, c->dV, c->dW, c->dMT, nullptr, c->mp,
+                                   c->fused_wgs, 0.f, c->dSlab, ctl, 0);
   stat_end(c, SITE_FUSED);
   if (lrc != PMF_OK) return fail(c, lrc, "fused SNMF kernel launch failed");
   HIPCHK(c, hipGetLastError());
@@ -2031,7 +2029,7 @@ void choose_stat_site(pmf_ctx* c, bool gram) {
   } else if (c->fused_wgs > 0 && c->algo != PMF_ALGO_NMFALS) {
     st.site = SITE_FUSED;
     st.name = c->fused8 ? c->path.c_str()
-                        : fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_SNMF   ? FUSED_SNMF
+                        : pmf_fused_kernel_name(c->NT, c->np, c->algo == PMF_ALGO_SNMF   ? FUSED_SNMF
                                                           : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF
                                                           : c->algo == PMF_ALGO_RNMF ? FUSED_RNMF
                                                                                      : FUSED_NMF);
@@ -2112,7 +2110,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   if ((algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF) && c->NT <= 2 && c->np == 448) c->np = 512;
   // ... and the cooperative kernel (pmf_coop.h) takes 6, 8, 12 or 16 column panels beyond 4
   if ((algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF) && c->nb == 1 && k <= 128) {
-    const int padded = coop_pad_np(c->NT, c->np);
+    const int padded = pmf_coop_pad_np(c->NT, c->np);
     if (padded > 0) c->np = padded;
   }
   int rc = [&]() -> int {
@@ -2133,14 +2131,14 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
     c->rows_per_chunk = (int)(round_up((blocks16 + c->nchunks - 1) / c->nchunks, 4) * 16);   // whole 64-row stages (k_colgemm_stream)
     c->nchunks = (int)((c->mp + c->rows_per_chunk - 1) / c->rows_per_chunk);
     c->fused_wgs = (c->nb == 1 && (algo == PMF_ALGO_NMF || algo == PMF_ALGO_SNMF || algo == PMF_ALGO_BNMF || algo == PMF_ALGO_RNMF))
-                       ? fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
+                       ? pmf_fused_grid_for(c->NT, c->np, c->mp, /*allow_split=*/algo != PMF_ALGO_SNMF) : 0;
     {
       int bt = 0, rb = 0, pn = 0;
-      if (c->fused_wgs == 0 && c->nb == 1 && coop_shape(c->NT, c->np, &bt, &rb, &pn) &&
+      if (c->fused_wgs == 0 && c->nb == 1 && pmf_coop_shape(c->NT, c->np, &bt, &rb, &pn) &&
           (algo == PMF_ALGO_NMF || algo == PMF_ALGO_BNMF || (algo == PMF_ALGO_RNMF && bt == 2 && rb == 4))) {
         c->fused8 = true;
         c->coop_bt = bt; c->coop_rb = rb;
-        c->fused_wgs = coop_grid_for(c->mp, rb);
+        c->fused_wgs = pmf_coop_grid_for(c->mp, rb);
       }
     }
     const int nslabs = std::max(c->nchunks, c->fused_wgs);
@@ -2190,7 +2188,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
              algo == PMF_ALGO_BNMF ? ",bnmf" : algo == PMF_ALGO_RNMF ? ",rnmf" : "");
     c->path = nb_;
   } else
-  c->path = (c->fused_wgs > 0) ? std::string(fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF   ? FUSED_SNMF
+  c->path = (c->fused_wgs > 0) ? std::string(pmf_fused_kernel_name(c->NT, c->np, algo == PMF_ALGO_SNMF   ? FUSED_SNMF
                                                                            : algo == PMF_ALGO_BNMF ? FUSED_BNMF
                                                                            : algo == PMF_ALGO_RNMF ? FUSED_RNMF
                                                                                                    : FUSED_NMF))

@@ -31,6 +31,7 @@
 #pragma once
 #include "pmf_dev.h"
 #include "../../include/pymf_hip.h"
+#include "pmf_fused_api.h"   // FUSED_*, FusedCtl
 
 #define PMF_GLDS16(gsrc, ldst)                                                            \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), \
@@ -97,22 +98,6 @@ __device__ __forceinline__ f32x4 vtile_read4(const float* base, int row, int chu
 
 // blk_per / blk_extra: 16-row blocks per wave (floor) and the number of waves that take one
 // more; computed on the host so every loop bound and base address is scalar (SGPR).
-enum { FUSED_NMF = 0, FUSED_SNMF = 1, FUSED_BNMF = 2, FUSED_RNMF = 3 };   // RNMF: V is D = S - data
-
-// Free-running pmf_factorize loops.  stop: a launch enqueued behind a converged iteration is a no-op.
-// conv_iter >= 0: the error and the convergence test of THAT (the previous) iteration, nmf.py:134-139,
-// 198-202, are still to be evaluated from the trace terms its H step left in tt -- every workgroup does
-// it for itself while its first tiles are in flight (same data, same arithmetic: the same decision
-// everywhere; workgroup 0 records it), which saves the k_conv_check launch between two iterations:
-// 4.8 us of a 67 us iteration at 65 536 x 512, k = 32.  Same expressions as k_conv_check (pmf_small.h).
-struct FusedCtl {
-  int* stop;            // [0] 0 run / 1 converged / 2 the trace identity cancels, [1] iteration; or NULL
-  const double* tt;     // ntt pairs (<P,H>, <S,G>)
-  double* ferr;         // device error history
-  double vnorm2, eps, nsamp;
-  int ntt, conv_iter;
-};
-
 template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ V,
                                                        float* __restrict__ W,

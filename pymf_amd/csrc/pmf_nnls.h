@@ -22,6 +22,7 @@
 #include "pmf_dev.h"
 #include "../../include/pymf_hip.h"
 
+#ifndef PMF_NNLS_TEMPLATES_ONLY   // (non-template kernels: defined by the one translation unit that launches them)
 // HA (float64, padded: identity on rows/cols >= k) from the reduced (P | S) buffer: HA = S.
 __global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int np, int KP, int k,
                                   double* __restrict__ Gd) {
@@ -32,6 +33,8 @@ __global__ void k_hessian_from_ps(const float* __restrict__ PS, int64_t ldp, int
   if (r >= k || c >= k) v = (r == c) ? 1.0 : 0.0;
   Gd[q] = v;
 }
+
+#endif
 
 // (The uniqueness test -- flag = 1 iff the unpivoted LDL^T of HA, dead variables left out, keeps every pivot above 1e-8 of its
 // diagonal entry -- is a by-product of k_inverse_spd_mfma (pmf_inv.h: `spd_flag`) since round 4; the one-wave kernel of rounds
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256) void k_nnqp(const double* __restrict__ Hd, int
 // between problems.  Same pivoting rules, tolerances and tie-breaks as k_nnqp: the results agree
 // with it where both apply (k <= 64), and the minimiser is unique whenever HA is positive definite.
 // A generic path, not a fast one: every set change streams |P| * k doubles of A.
+#ifndef PMF_NNLS_TEMPLATES_ONLY
 __global__ __launch_bounds__(1024) void k_spd_unique_big(const double* __restrict__ Hd, int KP, int k,
                                                          double* __restrict__ M /*[KP][KP] scratch*/,
                                                          int* __restrict__ flag) {
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(1024) void k_spd_unique_big(const double* __restric
   __syncthreads();
   if (tid == 0) flag[0] = s_ok;
 }
+#endif
 
 template <int VPL>   // variables per lane: 2, 4, 8 or 16 (k <= 64 VPL)
 __global__ __launch_bounds__(64) void k_nnqp_big(const double* __restrict__ Hd, int KP, int k,
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(64) void k_nnqp_big(const double* __restrict__ Hd, 
 }
 
 // scratch doubles k_nnqp_big needs for `blocks` workgroups
+#ifndef PMF_NNLS_TEMPLATES_ONLY   // (a launcher's body instantiates its kernels wherever it is parsed)
 static inline int nnqp_big_vpl(int k) { return k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 16; }
 static inline int64_t nnqp_big_blocks(int k, int64_t nprob) {
   const int64_t KS = 64 * nnqp_big_vpl(k);
@@ -562,3 +568,4 @@ static inline int launch_nnqp(hipStream_t s, int KP, int k, const double* Hd, co
   }
   return PMF_OK;
 }
+#endif

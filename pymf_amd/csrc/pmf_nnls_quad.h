@@ -522,6 +522,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
   }
 }
 
+#ifndef PMF_QUAD_TEMPLATES_ONLY   // (pmf_nnls_tu.hip includes this header for static_for only)
 template <int QN, int NW, bool COUNT>
 static inline int launch_nnqp_quad_t(hipStream_t s, int KP, int k, const double* Horig, const double* Hd, const double* Bd, const float* F, int64_t f_sk,
                                      int64_t f_sp, float* X, int64_t x_sk, int64_t x_sp, int64_t nprob, const int* warm, const QuadCtl& ctl) {
@@ -557,3 +558,4 @@ static inline int launch_nnqp_quad(hipStream_t s, int KP, int k, const double* H
   return launch_nnqp_quad_t<32, 4, false>(s, KP, k, Horig, Hd, Bd, F, f_sk, f_sp, X, x_sk, x_sp, nprob, warm,
                                           QuadCtl{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 }
+#endif
