@@ -108,10 +108,10 @@ def test_class_level_multi_rank_path_on_one_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [2, 4])
+@pytest.mark.parametrize("size", [2, 4, 8])
 def test_one_shot_ipc_allreduce_processes_on_one_gpu(size):
     """the one-shot all-reduce (pmf_ipc.h: every rank writes its partial of (W^T V | W^T W) into
-    every peer's IPC-mapped receive area and adds the N partials in rank order) with two and with FOUR processes sharing GPU 0 --
+    every peer's IPC-mapped receive area and adds the N partials in rank order) with two, four and EIGHT processes (the node size the receive areas are laid out for) sharing GPU 0 --
     RCCL refuses that set-up ("Duplicate GPU detected").  The class-level worker must reproduce the unsharded oracle,
     keep H bit-identical across the ranks, leave an early-exiting loop at the same iteration on both ranks, AND give
     the same bits as the host transport (both add in rank order): the worker prints digests that are compared here."""
