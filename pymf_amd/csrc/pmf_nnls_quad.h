@@ -309,33 +309,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
       }
 
       PMF_QSTAMP(0);
-      // ---- complement form: y = B (f on P) = y0 - B (f on N), kept in vecV; b = -y[N].  Primal: b = f[P]. ----
-      double y[4] = {y0[0], y0[1], y0[2], y0[3]};
-      {
-        // over the positions of the S frame (S = N here), four at a time: one dword of the list, then the four operands
-        // and eight row pieces are requested TOGETHER (term by term: a chain of dependent LDS round trips)
-        for (int p0 = jstart & ~3; p0 < QN; p0 += 4) {
-          const unsigned u = reinterpret_cast<const unsigned*>(lS)[p0 >> 2];
-          double fc[4];
-          const double* row[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool lv = comp && p0 + e >= shift;
-            const int c = lv ? (int)((u >> (8 * e)) & 0xffu) : 0;
-            fc[e] = lv ? vecV[c] : 0.0;
-            row[e] = sM + 64 * QLD + c * QLD + r * 2;                 // B, row c, this lane's two 16-byte pieces
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            y[0] = fma(-row[e][0], fc[e], y[0]); y[1] = fma(-row[e][1], fc[e], y[1]);
-            y[2] = fma(-row[e][32], fc[e], y[2]); y[3] = fma(-row[e][33], fc[e], y[3]);
-          }
-        }
-      }
+      // ---- complement form, round 4: with nu = mu - f_N the system reads B[N,N] nu = -(y0)_N (y0 = B f, formed once per
+      // problem), the solution x = y0 + B[:,N] nu and the multipliers w_N = f_N - mu = -nu: ONE product with the columns of
+      // N per pass (below, behind the solve) instead of two -- rounds 2-3 first formed y = B (f on P) = y0 - B[:,N] f_N, a
+      // product of its own and one of the seven latency chains of a pass (12 k of its 51 k ticks).  Primal: b = f[P]. ----
       __builtin_amdgcn_wave_barrier();
       if (comp) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) vecV[16 * s + r] = y[s];
+        for (int s = 0; s < 4; ++s) vecV[16 * s + r] = y0[s];
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -445,7 +426,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
       }
       PMF_QSTAMP(5);
       // ---- candidate solution s and dual w per variable ----
-      //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)
+      //   complement: P: s = y0 + z, w = 0;  N: s = 0, w = -nu(t)
       //   primal:     P: s = mu(t), w = 0;   N: s = 0, w = f - z
       double sv[4], w[4];
 #pragma unroll
@@ -457,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_nnqp_quad(const do
         const unsigned long long smask = comp ? (~pm & kmask) : pm;
         const bool inS = (smask >> v) & 1ull;
         const double muv = inS ? vecC[(shift + __popcll(smask & below)) & (QN - 1)] : 0.0;
-        if (comp) { sv[s] = inP ? y[s] + z[s] : 0.0; w[s] = (real && !inP) ? f[s] - muv : 0.0; }
+        if (comp) { sv[s] = inP ? y0[s] + z[s] : 0.0; w[s] = (real && !inP) ? -muv : 0.0; }
         else { sv[s] = inP ? muv : 0.0; w[s] = (real && !inP) ? f[s] - z[s] : 0.0; }
       }
       __builtin_amdgcn_wave_barrier();
