@@ -195,13 +195,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restr
       if (t == 0) { if (pass == 0) atomicAdd(&g_quad_cnt[0], 1ull); atomicAdd(&g_quad_cnt[1], 1ull); atomicAdd(&g_quad_cnt[2], (unsigned long long)ns); atomicAdd(&g_quad_cnt[4 + min(ns / 8, 8)], 1ull); }
 #endif
       PMF_QSTAMP(0);
-      // ---- complement form: y = B (f on P) = y0 - B (f on N), y0 = B (f on the live variables) once per problem ----
-      double y[2] = {0.0, 0.0};
+      // ---- complement form (round 4, as k_nnqp_quad): with nu = mu - f_N the system is B[N,N] nu = -(y0)_N, y0 = B f once per
+      //      problem (k_nnqp_y0); x = y0 + B[:,N] nu, w_N = -nu: ONE product with the rows of N per pass (behind the solve)
+      //      instead of two (rounds 2-3 first formed y = y0 - B (f on N): ns rows of B from L2 per pass) ----
       if (comp) {
-        y[0] = y0[0]; y[1] = y0[1];
-        wv_rows_dot<true, true>(Bd, KP, t, lst, vecV, ns, y[0], y[1]);
         __builtin_amdgcn_wave_barrier();
-        vecV[t] = y[0]; vecV[t + 64] = y[1];
+        vecV[t] = y0[0]; vecV[t + 64] = y0[1];
         __builtin_amdgcn_wave_barrier();
       }
       PMF_QSTAMP(1);
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restr
       wv_rows_dot<false, false>(Msel, KP, t, lst, vecC, ns, z[0], z[1]);
       PMF_QSTAMP(5);
       // ---- candidate solution s and dual w per variable, then block principal pivoting (k_nnqp_quad's rules) ----
-      //   complement: P: s = y + z, w = 0;   N: s = 0, w = f - mu(t)
+      //   complement: P: s = y0 + z, w = 0;  N: s = 0, w = -nu(t)
       //   primal:     P: s = mu(t), w = 0;   N: s = 0, w = f - z
       unsigned long long out_m[2], in_m[2];
 #pragma unroll
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_nnqp_wave(const double* __restr
         const bool real = (live[s] >> t) & 1ull;
         const double muv = mypos[s] >= 0 ? vecC[mypos[s]] : 0.0;
         double sv, w;
-        if (comp) { sv = inP ? y[s] + z[s] : 0.0; w = (real && !inP) ? f[s] - muv : 0.0; }
+        if (comp) { sv = inP ? y0[s] + z[s] : 0.0; w = (real && !inP) ? -muv : 0.0; }
         else { sv = inP ? muv : 0.0; w = (real && !inP) ? f[s] - z[s] : 0.0; }
         out_m[s] = __ballot(inP && sv < 0.0);
         in_m[s] = __ballot(real && !inP && w > tol);
