@@ -69,7 +69,8 @@ int pmf_nccl_unique_id(void* out);
  *   algo      PMF_ALGO_*
  *   m_local   rows of V (= rows of W) held by THIS rank (the whole matrix when nranks==1)
  *   n         columns of V (= columns of H), identical on all ranks
- *   k         num_bases, 1 .. 1024 for every algorithm (beyond 128 -- 64 for NMFALS -- generic kernels run)
+ *   k         num_bases, 1 .. 2432 (NMFALS / NMFNNLS: 1 .. 1024); beyond 128 -- 64 for NMFALS -- generic kernels run.
+ *             (The reference has no limit, nmf.py:116-120; beyond these PMF_EINVAL.)
  *   rank,nranks,nccl_id   RCCL world; nranks==1 -> nccl_id may be NULL and RCCL is not touched
  *                         (a non-NULL id with nranks==1 creates a 1-rank communicator)
  */

@@ -85,7 +85,8 @@ def test_bad_arguments_return_einval(lib):
     assert _create_code(lib, lib.ALGO_NMF, 4, 0, 2) == lib.PMF_EINVAL          # n < 1
     assert _create_code(lib, lib.ALGO_NMF, 4, 4, 0) == lib.PMF_EINVAL          # k < 1
     assert _create_code(lib, 7, 4, 4, 2) == lib.PMF_EINVAL                     # unknown algo
-    assert _create_code(lib, lib.ALGO_NMF, 4, 4, 1025) == lib.PMF_EINVAL       # num_bases beyond the build's limit
+    assert _create_code(lib, lib.ALGO_NMF, 4, 4, 2433) == lib.PMF_EINVAL       # num_bases beyond the build's limit
+    assert _create_code(lib, lib.ALGO_NMFALS, 4, 4, 1025) == lib.PMF_EINVAL    # (NMFALS / NMFNNLS: 1 024)
     assert _create_code(lib, lib.ALGO_NMF, 4, 4, 2, 0, 3, 2) == lib.PMF_EINVAL  # rank >= nranks
     assert _create_code(lib, lib.ALGO_NMF, 4, 4, 2, 0, 0, 2, None) == lib.PMF_EINVAL   # nranks > 1 without an id
     valid = _create_code(lib, lib.ALGO_NMF, 4, 4, 129)                         # num_bases > 128 is a supported NMF shape

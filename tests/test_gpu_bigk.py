@@ -232,3 +232,41 @@ def test_nndsvd_wide_bases_vs_float64_oracle(pm):
     assert rel_fro(mdl.W, W, what="mdl.W") < 1e-3 and rel_fro(mdl.H, H, what="mdl.H") < 1e-3
     ref_err = np.linalg.norm(V.astype(np.float64) - W @ H)
     assert abs(mdl.ferr[0] - ref_err) <= 1e-3 * max(ref_err, 1e-3)
+
+
+@pytest.mark.parametrize("cls_name,shape,k,niter", [("NMF", (3000, 2600), 1500, 3), ("BNMF", (3000, 2600), 1500, 3),
+                                                    ("SNMF", (3000, 2600), 1500, 2), ("RNMF", (3000, 2600), 1500, 2),
+                                                    ("NMF", (3000, 2800), 2432, 1), ("SNMF", (3000, 2800), 2432, 1)])
+def test_beyond_1024_bases_vs_float64_oracle(pm, cls_name, shape, k, niter):
+    """The reference has no limit on num_bases (nmf.py:116-120, snmf.py:69-70); round 4 lifted the library's from 1 024 to
+    2 432 (NMFALS / NMFNNLS stay at 1 024): the generic kernels against the float64 oracles at 1 500 and at the limit."""
+    import oracle
+    from pymf_amd.rnmf import RNMF
+    from pymf_amd.bnmf import BNMF
+    rs = np.random.RandomState(sum(shape) + k)
+    V = (rs.random_sample(shape) - (0.5 if cls_name == "SNMF" else 0.0)).astype(np.float32)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    kw = {"lamb": 1.0} if cls_name == "RNMF" else {}
+    o = getattr(oracle, cls_name + "Oracle")(V.astype(np.float64), num_bases=k, **kw)
+    cls = {"RNMF": RNMF, "BNMF": BNMF}.get(cls_name) or getattr(pm, cls_name)
+    mdl = cls(V, num_bases=k, **kw)
+    if cls_name == "RNMF":                 # its init_w / init_h are part of the algorithm (rnmf.py:76-96): same seed, same stream
+        np.random.seed(5); o.factorize(niter=niter)
+        np.random.seed(5); mdl.factorize(niter=niter)
+    else:
+        o.W, o.H = W0.copy(), H0.copy()
+        mdl.W, mdl.H = W0.copy(), H0.copy()
+        o.factorize(niter=niter)
+        mdl.factorize(niter=niter)
+    assert rel_fro(mdl.W, o.W, what="mdl.W") < (2e-4 if cls_name == "RNMF" else 1e-5)
+    assert rel_fro(mdl.H, o.H, what="mdl.H") < 5e-6
+    close(mdl.ferr, o.ferr, rtol=5e-6, what="mdl.ferr")
+
+
+def test_num_bases_limits_are_reported(pm):
+    with pytest.raises(Exception) as e:
+        pm.NMF(np.ones((8, 8), dtype=np.float32), num_bases=2433).factorize(niter=1)
+    assert "2432" in str(e.value)
+    with pytest.raises(Exception) as e:
+        pm.NMFALS(np.ones((8, 8), dtype=np.float32), num_bases=1025).factorize(niter=1)
+    assert "1024" in str(e.value)

@@ -8,7 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 declare -A ARGS=( [cfg4]="--steps 20 --warmup 5" [cfg2]="--config cfg2 --steps 200 --warmup 5" \
                   [cfg3]="--config cfg3 --steps 50 --warmup 3" [cfg5]="--config cfg5 --steps 20 --warmup 5" )
-for c in cfg4 cfg2 cfg3 cfg5; do
+for c in ${CONFIGS:-cfg4 cfg2 cfg3 cfg5}; do
   python3 $R/bench.py --gpus 1 ${ARGS[$c]} > $O/$c.json 2> $O/$c.err
   tail -c 400 $O/$c.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$c -- python3 $R/bench.py --gpus 1 ${ARGS[$c]} --no-cpu-baseline > $O/${c}_under_rocprof.json 2> $O/${c}_rocprof.err
@@ -19,7 +19,7 @@ done
 python3 - $O <<'PY'
 import json, sys, glob, os
 O = sys.argv[1]
-for c in ("cfg4", "cfg2", "cfg3", "cfg5"):
+for c in (os.environ.get('CONFIGS') or 'cfg4 cfg2 cfg3 cfg5').split():
     for suffix in ("", "_under_rocprof"):
         p = os.path.join(O, c + suffix + ".json")
         try:
@@ -32,4 +32,4 @@ for c in ("cfg4", "cfg2", "cfg3", "cfg5"):
             r["max_kernel_ms"] or 0, r["bound"], r["achieved"], r["unit"], r["frac"], r["kernel_share_of_timed_region"],
             j.get("cpu_baseline", {}).get("value")))
 PY
-for c in cfg4 cfg2 cfg3 cfg5; do echo "== $c"; head -8 $O/${c}_kernel_stats.csv 2>/dev/null | cut -c1-160; done
+for c in ${CONFIGS:-cfg4 cfg2 cfg3 cfg5}; do echo "== $c"; head -8 $O/${c}_kernel_stats.csv 2>/dev/null | cut -c1-160; done
