@@ -190,33 +190,44 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt) S[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  if (nb > 0) {
-    if (!SNMF) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_w(bfirst, q);
-    }
-#pragma unroll
-    for (int p = 0; p < (SPREAD ? NPANEL - 1 : NPANEL); ++p)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_v(bfirst, p, q);
-  }
-
-  // ---- H and G into LDS by LDS-DMA as well (whole workgroup, once): 4 rows x 256 B per
-  // instruction, all in flight together with the first block's V/W tiles ----
+  // ---- prologue: H, G and the first block's V / W tiles into LDS by LDS-DMA, in the order the first block uses them ----
+  // Round 4: the requests go out stage by stage -- [H panel p of all waves' shares][V panel p of the first block] (W behind
+  // stage 0), G last -- and the first block waits for ITS stage only (counted vmcnt + a workgroup barrier per stage, H being
+  // shared): its MFMAs start when a quarter of the 72-90 KiB a workgroup pulls has landed instead of behind all of it
+  // (rounds 1-3: one vmcnt(0) + barrier; 6.5 k of the 97 k cycles of the kernel at 65 536 x 512, k = 32).
   // The MFMA N index of a lane is free: column i of tile nt of Num / Den (and of the new W) is
   // basis NT i + nt, i.e. the NT tiles of a lane hold NT CONSECUTIVE bases, so the old W rows are
   // fetched and the new ones stored NT floats at a time (16-byte accesses at k = 64).  All it takes
   // is to put the rows of H and G into the LDS images in that order; k_reduce_slabs_tiles knows it.
+  constexpr int HP = SPLIT * NT;                 // H pieces of a stage per wave (KP / 4 row groups per panel over 4 waves)
+  constexpr int GP = SNMF ? 0 : NT;              // G pieces per wave
+  constexpr int WP = SNMF ? 0 : 4;               // W pieces per wave
   {
     const int drow = lane >> 4, dchunk = lane & 15;
-    for (int d = wv; d < NPT * (KP / 4); d += 4) {             // H: panel p, rows 4rg..4rg+3
-      const int p = d / (KP / 4), rg = d % (KP / 4);
-      const int row = 4 * rg + drow;                           // LDS row 16 nt + i ...
-      const int bas = NT * (row & 15) + (row >> 4);            // ... holds basis NT i + nt (see below)
-      const float* src = H + (size_t)bas * NP + 64 * p + 4 * (dchunk ^ (row & 15));
-      PMF_GLDS16(src, sH + p * (KP * 64) + rg * 256);
+#pragma unroll
+    for (int st = 0; st < NPANEL; ++st) {
+#pragma unroll
+      for (int hh = 0; hh < SPLIT; ++hh)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {                           // H: panel p, rows 4rg..4rg+3
+          const int p = hh * NPANEL + st, rg = 4 * u + wv;
+          const int row = 4 * rg + drow;                         // LDS row 16 nt + i ...
+          const int bas = NT * (row & 15) + (row >> 4);          // ... holds basis NT i + nt
+          const float* src = H + (size_t)bas * NP + 64 * p + 4 * (dchunk ^ (row & 15));
+          PMF_GLDS16(src, sH + p * (KP * 64) + rg * 256);
+        }
+      if (nb > 0 && (st < NPANEL - 1 || !SPREAD)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_v(bfirst, st, q);
+      }
+      if (st == 0 && !SNMF && nb > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_w(bfirst, q);
+      }
     }
-    for (int rg = wv; rg < (SNMF ? 0 : KP / 4); rg += 4) {     // G: rows 4rg..4rg+3 (SNMF: no G)
+#pragma unroll
+    for (int u = 0; u < (SNMF ? 0 : NT); ++u) {                  // G: rows 4rg..4rg+3 (SNMF: no G)
+      const int rg = 4 * u + wv;
       const int row = 4 * rg + drow;
       const int bas = NT * (row & 15) + (row >> 4);
       int c = dchunk ^ (row & 15);
@@ -250,8 +261,34 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       return;
     }
   }
-  wait_vmcnt<0>();
-  __syncthreads();
+  // workgroup barrier that leaves LDS-DMA pieces in flight (__syncthreads() may drain them: vmcnt(0))
+  auto wg_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // Stage st of the prologue has landed in every wave's share.  Younger than this wave's V pieces of stage st: the later
+  // stages' H and V pieces, G, W behind stage 0 and (SPREAD) the last panel's pieces issued under steps 0-2 of the block.
+  auto first_stage = [&](int st) {
+    if (st >= NPANEL - 1) wait_vmcnt<0>();            // the last stage: G and W with it (the Den steps follow)
+    else if (SPREAD) {
+      if (st == 0) wait_vmcnt<WP + 2 * (HP + 4) + HP + GP>();
+      else if (st == 1) wait_vmcnt<(HP + 4) + HP + GP + 3>();
+      else wait_vmcnt<HP + GP + 4>();                 // (the four last-panel pieces have gone out under steps 0-3)
+    } else {
+      if (st == 0) wait_vmcnt<WP + (NPANEL - 1) * (HP + 4) + GP>();
+      else if (st == 1) wait_vmcnt<(NPANEL > 2 ? (NPANEL - 2) * (HP + 4) : 0) + GP>();
+      else if (st == 2) wait_vmcnt<(NPANEL > 3 ? (NPANEL - 3) * (HP + 4) : 0) + GP>();
+      else if (st == 3) wait_vmcnt<(NPANEL > 4 ? (NPANEL - 4) * (HP + 4) : 0) + GP>();
+      else wait_vmcnt<0>();
+    }
+    wg_barrier();
+  };
+  if (nb == 0) {          // a wave without a block: its shares of H and G, and the first block's barriers
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int st = 0; st < NPANEL; ++st) wg_barrier();
+  }
 
   // Fragment double buffers: step s+1's LDS reads are issued before step s's MFMAs.
   f32x4 fa[2];
@@ -271,8 +308,8 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #endif
   for (int b = 0; b < (SPLIT == 2 ? nb_wg : nb); ++b) {
     if (SPLIT == 2) {
-      __syncthreads();                                  // the exchange area is free again
-      if (b >= nb) { __syncthreads(); continue; }       // a pair without this block only keeps step
+      wg_barrier();                                     // the exchange area is free again
+      if (b >= nb) { wg_barrier(); continue; }          // a pair without this block only keeps step (nb == 0: above)
     }
     const int blk = bfirst + b * bstep;
     const bool more = (b + 1 < nb);
@@ -317,13 +354,18 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
     };
 
     // ---------------- phase A: Num = V_b H^T, Den = W_b G ----------------
-    wait_panel(0);               // also covers the (older) W image
+    const bool first = (b == 0);                    // the first block runs behind the prologue's stages
+    if (first) first_stage(0);
+    else wait_panel(0);          // also covers the (older) W image
     PMF_STAMP(ts1);
     load_step(0, 0);
 #pragma unroll
     for (int s = 0; s < NSA; ++s) {
       if (s + 1 < NSA) {
-        if (s + 1 < NSN && ((s + 1) & 3) == 0) wait_panel((s + 1) >> 2);
+        if (s + 1 < NSN && ((s + 1) & 3) == 0) {
+          if (first) first_stage((s + 1) >> 2);
+          else wait_panel((s + 1) >> 2);
+        }
         load_step(s + 1, (s + 1) & 1);
       }
       const int buf = s & 1;
@@ -357,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
       // (a + b == b + a exactly), hence the same new W rows
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) sX[(wv * NT + nt) * 64 + lane] = num[nt];
-      __syncthreads();
+      wg_barrier();
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) num[nt] += sX[((wv ^ 1) * NT + nt) * 64 + lane];
     }
