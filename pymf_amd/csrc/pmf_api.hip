@@ -2092,7 +2092,7 @@ int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int3
   if (algo < 0 || algo > 4) return fail(nullptr, PMF_EINVAL, "algo must be 0 (NMF), 1 (NMFALS), 2 (SNMF), 3 (BNMF) or 4 (RNMF)");
   if (m_local < 1 || n < 1 || k < 1) return fail(nullptr, PMF_EINVAL, "m, n, k must be >= 1");
   // The reference has no limit on num_bases (nmf.py:116-120); the generic kernels beyond 128 bases have been checked against
-  // the float64 oracles at 1 500, 2 304 and 2 432 bases (tools/bigk_limit_probe.py, tests/test_gpu_bigk.py); beyond 2 432 (19 blocks of 128)
+  // the float64 oracles at 1 500, 2 304 and 2 432 bases (tests/sweeps/bigk_limit_probe.py, tests/test_gpu_bigk.py); beyond 2 432 (19 blocks of 128)
   // the 16-column block of H that k_nmf_h and k_trace_terms keep in LDS (64 bytes per basis) no longer fits the 160 KiB.  NMFALS /
   // NMFNNLS beyond 128 bases solve one variable at a time (k_nnqp_big) and stay at 1 024.
   if (k > (algo == PMF_ALGO_NMFALS ? 1024 : 2432))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of NMFALS / NMFNNLS (exact active-set QP on the device) against the float64 oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pymf_amd
 from oracle import NMFALSOracle

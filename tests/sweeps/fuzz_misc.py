@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweeps of the streamed NMF path (vs the resident one) and of NNDSVD (vs the float64 closed form)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pymf_amd
 from oracle import nndsvd_closed_form

@@ -3,7 +3,7 @@
 k > n, every fused / split / tiled shape class).  ferr is compared relative to ||V||: an (almost)
 exact fit leaves a float32-sized residual floor."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pymf_amd
 from pymf_amd.rnmf import RNMF

@@ -2,7 +2,7 @@
 """Random shapes through the any-shape two-pass kernels (force_tiled) with the stream kernels on and off: W, H must be
 bit-identical between the two, and agree with the float64 oracle; ragged row counts, every base-count class."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pymf_amd import _lib
 from oracle import NMFOracle

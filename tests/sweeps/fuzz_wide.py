@@ -2,7 +2,7 @@
 """Randomised sweep of SNMF over every inverse kernel (k_inverse_spd_mfma<4>, <8>, k_inverse_spd_big) and of the
 wide-base generic paths (NMFALS / NMFNNLS > 64, SNMF / RNMF > 128) against the float64 oracles."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pymf_amd
 import oracle

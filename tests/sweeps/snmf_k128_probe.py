@@ -1,7 +1,7 @@
 """cfg5 shape class (k = n = 128): error of the device SNMF vs the float64 oracle, iteration by
 iteration, for dense and CSR input of the same matrix (diagnostic; oracle = test infrastructure)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp
 import pymf_amd
 from oracle import SNMFOracle

@@ -2,7 +2,7 @@
 """NNDSVD through the two eigen-solvers of pmf_nndsvd_init (full Jacobi / filtered top-k subspace iteration) on a few
 spectra: agreement of the two, distance from the float64 oracle, wall time.  PMF_TOPK_DEBUG=1 prints the iterations."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pymf_amd import _lib
 from oracle import nndsvd_closed_form

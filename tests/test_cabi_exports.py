@@ -66,6 +66,12 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "import torch" not in txt, f        # north_star: no PyTorch in the product
+    # ... nor may the diagnostics under tools/ (the checkers that compare with the oracle live in tests/sweeps/); the only
+    # users outside tests/ are __graft_entry__.smoke() and bench.py's cpu_baseline / parity legs
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), "tools/" + f
 
 
 def _create_code(lib, *args):

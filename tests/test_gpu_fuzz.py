@@ -1,0 +1,25 @@
+"""Seeded samples of the randomised sweeps under tests/sweeps/ (odd shapes, dtypes, layouts, every kernel class) as part of the
+GPU suite: each sweep compares the library with the float64 oracles case by case and prints `bad N` at the end."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tool,args", [("fuzz_nmf.py", ["2024", "40"]),          # NMF / SNMF / BNMF / RNMF: fused, split, coop, tiled
+                                       ("fuzz_als.py", ["2025", "25"]),          # NMFALS / NMFNNLS up to 64 bases
+                                       ("fuzz_als.py", ["2026", "10", "wide"]),  # ... 65-128 bases (k_nnqp_wave)
+                                       ("fuzz_tiled.py", ["2027", "20"]),        # two-pass kernels, stream forms on and off: bit-identical
+                                       ("fuzz_wide.py", ["2028", "12"]),         # every inverse kernel, > 128 bases
+                                       ("fuzz_misc.py", ["2029"])])              # streamed passes, NNDSVD
+def test_seeded_sample_of_the_randomised_sweeps(tool, args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", tool)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=600, cwd=ROOT)
+    out = p.stdout.decode("utf-8", "replace")
+    tail = "\n".join(out.strip().splitlines()[-15:])
+    assert p.returncode == 0, tail
+    assert out.strip().splitlines()[-1].strip() == "bad 0", tail
