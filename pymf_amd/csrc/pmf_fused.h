@@ -664,8 +664,10 @@ static inline int fused_grid_for(int NT, int np, int64_t mp, bool allow_split = 
 
 static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF) {
   static char buf[64];
-  snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d%s>", NT, np / 64,
-           mode == FUSED_SNMF ? ",snmf" : mode == FUSED_BNMF ? ",bnmf" : mode == FUSED_RNMF ? ",rnmf" : "");
+  // (the template arguments as rocprofv3 prints them: NT, column panels PER WAVE, and SPLIT 2 where two waves share a block)
+  const bool split = !fused_shape_ok(NT, np) && fused_shape_split(NT, np) && mode != FUSED_SNMF;
+  snprintf(buf, sizeof(buf), "k_nmf_fused<%d,%d%s%s>", NT, split ? np / 128 : np / 64,
+           mode == FUSED_SNMF ? ",snmf" : mode == FUSED_BNMF ? ",bnmf" : mode == FUSED_RNMF ? ",rnmf" : "", split ? ",SPLIT 2" : "");
   return buf;
 }
 

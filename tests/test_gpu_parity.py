@@ -1013,7 +1013,7 @@ def test_full_size_properties_cfg2(pm):
     m, n, k = 65536, 512, 32
     a = _lib.Context(_lib.ALGO_NMF, m, n, k)
     a.fill_v_uniform(1234); a.fill_w_uniform(42); a.fill_h_uniform(43)
-    assert a.path_name == "k_nmf_fused<2,8>"
+    assert a.path_name == "k_nmf_fused<2,4,SPLIT 2>"
     ferr, done, conv = a.factorize(8, compute_err=True)
     assert done == 8 and conv < 0
     assert np.all(np.diff(ferr) <= 1e-6 * ferr[0]), ferr
