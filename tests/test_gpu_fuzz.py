@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                        ("fuzz_als.py", ["2026", "10", "wide"]),  # ... 65-128 bases (k_nnqp_wave)
                                        ("fuzz_tiled.py", ["2027", "20"]),        # two-pass kernels, stream forms on and off: bit-identical
                                        ("fuzz_wide.py", ["2028", "12"]),         # every inverse kernel, > 128 bases
-                                       ("fuzz_misc.py", ["2029"])])              # streamed passes, NNDSVD
+                                       ("fuzz_misc.py", ["2029"]),               # streamed passes, NNDSVD
+                                       ("threads_probe.py", []),                 # 24 host threads, one object each: bit-identical to sequential
+                                       ("stress_leaks.py", [])])                 # 180 contexts, 20 000-iteration loops: memory comes back
 def test_seeded_sample_of_the_randomised_sweeps(tool, args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", tool)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=600, cwd=ROOT)
