@@ -258,6 +258,12 @@ void stat_end(pmf_ctx* c, int site) {
 }
 
 // ---- kernel launch helpers --------------------------------------------------------------
+// Grid of the element-wise kernels (256 threads, grid-stride loops): one thread per element up to 2^30 threads -- a launch of
+// more than 2^32 threads wraps without an error (found with a 36 Mi x 256 matrix, tests/sweeps/huge_probe.py).
+static inline unsigned elem_grid(int64_t count) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, (int64_t)1 << 22));
+}
+
 template <int NT, int EPI>
 int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
                    float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1, int64_t ldc = 0) {
@@ -946,7 +952,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
                      c->dH, wscale, wmode);
   HIPCHK(c, hipGetLastError());
   const int64_t total = c->mp * KP;
-  hipLaunchKernelGGL(k_nndsvd_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->dW, total, KP,
+  hipLaunchKernelGGL(k_nndsvd_w, dim3(elem_grid(total)), dim3(256), 0, c->stream, c->dW, total, KP,
                      c->m, wscale, wmode);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1077,7 +1083,7 @@ int bigk_update_w_rows(pmf_ctx* c, const float* X, float* Wr, float* W1r, float*
     PMFCHK((launch_rowgemm<8, EPI_STORE>(c, X, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
                                          W1r + b * 128, rows_p, mvalid, c->KP)));
   const int64_t count = rows_p * c->KP;
-  hipLaunchKernelGGL(k_nmf_w_elem, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, Wr, W1r, W2r, count,
+  hipLaunchKernelGGL(k_nmf_w_elem, dim3(elem_grid(count)), dim3(256), 0, c->stream, Wr, W1r, W2r, count,
                      c->algo == PMF_ALGO_BNMF ? 1 : rn ? 2 : 0, (float)c->lamb_w, c->KP, mvalid, c->k);
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
@@ -2287,7 +2293,7 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
 static int fill(pmf_ctx* c, float* X, int64_t ld, int64_t rows, int64_t cols, int64_t row0, uint64_t seed) {
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t E = rows * cols;
-  hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, X, ld,
+  hipLaunchKernelGGL(k_fill_uniform, dim3(elem_grid(E)), dim3(256), 0, c->stream, X, ld,
                      rows, cols, row0, cols, seed);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2603,7 +2609,7 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
   float* dS = nullptr;
   PMFCHK(talloc(c, tmp, &dS, (size_t)c->mp * c->np));
   const int64_t E = c->mp * c->np;
-  hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((E / 4 + 255) / 256)), dim3(256), 0, c->stream, c->dD, c->dV, E, dS);
+  hipLaunchKernelGGL(k_add_f32, dim3(elem_grid(E / 4)), dim3(256), 0, c->stream, c->dD, c->dV, E, dS);
   HIPCHK(c, hipGetLastError());
   return download_padded(c, S, c->n, dS, c->np, c->m, c->n);
 }

@@ -312,13 +312,13 @@ __global__ __launch_bounds__(1024) void k_nndsvd_finalize(const double* __restri
 __global__ __launch_bounds__(256) void k_nndsvd_w(float* __restrict__ W, int64_t total, int KP, int64_t m,
                                                   const float* __restrict__ wscale,
                                                   const int* __restrict__ wmode) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int64_t r = idx / KP;
-  const int col = (int)(idx % KP);
-  const float u = W[idx], s = wscale[col];
-  const int mode = wmode[col];
-  float o = 0.f;
-  if (r < m) o = mode == 0 ? s * fabsf(u) : (mode > 0 ? s * fmaxf(u, 0.f) : s * fmaxf(-u, 0.f));
-  W[idx] = o;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {   // (grid-stride: > 2^32 elements)
+    const int64_t r = idx / KP;
+    const int col = (int)(idx % KP);
+    const float u = W[idx], s = wscale[col];
+    const int mode = wmode[col];
+    float o = 0.f;
+    if (r < m) o = mode == 0 ? s * fabsf(u) : (mode > 0 ? s * fmaxf(u, 0.f) : s * fmaxf(-u, 0.f));
+    W[idx] = o;
+  }
 }

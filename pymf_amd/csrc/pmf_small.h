@@ -398,8 +398,7 @@ __global__ __launch_bounds__(1024) void k_inverse_spd_big(double* A0, double* A1
 // out = a + b over count floats (count a multiple of 4): RNMF's S = D + V for pmf_rnmf_get_s_f32.
 __global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ a, const float* __restrict__ b, int64_t count,
                                                  float* __restrict__ out) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (4 * q < count)
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; 4 * q < count; q += (int64_t)gridDim.x * 256)
     reinterpret_cast<f32x4*>(out)[q] = reinterpret_cast<const f32x4*>(a)[q] + reinterpret_cast<const f32x4*>(b)[q];
 }
 
@@ -489,10 +488,11 @@ __global__ void k_sum_f64(const double* __restrict__ part, int n, double* __rest
 // Synthetic U[0,1) fill of the logical rows x cols block of a padded [.,ld] buffer.
 __global__ void k_fill_uniform(float* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
                                int64_t row0, int64_t cols_global, uint64_t seed) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * cols) return;
-  const int64_t r = e / cols, c = e % cols;
-  X[r * ld + c] = u01_from(seed, (uint64_t)((row0 + r) * cols_global + c));
+  // grid-stride: a launch of one thread per element wraps silently beyond 2^32 threads (a 36 Mi x 256 matrix has 9.7e9 elements)
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e % cols;
+    X[r * ld + c] = u01_from(seed, (uint64_t)((row0 + r) * cols_global + c));
+  }
 }
 
 // ---- host <-> device transport of V / W / H (pmf_set_*_f32 / _f64, pmf_get_*_f64) ----------------------------------

@@ -1010,19 +1010,19 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_block(const float* __rest
 __global__ __launch_bounds__(256) void k_nmf_w_elem(float* __restrict__ W, const float* __restrict__ Num,
                                                     const float* __restrict__ Den, int64_t count, int bnmf,
                                                     float lamb, int KP = 0, int64_t mvalid = 0, int kvalid = 0) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= count) return;
-  const float w = W[q];
-  if (bnmf == 2) {
-    const float x = Num[q];
-    const float r = w * ((fabsf(x) - x) / (2.0f * Den[q]));
-    W[q] = (q / KP < mvalid && (int)(q % KP) < kvalid) ? r : 0.f;
-  } else if (bnmf) {
-    const float w1 = Num[q] + (3.0f * lamb) * (w * w);
-    const float w2 = ((Den[q] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
-    W[q] = w * (w1 / w2);
-  } else {
-    W[q] = (w * Num[q]) / (Den[q] + PMF_EPS_DEN);
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (int64_t)gridDim.x * 256) {   // (grid-stride: > 2^32 elements)
+    const float w = W[q];
+    if (bnmf == 2) {
+      const float x = Num[q];
+      const float r = w * ((fabsf(x) - x) / (2.0f * Den[q]));
+      W[q] = (q / KP < mvalid && (int)(q % KP) < kvalid) ? r : 0.f;
+    } else if (bnmf) {
+      const float w1 = Num[q] + (3.0f * lamb) * (w * w);
+      const float w2 = ((Den[q] + (2.0f * lamb) * (w * w * w)) + lamb * w) + PMF_EPS_DEN;
+      W[q] = w * (w1 / w2);
+    } else {
+      W[q] = (w * Num[q]) / (Den[q] + PMF_EPS_DEN);
+    }
   }
 }
 
