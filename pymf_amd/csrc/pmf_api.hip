@@ -60,6 +60,10 @@ struct pmf_ctx {
   int k = 0, device = 0, rank = 0, nranks = 1;
   int nb = 1;                   // > 1: num_bases > 128 (NMF): KP = 128 nb, bases handled in blocks of 128
   float* dW2 = nullptr;         // ... Den = W (H H^T), [mp][KP] (dW1 holds Num = V H^T)
+  float* dWideT = nullptr;      // chunk result of a product over more than PMF_WIDE_K columns
+  int64_t wide_cap = 0;
+  float *dWideN = nullptr, *dWideD = nullptr;   // ... Num and Den of the W rules there (wide_update_w_rows)
+  int64_t wide_nd_cap = 0;
   int64_t mp = 0;
   int np = 0, KP = 0, NT = 0;
   hipStream_t stream = nullptr;
@@ -312,8 +316,8 @@ int launch_rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const flo
 }
 
 template <int EPI>
-int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
-            float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
+int rowgemm_one(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
+                float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
   if (c->nb > 1) {            // num_bases > 128: the plain product in blocks of 128 bases, C is [.][KP]
     if (EPI != EPI_STORE) return fail(c, PMF_EINVAL, "rowgemm: only the plain product runs in base blocks");
     for (int b = 0; b < c->nb; ++b)
@@ -328,6 +332,62 @@ int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, 
     case 8: return launch_rowgemm<8, EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
   }
   return fail(c, PMF_EINVAL, "bad NT");
+}
+
+// A product over the columns of V is ONE accumulation chain of kdim / 4 MFMA steps per output element, and the fp32 MFMA
+// does not round its running sum to nearest: the chain loses a fraction of about 1.5e-16 * steps^2 of the sum (measured on
+// uniform data, tests/sweeps/wide_scan.py: V H^T biased by -2e-7 at 32 768 columns, -3.2e-6 at 131 072, -4.2e-5 at 524 288,
+// -1.5e-4 at 10^6 -- W comes out scaled by that factor and H by its inverse, the fit itself is unaffected).  Products over
+// more than PMF_WIDE_K columns are therefore formed in chunks of PMF_WIDE_K columns whose results are added in float32
+// (round to nearest): the bias stays at the 65 536-column level (1e-6) whatever n.  Shapes up to 65 536 columns run as before.
+constexpr int PMF_WIDE_K = 65536;
+
+template <int EPI>
+int rowgemm(pmf_ctx* c, const float* A, int64_t lda, int kdimA, const float* B, int64_t ldb,
+            float* W, const float* G, float* C, int64_t rows_p = -1, int64_t mvalid = -1) {
+  if constexpr (EPI == EPI_STORE) {
+    if (kdimA > PMF_WIDE_K) {
+      const int64_t rp = rows_p < 0 ? c->mp : rows_p;
+      const int64_t count = rp * c->KP;
+      if (c->wide_cap < count) {
+        if (c->dWideT) { (void)hipFree(c->dWideT); c->dWideT = nullptr; c->wide_cap = 0; }
+        PMFCHK(dalloc(c, &c->dWideT, (size_t)count));
+        c->wide_cap = count;
+      }
+      for (int k0 = 0; k0 < kdimA; k0 += PMF_WIDE_K) {
+        const int kc = std::min(PMF_WIDE_K, kdimA - k0);
+        PMFCHK(rowgemm_one<EPI_STORE>(c, A + k0, lda, kc, B + k0, ldb, W, G, k0 == 0 ? C : c->dWideT, rows_p, mvalid));
+        if (k0 > 0) {
+          hipLaunchKernelGGL(k_acc_f32, dim3(elem_grid(count / 4)), dim3(256), 0, c->stream, C, c->dWideT, count);
+          HIPCHK(c, hipGetLastError());
+        }
+      }
+      return PMF_OK;
+    }
+  }
+  return rowgemm_one<EPI>(c, A, lda, kdimA, B, ldb, W, G, C, rows_p, mvalid);
+}
+
+// The W rules of NMF / BNMF / RNMF over more than PMF_WIDE_K columns: Num = X H^T in chunks (above), Den = W G by a small
+// kernel, the rule element by element -- what the one-launch forms (update rule as the product's epilogue) cannot do in chunks.
+int wide_update_w_rows(pmf_ctx* c, const float* X, float* Wr, int64_t rows_p, int64_t mvalid) {
+  const int64_t count = rows_p * c->KP;
+  if (c->wide_nd_cap < count) {
+    if (c->dWideN) { (void)hipFree(c->dWideN); c->dWideN = nullptr; }
+    if (c->dWideD) { (void)hipFree(c->dWideD); c->dWideD = nullptr; }
+    c->wide_nd_cap = 0;
+    PMFCHK(dalloc(c, &c->dWideN, (size_t)count));
+    PMFCHK(dalloc(c, &c->dWideD, (size_t)count));
+    c->wide_nd_cap = count;
+  }
+  float *Num = c->dWideN, *Den = c->dWideD;
+  PMFCHK(rowgemm<EPI_STORE>(c, X, c->np, c->np, c->dH, c->np, nullptr, nullptr, Num, rows_p, mvalid));
+  hipLaunchKernelGGL(k_den_small, dim3(elem_grid(count)), dim3(256), 0, c->stream, Wr, c->dG, Den, rows_p, c->KP);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_nmf_w_elem, dim3(elem_grid(count)), dim3(256), 0, c->stream, Wr, Num, Den, count,
+                     c->algo == PMF_ALGO_BNMF ? 1 : c->algo == PMF_ALGO_RNMF ? 2 : 0, (float)c->lamb_w, c->KP, mvalid, c->k);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
 }
 
 // Partials of (W^T X | W^T W) over row chunks into c->dSlab: X [rows_p][xn] (ldx), W [rows_p][.] (ldw), chunks of rpc rows.
@@ -1056,7 +1116,7 @@ int bigk_update_w_rows(pmf_ctx* c, const float* X, float* Wr, float* W1r, float*
   for (int b = 0; b < c->nb; ++b)                            // Den = W G^T, every block from the OLD W
     PMFCHK((launch_rowgemm<8, EPI_STORE>(c, Wr, c->KP, c->KP, c->dG + (size_t)b * 128 * c->KP, c->KP, nullptr, nullptr,
                                          W2r + b * 128, rows_p, mvalid, c->KP)));
-  if (c->opt_rowgemm_stream && c->np % 128 == 0) {
+  if (c->opt_rowgemm_stream && c->np % 128 == 0 && c->np <= PMF_WIDE_K) {
     // Num = V H_b^T with the update rule as its epilogue: block b of W is rewritten in place (V H^T does not read W)
     const int ntiles = (int)(rows_p / 32);
     const dim3 grid((unsigned)std::min((ntiles + 3) / 4, 512));     // persistent workgroups (k_rowgemm_stream)
@@ -1079,9 +1139,7 @@ int bigk_update_w_rows(pmf_ctx* c, const float* X, float* Wr, float* W1r, float*
     }
     return PMF_OK;
   }
-  for (int b = 0; b < c->nb; ++b)
-    PMFCHK((launch_rowgemm<8, EPI_STORE>(c, X, c->np, c->np, c->dH + (size_t)b * 128 * c->np, c->np, nullptr, nullptr,
-                                         W1r + b * 128, rows_p, mvalid, c->KP)));
+  PMFCHK(rowgemm<EPI_STORE>(c, X, c->np, c->np, c->dH, c->np, nullptr, nullptr, W1r, rows_p, mvalid));   // (all blocks; in chunks of columns when wide)
   const int64_t count = rows_p * c->KP;
   hipLaunchKernelGGL(k_nmf_w_elem, dim3(elem_grid(count)), dim3(256), 0, c->stream, Wr, W1r, W2r, count,
                      c->algo == PMF_ALGO_BNMF ? 1 : rn ? 2 : 0, (float)c->lamb_w, c->KP, mvalid, c->k);
@@ -1133,10 +1191,12 @@ int nmf_update_w(pmf_ctx* c) {
   if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->fused_wgs > 0 && !c->fixed_h_loop && !use_csr(c))
     return nmf_fused_pass(c);
   PMFCHK(ensure_gram(c, 0.0));
-  if (c->algo == PMF_ALGO_RNMF) {
-    if (!c->s_valid) return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+  if (c->algo == PMF_ALGO_RNMF && !c->s_valid)
+    return fail(c, PMF_EINVAL, "RNMF: S does not exist yet (init_h / update_s create it, rnmf.py:94-98)");
+  if (c->np > PMF_WIDE_K)       // more columns than one accumulation chain should span: V H^T in chunks, the rule element-wise
+    return wide_update_w_rows(c, c->algo == PMF_ALGO_RNMF ? c->dD : c->dV, c->dW, c->mp, c->m);
+  if (c->algo == PMF_ALGO_RNMF)
     return rowgemm<EPI_RNMF_W>(c, c->dD, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
-  }
   if (c->algo == PMF_ALGO_BNMF)
     return rowgemm<EPI_BNMF_W>(c, c->dV, c->np, c->np, c->dH, c->np, c->dW, c->dG, nullptr);
   if (c->fixed_h_loop) {
@@ -2227,7 +2287,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage, (void*)c->dGramPart, (void*)c->dGramTickets})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage, (void*)c->dGramPart, (void*)c->dGramTickets, (void*)c->dWideT, (void*)c->dWideN, (void*)c->dWideD})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
@@ -2702,6 +2762,8 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
     if (c->st_flags & PMF_COMPUTE_W) {
       if (c->nb > 1 && (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF)) {   // blocks of 128 bases (bigk_update_w)
         PMFCHK(bigk_update_w_rows(c, T, Wt, c->dW1 + row0 * c->KP, c->dW2 + row0 * c->KP, rows_p, rows));
+      } else if ((c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->np > PMF_WIDE_K) {   // (very wide data)
+        PMFCHK(wide_update_w_rows(c, T, Wt, rows_p, rows));
       } else if (c->algo == PMF_ALGO_BNMF) {   // bnmf.py:87-90: the penalised W rule, same contractions
         PMFCHK(rowgemm<EPI_BNMF_W>(c, T, c->np, c->np, c->dH, c->np, Wt, c->dG, nullptr, rows_p, rows));
       } else if (c->algo == PMF_ALGO_SNMF) {   // snmf.py:67-70: the tile's rows of W = V M^T

@@ -402,6 +402,28 @@ __global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ a, co
     reinterpret_cast<f32x4*>(out)[q] = reinterpret_cast<const f32x4*>(a)[q] + reinterpret_cast<const f32x4*>(b)[q];
 }
 
+// dst += src (count a multiple of 4): the chunk sums of a product over very many columns (pmf_api.hip: PMF_WIDE_K).
+__global__ __launch_bounds__(256) void k_acc_f32(float* __restrict__ dst, const float* __restrict__ src, int64_t count) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; 4 * q < count; q += (int64_t)gridDim.x * 256) {
+    f32x4 d = reinterpret_cast<f32x4*>(dst)[q];
+    d += reinterpret_cast<const f32x4*>(src)[q];
+    reinterpret_cast<f32x4*>(dst)[q] = d;
+  }
+}
+
+// Den[r][j] = sum_i W[r][i] G[i][j] for a [rows][KP] W (KP <= 128): the small second product of the W rules where the
+// first one (V H^T over very many columns) was formed in chunks and the rule is applied element by element (k_nmf_w_elem).
+__global__ __launch_bounds__(256) void k_den_small(const float* __restrict__ W, const float* __restrict__ G, float* __restrict__ Den,
+                                                   int64_t rows, int KP) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < rows * KP; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / KP;
+    const int j = (int)(e % KP);
+    float s = 0.f;
+    for (int i = 0; i < KP; ++i) s = fmaf(W[r * KP + i], G[(int64_t)i * KP + j], s);
+    Den[e] = s;
+  }
+}
+
 // Per-block float64 partials of sum(X^2) over a padded [rows][ld] buffer (padding is zero).
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ X, int64_t count,
                                                double* __restrict__ part) {
