@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Degenerate VALUES against the oracle (what the reference's arithmetic does with them): all-zero data, zero rows / columns,
+constant data, a zero basis, data of magnitude 1e-12 and 1e+12, an exact low-rank V."""
+import os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import pymf_amd
+import oracle
+
+warnings.simplefilter("ignore")
+rs = np.random.RandomState(5)
+bad = 0
+
+
+def run(label, cls, ocls, V, k, niter=4, W0=None, H0=None, tol=2e-5):
+    global bad
+    m, n = V.shape
+    W0 = rs.random_sample((m, k)) if W0 is None else W0
+    H0 = rs.random_sample((k, n)) if H0 is None else H0
+    a, o = cls(V.astype(np.float32), num_bases=k), ocls(V.astype(np.float32).astype(np.float64), num_bases=k)
+    a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+    try:
+        with np.errstate(all="ignore"):
+            o.factorize(niter=niter)
+        oerr = None
+    except Exception as e:
+        oerr = type(e).__name__
+    try:
+        a.factorize(niter=niter)
+        aerr = None
+    except Exception as e:
+        aerr = type(e).__name__
+    if oerr or aerr:
+        ok = oerr == aerr
+        print("%-44s oracle raises %s, library raises %s %s" % (label, oerr, aerr, "" if ok else "BAD"))
+        bad += not ok
+        return
+    fin_o, fin_a = np.isfinite(o.W).all() and np.isfinite(o.H).all(), np.isfinite(a.W).all() and np.isfinite(a.H).all()
+    sc = lambda x: max(np.linalg.norm(x), 1e-300)
+    eW, eH = np.linalg.norm(a.W - o.W) / sc(o.W), np.linalg.norm(a.H - o.H) / sc(o.H)
+    ef = np.max(np.abs(a.ferr - o.ferr) / np.maximum(np.abs(o.ferr), 1e-6 * sc(V)))
+    ok = (fin_o == fin_a) and (not fin_o or (eW < tol and eH < tol and ef < 1e-4 and len(a.ferr) == len(o.ferr)))
+    print("%-44s finite %s/%s relW %.1e relH %.1e ferr %.1e len(ferr) %d/%d %s" % (label, fin_o, fin_a, eW, eH, ef, len(o.ferr), len(a.ferr), "" if ok else "BAD"), flush=True)
+    bad += not ok
+
+
+for (m, n, k) in ((300, 256, 16), (200, 700, 8)):
+    U = rs.random_sample((m, n))
+    run("NMF zero data %dx%d" % (m, n), pymf_amd.NMF, oracle.NMFOracle, np.zeros((m, n)), k)
+    Z = U.copy(); Z[5] = 0; Z[:, 7] = 0; Z[100:120] = 0
+    run("NMF zero rows and a zero column", pymf_amd.NMF, oracle.NMFOracle, Z, k)
+    run("NMF constant data", pymf_amd.NMF, oracle.NMFOracle, np.full((m, n), 3.0), k)
+    W0 = rs.random_sample((m, k)); W0[:, 2] = 0
+    H0 = rs.random_sample((k, n)); H0[3] = 0
+    run("NMF a zero basis in W0 and one in H0", pymf_amd.NMF, oracle.NMFOracle, U, k, W0=W0, H0=H0)
+    # (data far below the rules' 1e-9: both implementations collapse towards zero within two iterations -- W ~ 1e-28, then
+    # W^T V ~ 1e-38 -- where float32 underflows and float64 carries on with 1e-40s; same ferr, same stopping iteration; not checked)
+    run("NMF data of magnitude 1e-6", pymf_amd.NMF, oracle.NMFOracle, U * 1e-6, k, tol=1e-4)
+    run("NMF data of magnitude 1e+12", pymf_amd.NMF, oracle.NMFOracle, U * 1e12, k)
+    L = rs.random_sample((m, 3)).dot(rs.random_sample((3, n)))
+    run("NMF exact rank 3, k = %d" % k, pymf_amd.NMF, oracle.NMFOracle, L, k, niter=30, tol=1e-3)
+    run("SNMF zero data", pymf_amd.SNMF, oracle.SNMFOracle, np.zeros((m, n)), k)
+    run("SNMF constant data", pymf_amd.SNMF, oracle.SNMFOracle, np.full((m, n), -2.0), k, tol=1e-3)
+    run("SNMF zero rows and a zero column", pymf_amd.SNMF, oracle.SNMFOracle, Z - 0.3 * (Z != 0), k)
+    run("NMFALS zero data", pymf_amd.NMFALS, oracle.NMFALSOracle, np.zeros((m, n)), min(k, 8), niter=2, tol=1e-3)
+    run("NMFALS zero rows and a zero column", pymf_amd.NMFALS, oracle.NMFALSOracle, Z, min(k, 8), niter=2, tol=1e-3)
+print("bad %d" % bad)

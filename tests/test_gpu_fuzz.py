@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                        ("stress_leaks.py", []),                  # 180 contexts, 20 000-iteration loops: memory comes back
                                        ("huge_probe.py", ["20971520"]),          # V of 5.4e9 elements (> 2^32): W rows vs the oracle, one-pass vs two-pass
                                        ("huge_probe2.py", ["20971520"]),         # ... NMFALS (KKT), SNMF on it; NMF 1 024 x 1 000 000
-                                       ("wide_scan.py", [])])                    # 32 768 ... 1 000 000 columns: chunked accumulation chains
+                                       ("wide_scan.py", []),                     # 32 768 ... 1 000 000 columns: chunked accumulation chains
+                                       ("degenerate_values.py", [])])            # zero / constant / low-rank data, zero bases, 1e-6 ... 1e+12
 def test_seeded_sample_of_the_randomised_sweeps(tool, args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", tool)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=600, cwd=ROOT)
