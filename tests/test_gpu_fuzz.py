@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                        ("stress_leaks.py", []),                  # 180 contexts, 20 000-iteration loops: memory comes back
                                        ("huge_probe.py", ["20971520"]),          # V of 5.4e9 elements (> 2^32): W rows vs the oracle, one-pass vs two-pass
                                        ("huge_probe2.py", ["20971520"]),         # ... NMFALS (KKT), SNMF on it; NMF 1 024 x 1 000 000
+                                       ("huge_probe3.py", ["20971520", "256"]),  # ... 256 bases: W of 5.4e9 elements on the wide-base path
                                        ("wide_scan.py", []),                     # 32 768 ... 1 000 000 columns: chunked accumulation chains
                                        ("degenerate_values.py", [])])            # zero / constant / low-rank data, zero bases, 1e-6 ... 1e+12
 def test_seeded_sample_of_the_randomised_sweeps(tool, args):
