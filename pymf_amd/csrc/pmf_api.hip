@@ -636,6 +636,7 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
     c->g_parts = 0;
   }
   if (c->g_valid) return PMF_OK;
+  c->g_parts = 0;   // (a count left behind by an H step whose H has been replaced since: the partials in dGpart are that H's)
   dim3 grid((unsigned)(c->KP / 16), (unsigned)(c->KP / 16));
   const int ks = c->np >= 2048 && c->np % 512 == 0 ? 8 : c->np >= 512 && c->np % 256 == 0 ? 4 : 1;   // column slices (wide H)
   if (ks > 1 && c->nb == 1) {
@@ -1017,7 +1018,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_w = c->have_h = true;
-  c->g_valid = c->ps_valid = c->num_valid = c->trace_ready = false;
+  c->g_valid = c->ps_valid = c->num_valid = c->trace_ready = false; c->g_parts = 0;
   return PMF_OK;
 }
 
@@ -1308,7 +1309,7 @@ int h_step_from_ps(pmf_ctx* c) {
                        c->algo == PMF_ALGO_BNMF ? 1 : c->algo == PMF_ALGO_RNMF ? 2 : 0, (float)c->lamb_h,
                        c->k, (int)c->n);
   HIPCHK(c, hipGetLastError());
-  c->g_valid = false; c->num_valid = false;
+  c->g_valid = false; c->g_parts = 0; c->num_valid = false;
   c->ps_valid = true;    // dPS belongs to the current W (update_h never touches W)
   c->trace_ready = false;
   if (c->algo == PMF_ALGO_BNMF) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }   // bnmf.py:84-85
@@ -1855,7 +1856,7 @@ int als_update_h(pmf_ctx* c) {
   }
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
   PMFCHK(solve_nnqps(c, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, false));
-  c->g_valid = false; c->num_valid = false;
+  c->g_valid = false; c->g_parts = 0; c->num_valid = false;
   c->ps_valid = true;
   c->trace_ready = false;
   return PMF_OK;
@@ -2377,7 +2378,7 @@ int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
 int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dH, c->np, c->k, c->n, 0, seed));
-  c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;
+  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false;
   return PMF_OK;
 }
 
@@ -2420,7 +2421,7 @@ int pmf_set_h_f64(pmf_ctx* c, const double* H) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(zero_padding(c, c->dH, c->np, c->KP, c->k, c->n));
   PMFCHK(upload_rows<double>(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;
+  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false;
   return PMF_OK;
 }
 int pmf_get_h_f64(pmf_ctx* c, double* H) {
@@ -2449,7 +2450,7 @@ int pmf_set_h_f32(pmf_ctx* c, const float* H) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(zero_padding(c, c->dH, c->np, c->KP, c->k, c->n));
   PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false; c->num_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
+  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
   return PMF_OK;
 }
 int pmf_get_h_f32(pmf_ctx* c, float* H) {

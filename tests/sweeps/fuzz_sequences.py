@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Random SEQUENCES of calls on one object and on its oracle twin (the reference's semantics): factorize() with every flag
+combination, the single hooks, frobenius_norm(), new W / H assigned, W / H / data edited in place, data replaced, copies and
+pickles carried on with -- after every step W, H and ferr must agree.  What this hunts: stale device state (which of V, W, H,
+(P | S), G, the trace terms is current) after an unusual order of calls.   python3 tests/sweeps/fuzz_sequences.py [seed] [cases]"""
+import os, sys, copy, pickle, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import pymf_amd
+import oracle
+
+warnings.simplefilter("ignore")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+rs = np.random.RandomState(seed)
+bad = 0
+CLASSES = [("NMF", pymf_amd.NMF, oracle.NMFOracle, 2e-5), ("SNMF", pymf_amd.SNMF, oracle.SNMFOracle, 2e-4),
+           ("NMFALS", pymf_amd.NMFALS, oracle.NMFALSOracle, 2e-3)]
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def floor32(o, V):
+    """What float32 storage of W and H leaves of ||V - W H|| on an exact fit: rounding of the factors times their size
+    (an ill-conditioned H makes W H a difference of large terms)."""
+    return 5e-6 * max(np.linalg.norm(V), np.linalg.norm(o.W) * np.linalg.norm(o.H))
+
+
+for case in range(ncase):
+    name, cls, ocls, tol = CLASSES[int(rs.randint(len(CLASSES)))]
+    m = int(rs.choice([7, 40, 130, 600, 2100])); n = int(rs.choice([5, 64, 100, 256, 300, 520])); k = int(rs.choice([1, 3, 8, 16, 33]))
+    if name == "NMFALS":
+        k = min(k, 8, m, n)                   # (well-posed QPs: comparisons of the factors themselves need unique minimisers)
+    if name == "SNMF":
+        k = min(k, n, m)
+    V = rs.random_sample((m, n)).astype(np.float32) - (0.4 if name == "SNMF" else 0.0)
+    a, o = cls(V.copy(), num_bases=k), ocls(V.astype(np.float64), num_bases=k)
+    W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
+    a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+    log = []
+    ok = True
+    for step in range(int(rs.randint(4, 12))):
+        op = int(rs.randint(11))
+        if op <= 2:
+            kw = dict(niter=int(rs.randint(1, 6)), compute_w=bool(rs.randint(2)), compute_h=bool(rs.randint(2)), compute_err=bool(rs.randint(2)))
+            log.append("factorize(%s)" % kw)
+            a.factorize(**kw); o.factorize(**kw)
+            if kw["compute_err"]:
+                L = min(len(a.ferr), len(o.ferr))
+                same = np.allclose(a.ferr[:L], o.ferr[:L], rtol=1e-4, atol=floor32(o, V))
+                if len(a.ferr) != len(o.ferr):
+                    # the reference's test |ferr[i] - ferr[i-1]| / n < 1e-8 (nmf.py:134-139) on a fit that has become stationary
+                    # to float32 noise (an exact fit after one step at one basis): the stopping iteration is then decided by
+                    # the last digits of ferr, where float32 storage and float64 differ -- accepted only
+                    # where every step behind the common part moves ferr by less than 1e-6 of ||V|| (the float32 floor of ferr)
+                    tail = np.concatenate([np.abs(np.diff(a.ferr[L - 1:])), np.abs(np.diff(o.ferr[L - 1:])),
+                                           np.abs(a.ferr[L - 1:L] - o.ferr[L - 1:L])])
+                    same = same and tail.max() <= floor32(o, V)
+                if not same:
+                    ok = False; log.append("ferr %s vs %s" % (a.ferr, o.ferr))
+        elif op == 3:
+            log.append("update_w"); a.update_w(); o.update_w()
+        elif op == 4:
+            log.append("update_h"); a.update_h(); o.update_h()
+        elif op == 5:
+            log.append("frobenius_norm")
+            fa, fo = a.frobenius_norm(), o.frobenius_norm()
+            if abs(fa - fo) > 1e-4 * fo + floor32(o, V):      # (an exact fit leaves a float32-sized residual floor)
+                ok = False; log.append("frobenius %r vs %r" % (fa, fo))
+        elif op == 6:
+            log.append("assign W"); Wn = o.W * (1.0 + 0.1 * rs.random_sample(o.W.shape)); a.W = Wn.copy(); o.W = Wn.copy()
+        elif op == 7:
+            log.append("edit H in place"); i, j = int(rs.randint(k)), int(rs.randint(n))
+            hv = a.H; hv[i, j] = hv[i, j] * 1.5 + 0.01; o.H[i, j] = o.H[i, j] * 1.5 + 0.01
+        elif op == 8:
+            log.append("edit data in place"); i, j = int(rs.randint(m)), int(rs.randint(n))
+            a.data[i, j] += 0.25; o.data[i, j] += 0.25
+        elif op == 9:
+            log.append("replace data"); Vn = (o.data * (1.0 + 0.05 * rs.random_sample(o.data.shape))).astype(np.float32)
+            a.data = Vn.copy(); o.data = Vn.astype(np.float64)
+        else:
+            how = int(rs.randint(3))
+            log.append(["copy.copy", "copy.deepcopy", "pickle"][how])
+            a = copy.copy(a) if how == 0 else copy.deepcopy(a) if how == 1 else pickle.loads(pickle.dumps(a))
+        eW, eH = rel(a.W, o.W), rel(a.H, o.H)
+        if os.environ.get("FUZZ_VERBOSE_CASE") == str(case):
+            print("   case %d step %d: %s -> relW %.2e relH %.2e  (ctx path %s)" % (case, step, log[-1], eW, eH, getattr(getattr(a, "_ctx", None), "path_name", None)), flush=True)
+        if not (eW < tol and eH < tol):
+            ok = False; log.append("relW %.2e relH %.2e" % (eW, eH))
+        if not ok:
+            break
+    if not ok:
+        bad += 1
+        print("BAD case %d: %s %dx%d k=%d: %s" % (case, name, m, n, k, " -> ".join(log[-8:])), flush=True)
+    try:
+        a._ctx.close()
+    except Exception:
+        pass
+print("seed %d: %d cases" % (seed, ncase))
+print("bad %d" % bad)

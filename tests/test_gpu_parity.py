@@ -1289,3 +1289,30 @@ def test_snmf_failed_w_step_keeps_the_device_resident_factors(pm):
         mdl.update_w()
     assert rel_fro(mdl.W, ref.W, what="W after a failed W step = W of the last successful call") < 5e-6
     np.testing.assert_array_equal(mdl.H, Hbad)
+
+
+@pytest.mark.parametrize("shape,k", [((300, 256), 16), ((40, 64), 1), ((2100, 100), 33)])
+def test_stale_gram_partials_after_an_early_exit(pm, shape, k):
+    """Round 4 (found by tests/sweeps/fuzz_sequences.py): a free-running loop that STOPS EARLY (nmf.py:198-202) puts the host's
+    picture of G = H H^T back to "per-workgroup partial sums" (what the last H step that really ran left); a NEW H after that made
+    G invalid but left the count of partials behind, and the second ensure_gram after it summed the old H's partials over the
+    freshly computed G -- the W-only loop that followed divided by the Gram matrix of an H that no longer existed (W off by
+    16-33 % in the sweep's case).  The sequence, against the oracle."""
+    from oracle import NMFOracle
+    rs = np.random.RandomState(shape[0] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    a, o = pm.NMF(V.copy(), num_bases=k), NMFOracle(V.astype(np.float64), num_bases=k)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+    a.factorize(niter=20000, compute_w=False, compute_h=True)          # coefficients for a fixed basis, until stationary
+    assert len(a.ferr) < 20000                                         # ... an early exit
+    o.H = np.asarray(a.H, dtype=np.float64).copy()                     # (the oracle need not stop at the same iteration)
+    Hn = o.H * (1.0 + 0.5 * rs.random_sample(o.H.shape))
+    a.H = Hn.copy(); o.H = Hn.copy()
+    a.update_w(); o.update_w()
+    assert rel_fro(a.W, o.W, what="W after update_w with the new H") < 2e-6
+    Wn = o.W * (1.0 + 0.1 * rs.random_sample(o.W.shape))
+    a.W = Wn.copy(); o.W = Wn.copy()
+    a.factorize(niter=3, compute_w=True, compute_h=False, compute_err=False); o.factorize(niter=3, compute_w=True, compute_h=False, compute_err=False)
+    assert rel_fro(a.W, o.W, what="W after the W-only loop behind it") < 5e-6
+    assert rel_fro(a.H, o.H, what="H untouched") < 1e-6
