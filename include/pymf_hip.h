@@ -135,6 +135,9 @@ int pmf_get_lambda(pmf_ctx* ctx, double* lamb_w, double* lamb_h);
  * copies S (m_local x n, row-major) to the host. */
 int pmf_rnmf_update_s(pmf_ctx* ctx);
 int pmf_rnmf_get_s_f32(pmf_ctx* ctx, float* S);
+/* S [m][n] contiguous handed to a context (the reference's S is an attribute that copies and pickles of the object carry,
+ * rnmf.py:96-98; new data keeps it too: pmf_set_v_* on an RNMF context re-bases the device state D = S - data). */
+int pmf_rnmf_set_s_f32(pmf_ctx* ctx, const float* S);
 
 /* Streamed V (the `data[:, :]` idiom of nmf.py:123,129 for data that does not fit
  * in HBM: an h5py dataset, a memmap, a matrix beyond 288 GB).  NMF, BNMF, SNMF and NMFALS contexts (not RNMF: the reference's RNMF keeps S, an in-memory array of data's shape, rnmf.py:94-98); pmf_set_v_* is not

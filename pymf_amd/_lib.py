@@ -58,6 +58,7 @@ SYMBOLS = [
     ("pmf_get_lambda", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     ("pmf_rnmf_update_s", _c.c_int, [_ctx]),
     ("pmf_rnmf_get_s_f32", _c.c_int, [_ctx, _c.c_void_p]),
+    ("pmf_rnmf_set_s_f32", _c.c_int, [_ctx, _c.c_void_p]),
     ("pmf_nndsvd_init", _c.c_int, [_ctx, _c.POINTER(_c.c_int32)]),
     ("pmf_stream_begin", _c.c_int, [_ctx, _c.c_uint32, _c.c_int64]),
     ("pmf_stream_tile", _c.c_int, [_ctx, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int64]),
@@ -292,6 +293,11 @@ class Context(object):
 
     def rnmf_update_s(self):
         self._chk(self._lib.pmf_rnmf_update_s(self._h))
+
+    def rnmf_set_s(self, S):
+        S = _f32c(S)
+        assert S.shape == (self.m, self.n), (S.shape, self.m, self.n)
+        self._chk(self._lib.pmf_rnmf_set_s_f32(self._h, S.ctypes.data))
 
     def rnmf_get_s(self):
         S = np.empty((self.m, self.n), dtype=np.float32)

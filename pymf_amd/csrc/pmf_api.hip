@@ -2307,11 +2307,31 @@ int pmf_ctx_destroy(pmf_ctx* c) {
 const char* pmf_last_error(const pmf_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 const char* pmf_path_name(const pmf_ctx* c) { return c ? c->path.c_str() : ""; }
 
+// RNMF keeps D = S - data on the device (rnmf.py:102,111); the reference's S is an attribute that SURVIVES new data
+// (update_w / update_h then work on S - new data until the next update_s): around a change of V the state goes
+// D -> S = D + V_old -> D = S - V_new.
+static int rnmf_data_change_begin(pmf_ctx* c) {
+  if (c->algo != PMF_ALGO_RNMF || !c->s_valid || !c->have_v || !c->dD || !c->dV) return PMF_OK;
+  const int64_t E = c->mp * c->np;
+  hipLaunchKernelGGL(k_acc_f32, dim3(elem_grid(E / 4)), dim3(256), 0, c->stream, c->dD, c->dV, E);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+static int rnmf_data_change_end(pmf_ctx* c) {
+  if (c->algo != PMF_ALGO_RNMF || !c->s_valid || !c->dD || !c->dV) return PMF_OK;
+  const int64_t E = c->mp * c->np;
+  hipLaunchKernelGGL(k_sub_f32, dim3(elem_grid(E / 4)), dim3(256), 0, c->stream, c->dD, c->dV, E);
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
 int pmf_set_v_dense_f32(pmf_ctx* c, const float* V, int64_t ld) {
   if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(ensure_dv(c));
+  PMFCHK(rnmf_data_change_begin(c));
   PMFCHK(upload_padded(c, c->dV, c->np, V, ld, c->m, c->n));
+  PMFCHK(rnmf_data_change_end(c));
   c->have_v = true; c->v_csr = false; c->csr_dense = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
@@ -2364,7 +2384,9 @@ static int fill(pmf_ctx* c, float* X, int64_t ld, int64_t rows, int64_t cols, in
 int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(ensure_dv(c));
+  PMFCHK(rnmf_data_change_begin(c));
   PMFCHK(fill(c, c->dV, c->np, c->m, c->n, row0, seed));
+  PMFCHK(rnmf_data_change_end(c));
   c->have_v = true; c->v_csr = false; c->csr_dense = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
@@ -2433,7 +2455,9 @@ int pmf_set_v_dense_f64(pmf_ctx* c, const double* V, int64_t ld) {
   if (!c || !V || ld < c->n) return fail(c, PMF_EINVAL, "pmf_set_v_dense_f64: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(ensure_dv(c));
+  PMFCHK(rnmf_data_change_begin(c));
   PMFCHK(upload_rows<double>(c, c->dV, c->np, V, ld, c->m, c->n));
+  PMFCHK(rnmf_data_change_end(c));
   c->have_v = true; c->v_csr = false; c->csr_dense = false; c->vnorm_valid = false; c->ps_valid = false; c->num_valid = false; c->c_valid = false;
   PMFCHK(local_vnorm(c));
   return PMF_OK;
@@ -2673,6 +2697,20 @@ int pmf_rnmf_get_s_f32(pmf_ctx* c, float* S) {
   hipLaunchKernelGGL(k_add_f32, dim3(elem_grid(E / 4)), dim3(256), 0, c->stream, c->dD, c->dV, E, dS);
   HIPCHK(c, hipGetLastError());
   return download_padded(c, S, c->n, dS, c->np, c->m, c->n);
+}
+
+// The reference's S is an attribute: it travels with copies and pickles of the object (the host class hands it to the new
+// context here) -- D = S - data, as pmf_rnmf_update_s leaves it.
+int pmf_rnmf_set_s_f32(pmf_ctx* c, const float* S) {
+  PMFCHK(need(c, true, false, false));
+  if (c->algo != PMF_ALGO_RNMF || !S) return fail(c, PMF_EINVAL, "pmf_rnmf_set_s_f32: RNMF only, S must not be NULL");
+  if (!c->dD) return fail(c, PMF_EINVAL, "pmf_rnmf_set_s_f32: no device state");
+  PMFCHK(upload_padded(c, c->dD, c->np, S, c->n, c->m, c->n));
+  c->s_valid = true;
+  PMFCHK(rnmf_data_change_end(c));                 // D = S - V
+  c->ps_valid = false; c->trace_ready = false;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PMF_OK;
 }
 
 // ---- streamed V: one pass = one reference iteration over row tiles handed in by the caller ------

@@ -411,6 +411,15 @@ __global__ __launch_bounds__(256) void k_acc_f32(float* __restrict__ dst, const 
   }
 }
 
+// dst -= src (count a multiple of 4).
+__global__ __launch_bounds__(256) void k_sub_f32(float* __restrict__ dst, const float* __restrict__ src, int64_t count) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; 4 * q < count; q += (int64_t)gridDim.x * 256) {
+    f32x4 d = reinterpret_cast<f32x4*>(dst)[q];
+    d -= reinterpret_cast<const f32x4*>(src)[q];
+    reinterpret_cast<f32x4*>(dst)[q] = d;
+  }
+}
+
 // Den[r][j] = sum_i W[r][i] G[i][j] for a [rows][KP] W (KP <= 128): the small second product of the W rules where the
 // first one (V H^T over very many columns) was formed in chunks and the rule is applied element by element (k_nmf_w_elem).
 __global__ __launch_bounds__(256) void k_den_small(const float* __restrict__ W, const float* __restrict__ G, float* __restrict__ Den,

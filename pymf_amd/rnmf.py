@@ -38,6 +38,25 @@ class RNMF(NMF):
             raise AttributeError("'RNMF' object has no attribute 'S'")   # rnmf.py: S is created by update_s
         return self._sync_to_device().rnmf_get_s()
 
+    # The reference's S is an attribute: a copy or a pickle of the object carries it, and new `data` leaves it as it is
+    # (update_w / update_h then work on S - new data until the next update_s).  Here S lives on the device as D = S - data:
+    # a new V re-bases D inside pmf_set_v_* (no host traffic); a copy takes S along as a host array and hands it to its own
+    # context the first time that context is used.
+    def __getstate__(self):
+        S = self.S if (self._has_s and self._ctx is not None) else self.__dict__.get("_s_host")
+        st = NMF.__getstate__(self)
+        st["_s_host"] = S
+        return st
+
+    def _sync_to_device_timed(self, ctx, with_data):
+        ctx = NMF._sync_to_device_timed(self, ctx, True if self.__dict__.get("_s_host") is not None else with_data)
+        S = self.__dict__.get("_s_host")
+        if S is not None:                                       # a context that has not seen this object's S yet
+            self._push_lambda()
+            ctx.rnmf_set_s(S)
+            self._s_host = None
+        return ctx
+
     def init_h(self):                                           # rnmf.py:84-94
         # the reference draws a random H and overwrites it with ones (rnmf.py:85-86): the draw is kept
         # so that the global NumPy stream stays where the reference leaves it

@@ -15,8 +15,13 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rs = np.random.RandomState(seed)
 bad = 0
+from pymf_amd.bnmf import BNMF
+from pymf_amd.rnmf import RNMF
 CLASSES = [("NMF", pymf_amd.NMF, oracle.NMFOracle, 2e-5), ("SNMF", pymf_amd.SNMF, oracle.SNMFOracle, 2e-4),
-           ("NMFALS", pymf_amd.NMFALS, oracle.NMFALSOracle, 2e-3)]
+           ("NMFALS", pymf_amd.NMFALS, oracle.NMFALSOracle, 2e-3), ("BNMF", BNMF, oracle.BNMFOracle, 5e-5),
+           ("RNMF", RNMF, oracle.RNMFOracle, 2e-3)]
+if os.environ.get("FUZZ_CLASSES"):
+    CLASSES = [c for c in CLASSES if c[0] in os.environ["FUZZ_CLASSES"].split(",")]
 
 
 def rel(a, b):
@@ -37,11 +42,26 @@ for case in range(ncase):
     if name == "SNMF":
         k = min(k, n, m)
     V = rs.random_sample((m, n)).astype(np.float32) - (0.4 if name == "SNMF" else 0.0)
-    a, o = cls(V.copy(), num_bases=k), ocls(V.astype(np.float64), num_bases=k)
-    W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
-    a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+    if name == "BNMF":
+        V = (V < 0.35).astype(np.float32)
+    kwc = {"lamb": 0.7} if name == "RNMF" else {}
+    a, o = cls(V.copy(), num_bases=k, **kwc), ocls(V.astype(np.float64), num_bases=k, **kwc)
     log = []
     ok = True
+    if name in ("BNMF", "RNMF"):
+        # their hooks need what factorize() sets up (the penalty schedule, bnmf.py:118-119; S, rnmf.py:84-98): one call first
+        kw = dict(niter=int(rs.randint(1, 5)))
+        sd = int(rs.randint(1 << 30))
+        if name == "RNMF":                    # init_w / init_h are part of the algorithm: same seed, same stream
+            np.random.seed(sd); o.factorize(**kw); np.random.seed(sd); a.factorize(**kw)
+        else:
+            W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
+            a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+            a.factorize(**kw); o.factorize(**kw)
+        log.append("factorize(%s)" % kw)
+    else:
+        W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
+        a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
     for step in range(int(rs.randint(4, 12))):
         op = int(rs.randint(11))
         if op <= 2:
@@ -59,6 +79,14 @@ for case in range(ncase):
                     tail = np.concatenate([np.abs(np.diff(a.ferr[L - 1:])), np.abs(np.diff(o.ferr[L - 1:])),
                                            np.abs(a.ferr[L - 1:L] - o.ferr[L - 1:L])])
                     same = same and tail.max() <= floor32(o, V)
+                    if same:
+                        # the two went on for a different number of (stationary) steps: what follows needs the same state --
+                        # the factors (equal to float32 noise) and, BNMF, the penalty schedule that advanced with every H step
+                        o.W, o.H = np.array(a.W, dtype=np.float64), np.array(a.H, dtype=np.float64)
+                        if name == "BNMF":
+                            o._lamb_W, o._lamb_H = a._lamb_W, a._lamb_H
+                        if name == "RNMF":
+                            o.S = np.array(a.S, dtype=np.float64)
                 if not same:
                     ok = False; log.append("ferr %s vs %s" % (a.ferr, o.ferr))
         elif op == 3:

@@ -77,3 +77,39 @@ def test_rnmf_fused_shapes_vs_oracle(pm, shape, k):
     o.factorize(niter=3)
     close(mdl.ferr, o.ferr, rtol=1e-7, what="mdl.ferr")
     assert rel_fro(mdl.W, o.W, what="mdl.W") < 2e-5 and rel_fro(mdl.H, o.H, what="mdl.H") < 8e-7
+
+
+def test_s_survives_new_data_and_copies(pm):
+    """Round 4 (found by tests/sweeps/fuzz_sequences.py): the reference's S is an ATTRIBUTE (rnmf.py:96-98) -- it stays as it is
+    when `data` is replaced or edited (update_w / update_h then work on S - new data, rnmf.py:102,111) and it travels with copies
+    and pickles.  The device keeps D = S - data: a new V used to leave the old D in place (silently the old data), a copy's
+    fresh context had no S at all ("S does not exist yet")."""
+    import copy, pickle
+    from oracle import RNMFOracle
+    from pymf_amd.rnmf import RNMF
+    rs = np.random.RandomState(12)
+    V = rs.random_sample((300, 200)).astype(np.float32)
+    V.flat[rs.randint(0, V.size, size=V.size // 100)] += 4.0
+    a, o = RNMF(V.copy(), num_bases=8, lamb=0.7), RNMFOracle(V.astype(np.float64), num_bases=8, lamb=0.7)
+    np.random.seed(3); o.factorize(niter=3)
+    np.random.seed(3); a.factorize(niter=3)
+    # new data, S kept
+    Vn = (V * (1.0 + 0.05 * rs.random_sample(V.shape))).astype(np.float32)
+    a.data = Vn.copy(); o.data = Vn.astype(np.float64)
+    a.update_w(); o.update_w()
+    assert rel_fro(a.W, o.W, what="W after update_w on new data with the old S") < 1e-3
+    assert rel_fro(a.S, o.S, what="S unchanged by new data") < 1e-5
+    a.update_h(); o.update_h()
+    assert rel_fro(a.H, o.H, what="H after update_h on new data") < 1e-4
+    # copies carry S
+    for how in (copy.copy, copy.deepcopy, lambda x: pickle.loads(pickle.dumps(x))):
+        b = how(a)
+        assert rel_fro(b.S, o.S, what="S of a copy") < 1e-5
+        oc = copy.deepcopy(o)
+        b.update_w(); oc.update_w()
+        assert rel_fro(b.W, oc.W, what="a copy's update_w") < 1e-3
+        b.factorize(niter=2); oc.factorize(niter=2)
+        # (soft thresholding is discontinuous: entries of the residual next to +-lamb fall on different sides in float32 and
+        # float64, and every further iteration spreads that -- the reason RNMF's tolerances are what they are, DESIGN section 4)
+        assert rel_fro(b.H, oc.H, what="a copy's factorize") < 5e-2
+        close(b.ferr, oc.ferr, rtol=2e-3, what="a copy's ferr")
