@@ -1071,17 +1071,18 @@ int launch_resid(pmf_ctx* c, bool rnmf, float lamb, const float* V = nullptr, co
 }
 
 // num_bases > 128: sum((V - W H)^2) over this rank's rows -> *dst (device), plain-FMA tiles; rnmf: D = S - V too
-int resid_bigk(pmf_ctx* c, bool rnmf, double* dst) {
-  const int gx = c->np / 64, gy = (int)(c->mp / 64);
+int resid_bigk(pmf_ctx* c, bool rnmf, double* dst, const float* V = nullptr, const float* W = nullptr, int64_t rows_p = 0) {
+  if (!V) { V = c->dV; W = c->dW; rows_p = c->mp; }      // (a row tile of a streamed pass otherwise)
+  const int gx = c->np / 64, gy = (int)(rows_p / 64);
   const int nb2 = gx * gy;
   DevTemps tmp;                       // frees `part` on every exit
   double* part = nullptr;
   PMFCHK(talloc(c, tmp, &part, (size_t)nb2));
   if (rnmf)
-    hipLaunchKernelGGL(k_resid_bigk<true>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
+    hipLaunchKernelGGL(k_resid_bigk<true>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, V, (int64_t)c->np, W,
                        c->KP, c->dH, (int64_t)c->np, part, (float)c->lamb_w, c->dD);
   else
-    hipLaunchKernelGGL(k_resid_bigk<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, c->dV, (int64_t)c->np, c->dW,
+    hipLaunchKernelGGL(k_resid_bigk<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, V, (int64_t)c->np, W,
                        c->KP, c->dH, (int64_t)c->np, part, 0.f, (float*)nullptr);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, part, nb2, dst);
@@ -2783,9 +2784,13 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
   float* Wt = c->dW + row0 * c->KP;
   const int first = c->st_tiles == 0;
   if (c->st_flags & PMF_STREAM_RESID) {
-    PMFCHK(launch_resid(c, false, 0.f, T, Wt, rows_p));
-    hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, c->resid_parts, c->dScal + 5);
-    HIPCHK(c, hipGetLastError());
+    if (c->nb > 1) {            // num_bases > 128: launch_resid's kernels end at 128 bases (found by tests/sweeps/fuzz_sequences.py)
+      PMFCHK(resid_bigk(c, false, c->dScal + 5, T, Wt, rows_p));
+    } else {
+      PMFCHK(launch_resid(c, false, 0.f, T, Wt, rows_p));
+      hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, c->resid_parts, c->dScal + 5);
+      HIPCHK(c, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_accum_f64, dim3(1), dim3(64), 0, c->stream, c->dStAcc + 1, c->dScal + 5, first);
     HIPCHK(c, hipGetLastError());
   } else {

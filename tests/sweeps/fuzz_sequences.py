@@ -6,9 +6,11 @@ pickles carried on with -- after every step W, H and ferr must agree.  What this
 import os, sys, copy, pickle, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+import logging
 import numpy as np
 import pymf_amd
 import oracle
+logging.disable(logging.CRITICAL)
 
 warnings.simplefilter("ignore")
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -36,16 +38,32 @@ def floor32(o, V):
 
 for case in range(ncase):
     name, cls, ocls, tol = CLASSES[int(rs.randint(len(CLASSES)))]
-    m = int(rs.choice([7, 40, 130, 600, 2100])); n = int(rs.choice([5, 64, 100, 256, 300, 520])); k = int(rs.choice([1, 3, 8, 16, 33]))
+    m = int(rs.choice([7, 40, 130, 600, 2100])); n = int(rs.choice([5, 64, 100, 256, 300, 520])); k = int(rs.choice([1, 3, 8, 16, 33, 33, 64, 100, 130]))
     if name == "NMFALS":
         k = min(k, 8, m, n)                   # (well-posed QPs: comparisons of the factors themselves need unique minimisers)
     if name == "SNMF":
-        k = min(k, n, m)
+        k = max(1, min(k, n // 2, m))         # (k = n makes every invertible H an exact fit and inv(H H^T) a float32 conditioning test)
     V = rs.random_sample((m, n)).astype(np.float32) - (0.4 if name == "SNMF" else 0.0)
     if name == "BNMF":
         V = (V < 0.35).astype(np.float32)
     kwc = {"lamb": 0.7} if name == "RNMF" else {}
-    a, o = cls(V.copy(), num_bases=k, **kwc), ocls(V.astype(np.float64), num_bases=k, **kwc)
+    variant = []
+    use_cls = cls
+    if rs.randint(4) == 0:                    # a subclass that overrides a hook: factorize() must run the hook loop
+        class Hooked(cls):
+            def update_h(self):
+                cls.update_h(self)
+        use_cls = Hooked; variant.append("hooked")
+    sparse = name == "SNMF" and rs.randint(3) == 0
+    if sparse:
+        import scipy.sparse as sp
+        V = V * (rs.random_sample(V.shape) < 0.2)
+        variant.append("csr")
+    a, o = use_cls(sp.csr_matrix(V) if sparse else V.copy(), num_bases=k, **kwc), ocls(V.astype(np.float64), num_bases=k, **kwc)
+    if name != "RNMF" and not sparse and rs.randint(4) == 0:
+        a.stream_rows = int(rs.choice([64, 256])); variant.append("stream_rows=%d" % a.stream_rows)
+    if rs.randint(5) == 0:
+        a.eager_factors = True; variant.append("eager")
     log = []
     ok = True
     if name in ("BNMF", "RNMF"):
@@ -66,8 +84,10 @@ for case in range(ncase):
         op = int(rs.randint(11))
         if op <= 2:
             kw = dict(niter=int(rs.randint(1, 6)), compute_w=bool(rs.randint(2)), compute_h=bool(rs.randint(2)), compute_err=bool(rs.randint(2)))
+            if sparse:
+                kw["compute_err"] = False     # (the reference's frobenius_norm() is its -123456 sentinel on sparse data; ours refuses the flag)
             log.append("factorize(%s)" % kw)
-            a.factorize(**kw); o.factorize(**kw)
+            a.factorize(show_progress=bool(rs.randint(4) == 0), **kw); o.factorize(**kw)
             if kw["compute_err"]:
                 L = min(len(a.ferr), len(o.ferr))
                 same = np.allclose(a.ferr[:L], o.ferr[:L], rtol=1e-4, atol=floor32(o, V))
@@ -96,6 +116,10 @@ for case in range(ncase):
         elif op == 5:
             log.append("frobenius_norm")
             fa, fo = a.frobenius_norm(), o.frobenius_norm()
+            if sparse:                                          # nmf.py:100-114: the sentinel
+                if fa != -123456:
+                    ok = False; log.append("frobenius on sparse data %r" % (fa,))
+                fa = fo
             if abs(fa - fo) > 1e-4 * fo + floor32(o, V):      # (an exact fit leaves a float32-sized residual floor)
                 ok = False; log.append("frobenius %r vs %r" % (fa, fo))
         elif op == 6:
@@ -105,10 +129,15 @@ for case in range(ncase):
             hv = a.H; hv[i, j] = hv[i, j] * 1.5 + 0.01; o.H[i, j] = o.H[i, j] * 1.5 + 0.01
         elif op == 8:
             log.append("edit data in place"); i, j = int(rs.randint(m)), int(rs.randint(n))
-            a.data[i, j] += 0.25; o.data[i, j] += 0.25
+            if sparse:
+                if a.data.nnz:
+                    q = int(rs.randint(a.data.nnz)); a.data.data[q] += 0.25
+                    o.data = np.asarray(a.data.todense(), dtype=np.float64)
+            else:
+                a.data[i, j] += 0.25; o.data[i, j] += 0.25
         elif op == 9:
             log.append("replace data"); Vn = (o.data * (1.0 + 0.05 * rs.random_sample(o.data.shape))).astype(np.float32)
-            a.data = Vn.copy(); o.data = Vn.astype(np.float64)
+            a.data = sp.csr_matrix(Vn) if sparse else Vn.copy(); o.data = Vn.astype(np.float64)
         else:
             how = int(rs.randint(3))
             log.append(["copy.copy", "copy.deepcopy", "pickle"][how])
@@ -122,7 +151,7 @@ for case in range(ncase):
             break
     if not ok:
         bad += 1
-        print("BAD case %d: %s %dx%d k=%d: %s" % (case, name, m, n, k, " -> ".join(log[-8:])), flush=True)
+        print("BAD case %d: %s %s %dx%d k=%d: %s" % (case, name, variant, m, n, k, " -> ".join(log[-8:])), flush=True)
     try:
         a._ctx.close()
     except Exception:

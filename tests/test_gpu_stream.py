@@ -273,3 +273,27 @@ def test_first_call_timings_are_reported():
     assert set(t) >= {"ctx", "init", "upload", "loop", "total"} and t["total"] >= t["loop"] > 0.0 and t["upload"] > 0.0
     mdl.factorize(niter=3, compute_err=False)
     assert "ctx" not in mdl.last_call_ms or mdl.last_call_ms["ctx"] == 0.0            # the context exists already
+
+
+@pytest.mark.parametrize("cls_name,shape,k,rows", [("NMF", (600, 100), 130, 256), ("NMF", (600, 1100), 130, 256), ("SNMF", (600, 256), 200, 64),
+                                                    ("BNMF", (600, 256), 130, 256)])
+def test_streamed_frobenius_norm_beyond_128_bases(pm, cls_name, shape, k, rows):
+    """Round 4 (found by tests/sweeps/fuzz_sequences.py): frobenius_norm() of a streamed object -- the residual-only pass over
+    the row tiles, which a subclass that overrides a hook also runs once per iteration -- used the <= 128-base residual kernel
+    at any base count: beyond 128 bases it read W with the wrong row stride and stopped at 128 bases (5 621 for 7 828)."""
+    import oracle
+    from pymf_amd.bnmf import BNMF
+    rs = np.random.RandomState(sum(shape) + k)
+    V = rs.random_sample(shape).astype(np.float32) - (0.4 if cls_name == "SNMF" else 0.0)
+    W0, H0 = rs.random_sample((shape[0], k)), rs.random_sample((k, shape[1]))
+    cls = BNMF if cls_name == "BNMF" else getattr(pm, cls_name)
+    a = cls(V.copy(), num_bases=k)
+    a.stream_rows = rows
+    a.W, a.H = W0.copy(), H0.copy()
+    f64 = lambda W, H: float(np.linalg.norm(V.astype(np.float64) - np.asarray(W, dtype=np.float64).dot(np.asarray(H, dtype=np.float64))))
+    close(a.frobenius_norm(), f64(W0, H0), rtol=2e-6, what="streamed frobenius_norm at the start")
+    if cls_name == "BNMF":
+        a.factorize(niter=1)
+    else:
+        a.update_w(); a.update_h()
+    close(a.frobenius_norm(), f64(a.W, a.H), rtol=2e-5, what="streamed frobenius_norm after one iteration")
