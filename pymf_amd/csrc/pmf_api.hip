@@ -2360,7 +2360,9 @@ int pmf_set_v_csr_f32(pmf_ctx* c, const int64_t* indptr, const int32_t* indices,
   c->nnz = nnz; c->have_v = true; c->v_csr = true; c->vnorm_valid = false; c->vnorm_local_valid = false; c->ps_valid = false; c->num_valid = false;
   c->c_valid = false;            // V^T V for the Gram-space loop is formed on first use (k_csr_gram)
   c->csr_dense = false;
-  if (c->nb > 1) {               // num_bases > 128: no CSR kernel at that width -- the rows are expanded once
+  // num_bases > 128: no CSR kernel at that width; n * num_bases beyond the 160 KiB LDS accumulator of the CSR scatter
+  // (k_csr_p: e.g. 520 columns x 100 bases): no CSR kernel at that SIZE -- the rows are expanded once
+  if (c->nb > 1 || (size_t)c->np * c->KP * sizeof(float) > (size_t)160 * 1024) {
     PMFCHK(ensure_dv(c));
     HIPCHK(c, hipMemsetAsync(c->dV, 0, (size_t)c->mp * c->np * sizeof(float), c->stream));
     hipLaunchKernelGGL(k_csr_densify, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dIndptr, c->dIndices,

@@ -238,3 +238,20 @@ def test_nnqp_quad_frames_are_bit_identical(pm, shape, k, niter):
     assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+def test_snmf_csr_shape_beyond_the_lds_accumulator(pm):
+    """Round 4 (tests/sweeps/fuzz_sequences.py): CSR data whose n x num_bases image does not fit the 160 KiB LDS accumulator of the
+    CSR scatter (520 columns x 100 bases) used to fail in update_h ("n * num_bases too large for the LDS accumulator"); the rows are
+    expanded once on the device instead, as for > 128 bases.  Against the oracle on the dense matrix."""
+    import scipy.sparse as sp
+    from oracle import SNMFOracle
+    rs = np.random.RandomState(9)
+    V = ((rs.random_sample((600, 520)) - 0.4) * (rs.random_sample((600, 520)) < 0.2)).astype(np.float32)
+    k = 100
+    W0, H0 = rs.random_sample((600, k)), rs.random_sample((k, 520))
+    a, o = pm.SNMF(sp.csr_matrix(V), num_bases=k), SNMFOracle(V.astype(np.float64), num_bases=k)
+    a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+    a.update_w(); o.update_w(); a.update_h(); o.update_h()
+    a.factorize(niter=2, compute_err=False); o.factorize(niter=2, compute_err=False)
+    assert rel_fro(a.W, o.W, what="mdl.W") < 2e-4 and rel_fro(a.H, o.H, what="mdl.H") < 2e-5
