@@ -73,6 +73,10 @@ int pmf_nccl_unique_id(void* out);
  *             (The reference has no limit, nmf.py:116-120; beyond these PMF_EINVAL.)
  *   rank,nranks,nccl_id   RCCL world; nranks==1 -> nccl_id may be NULL and RCCL is not touched
  *                         (a non-NULL id with nranks==1 creates a 1-rank communicator)
+ *                         With nranks > 1 the ranks must agree on which cached sums are current -- they decide which
+ *                         collectives the next call runs: when ANY rank has uploaded new V, W or H (pmf_set_*), EVERY rank
+ *                         calls pmf_invalidate_v before the next update / factorize / frobenius call (the host classes
+ *                         exchange one flag per call for this, pymf_amd/nmf.py _sync_to_device).
  */
 int pmf_ctx_create(pmf_ctx** out, int32_t algo, int64_t m_local, int64_t n, int32_t k,
                    int32_t device, int32_t rank, int32_t nranks, const void* nccl_id);

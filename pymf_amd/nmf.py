@@ -243,6 +243,7 @@ class NMF(object):
             fp = tuple(_fingerprint(x) for x in (csr.indptr, csr.indices, csr.data)) if self.check_data else None
             if same_obj and fp == self._v_fp:
                 return
+            self._uploaded = True
             self._upload_sparse(ctx)
         else:
             arr = np.asarray(self.data[:, :])                   # data[:,:] idiom, nmf.py:123,129
@@ -250,6 +251,7 @@ class NMF(object):
             fp = _fingerprint(arr) if self.check_data else None
             if same_obj and fp == self._v_fp:
                 return
+            self._uploaded = True
             ctx.set_v_dense(arr)
         self._v_src = self.data
         self._v_fp = fp
@@ -293,7 +295,16 @@ class NMF(object):
         ctx = self._context()
         t0 = time.perf_counter()
         try:
-            return self._sync_to_device_timed(ctx, with_data)
+            self._uploaded = False
+            ctx = self._sync_to_device_timed(ctx, with_data)
+            if self._world().size > 1:
+                # Which cached sums are current ((W^T V | W^T W), ||V||^2, the trace terms) decides which COLLECTIVES the next
+                # call runs -- and a rank whose rows were not touched keeps its caches when another rank's data or W rows were
+                # edited: the ranks would then disagree about the next all-reduce (one waits for a peer that never comes).
+                # So the ranks agree here: if anything was uploaded anywhere, everybody drops the derived state.
+                if _dist.allreduce_sum_array(np.array([1.0 if self._uploaded else 0.0]))[0] > 0:
+                    ctx.invalidate_v()
+            return ctx
         finally:
             self._tick("upload", t0)
 
@@ -303,6 +314,7 @@ class NMF(object):
             self._loop_data_checked = True
             if self._stream_rows():
                 if self._v_src is not self.data or self.check_data:
+                    self._uploaded = True
                     ctx.invalidate_v()            # streamed data is re-read every pass; ||V||^2 with it
                     self._v_src = self.data
             else:
@@ -321,6 +333,7 @@ class NMF(object):
                 raise TypeError("%s must be a floating-point array" % name)
             fp = _fingerprint(arr)
             if getattr(self, fp_attr) != fp:
+                self._uploaded = True
                 setter(arr)
                 setattr(self, fp_attr, fp)
             del arr

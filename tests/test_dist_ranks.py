@@ -200,3 +200,13 @@ def test_class_level_multi_rank_path_over_rccl():
     if _lib.device_count() < 2:
         pytest.skip("needs >= 2 GPUs: one RCCL rank per GPU")
     _spawn_workers("_dist_class_worker.py", 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,transport,seed", [(2, "ipc", 1), (2, "host", 2), (3, "ipc", 3)])
+def test_random_call_sequences_under_a_multi_rank_world(size, transport, seed):
+    """Round 4: the call-sequence sweep (tests/sweeps/fuzz_sequences.py found three stale-state bugs at one rank) with the rows
+    sharded over processes that share GPU 0: factorize() with every flag combination, the hooks, frobenius_norm(), W / H / data
+    edits -- gathered W, the replicated H (bit-identical across the ranks) and ferr against the unsharded oracle after every step."""
+    _spawn_workers("_dist_sequence_worker.py", size, extra_args=["--seed", str(seed), "--cases", "14"],
+                   extra_env={"PYMF_DIST_TRANSPORT": transport, "LOCAL_RANK": "0"})
