@@ -2,7 +2,9 @@
 multi-rank world) on row-sharded objects, against the UNSHARDED oracle twin.  Every rank draws the same sequence from the same
 seed; the calls that sum over the ranks (factorize, update_h, frobenius_norm) are collective by construction, the others are
 local.  argv: [--seed S] [--cases C].  The ranks may share a GPU (PYMF_DIST_TRANSPORT = host | ipc)."""
+import copy
 import os
+import pickle
 import sys
 import warnings
 import logging
@@ -52,7 +54,15 @@ def main():
         if name == "BNMF":
             V = (V < 0.35).astype(np.float32)
         lo, hi = w.row_range(m)
-        a, o = cls(V[lo:hi].copy(), num_bases=k), ocls(V.astype(np.float64), num_bases=k)
+        use_cls, variant = cls, []
+        if rs.randint(4) == 0:                # a subclass that overrides a hook: factorize() runs the hook loop
+            class Hooked(cls):
+                def update_h(self):
+                    cls.update_h(self)
+            use_cls = Hooked; variant.append("hooked")
+        a, o = use_cls(V[lo:hi].copy(), num_bases=k), ocls(V.astype(np.float64), num_bases=k)
+        if rs.randint(4) == 0:
+            a.stream_rows = int(rs.choice([64, 256])); variant.append("stream_rows=%d" % a.stream_rows)
         W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
         a.W, a.H = W0[lo:hi].copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
         log, ok = [], True
@@ -60,7 +70,7 @@ def main():
             kw = dict(niter=int(rs.randint(1, 5)))
             a.factorize(**kw); o.factorize(**kw); log.append("factorize(%s)" % kw)
         for step in range(int(rs.randint(4, 10))):
-            op = int(rs.randint(9))
+            op = int(rs.randint(11))
             if op <= 2:
                 kw = dict(niter=int(rs.randint(1, 6)), compute_w=bool(rs.randint(2)), compute_h=bool(rs.randint(2)), compute_err=bool(rs.randint(2)))
                 log.append("factorize(%s)" % kw)
@@ -95,11 +105,20 @@ def main():
             elif op == 7:
                 log.append("edit H in place"); i, j = int(rs.randint(k)), int(rs.randint(n))
                 hv = a.H; hv[i, j] = hv[i, j] * 1.5 + 0.01; o.H[i, j] = o.H[i, j] * 1.5 + 0.01
-            else:
+            elif op == 8:
                 log.append("edit data in place"); i, j = int(rs.randint(m)), int(rs.randint(n))
                 if lo <= i < hi:
                     a.data[i - lo, j] += 0.25
                 o.data[i, j] += 0.25
+            elif op == 9:
+                log.append("replace data"); Vn = (o.data * (1.0 + 0.05 * rs.random_sample(o.data.shape))).astype(np.float32)
+                a.data = Vn[lo:hi].copy(); o.data = Vn.astype(np.float64)
+            else:
+                how = int(rs.randint(3))
+                if "hooked" in variant and how == 2:
+                    how = 1                   # (a class defined inside a function does not pickle)
+                log.append(["copy.copy", "copy.deepcopy", "pickle"][how])
+                a = copy.copy(a) if how == 0 else copy.deepcopy(a) if how == 1 else pickle.loads(pickle.dumps(a))
             eW, eH = rel(gather_rows(a.W), o.W), rel(a.H, o.H)
             hs = dist.allgather_bytes(np.ascontiguousarray(a.H).tobytes())
             if not all(h == hs[0] for h in hs):
@@ -112,7 +131,7 @@ def main():
                 break
         if not ok:
             bad += 1
-            print("rank %d BAD case %d: %s %dx%d k=%d: %s" % (w.rank, case, name, m, n, k, " -> ".join(log[-8:])), flush=True)
+            print("rank %d BAD case %d: %s %s %dx%d k=%d: %s" % (w.rank, case, name, variant, m, n, k, " -> ".join(log[-8:])), flush=True)
         try:
             a._ctx.close()
         except Exception:
