@@ -42,7 +42,7 @@ for case in range(ncase):
     if name == "NMFALS":
         k = min(k, 8, m, n)                   # (well-posed QPs: comparisons of the factors themselves need unique minimisers)
     if name == "SNMF":
-        k = max(1, min(k, n // 2, m))         # (k = n makes every invertible H an exact fit and inv(H H^T) a float32 conditioning test)
+        k = max(1, min(k, n // 2, m // 2))    # (k = n or k = m makes every invertible factor an exact fit and the inverse a float32 conditioning test)
     V = rs.random_sample((m, n)).astype(np.float32) - (0.4 if name == "SNMF" else 0.0)
     if name == "BNMF":
         V = (V < 0.35).astype(np.float32)
@@ -81,9 +81,22 @@ for case in range(ncase):
         W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
         a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
     for step in range(int(rs.randint(4, 12))):
-        op = int(rs.randint(11))
-        if op <= 2:
+        op = int(rs.randint(12))
+        if op == 11:
+            # a tuning knob flipped in mid-life: every setting must give the reference's numbers, and no cached state of the
+            # other setting (Gram-space images, cached V H^T, slabs of another layout) may leak into the next call
+            name_o, val = [("force_tiled", int(rs.randint(2))), ("snmf_gram", int(rs.randint(3))), ("rowgemm_stream", int(rs.randint(2))),
+                           ("colgemm_stream", int(rs.randint(2))), ("nnqp_quad", int(rs.randint(3))), ("nnqp_frame16", int(rs.randint(2))),
+                           ("snmf_w_pipe", int(rs.choice([0, 32])))][int(rs.randint(7))]
+            log.append("set_option(%s=%d)" % (name_o, val))
+            a._context().set_option(name_o, val)
+        elif op <= 2:
             kw = dict(niter=int(rs.randint(1, 6)), compute_w=bool(rs.randint(2)), compute_h=bool(rs.randint(2)), compute_err=bool(rs.randint(2)))
+            if rs.randint(6) == 0 and name != "NMFALS":
+                # beyond one chunk of the free-running loops (32 iterations).  BNMF stays at 34: its penalty grows by 1.1 per
+                # iteration (1.1^130 = 2.4e5), entries driven to 0 UNDERFLOW in float32 where float64 keeps 1e-50s, and the
+                # rules' 1e-9 lets those regrow by 1e10 per iteration once the penalty is reset -- a float32 range effect
+                kw["niter"] = 34 if name == "BNMF" else int(rs.choice([34, 70, 130]))
             if sparse:
                 kw["compute_err"] = False     # (the reference's frobenius_norm() is its -123456 sentinel on sparse data; ours refuses the flag)
             log.append("factorize(%s)" % kw)
