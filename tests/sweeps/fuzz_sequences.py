@@ -39,6 +39,9 @@ def floor32(o, V):
 for case in range(ncase):
     name, cls, ocls, tol = CLASSES[int(rs.randint(len(CLASSES)))]
     m = int(rs.choice([7, 40, 130, 600, 2100])); n = int(rs.choice([5, 64, 100, 256, 300, 520])); k = int(rs.choice([1, 3, 8, 16, 33, 33, 64, 100, 130]))
+    if rs.randint(8) == 0:                    # every CU busy, several blocks per wave; or several column panels on the two-pass kernels
+        m, n = (70000, int(rs.choice([128, 256]))) if rs.randint(2) else (3000, 1100)
+        k = min(k, 64)
     if name == "NMFALS":
         k = min(k, 8, m, n)                   # (well-posed QPs: comparisons of the factors themselves need unique minimisers)
     if name == "SNMF":
