@@ -84,8 +84,32 @@ for case in range(ncase):
         W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
         a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
     for step in range(int(rs.randint(4, 12))):
-        op = int(rs.randint(12))
-        if op == 11:
+        op = int(rs.randint(13))
+        if op == 12 and name != "SNMF":
+            op = 3
+        if op == 12:
+            # a failing call in mid-life: a zero row of H makes H H^T exactly singular -- np.linalg.inv raises in the reference
+            # (snmf.py:69), the library raises the same; W must be what it was, and with H repaired everything goes on
+            log.append("singular H: update_w must raise, then repair")
+            Hs_a, Hs_o = np.array(a.H), o.H.copy()
+            r = int(rs.randint(k))
+            Hz = Hs_o.copy(); Hz[r] = 0.0
+            a.H = Hz.copy(); o.H = Hz.copy()
+            Wb = np.array(a.W)
+            errs = []
+            for obj in (a, o):
+                try:
+                    obj.update_w(); errs.append(None)
+                except Exception as e:
+                    errs.append(type(e).__name__)
+            if errs[0] != errs[1]:
+                ok = False; log.append("exceptions %s vs %s" % (errs[0], errs[1]))
+            elif errs[1] is not None and rel(a.W, Wb) > 0:
+                ok = False; log.append("W changed by the failed call")
+            a.H = Hs_o.copy(); o.H = Hs_o.copy()
+            if errs[1] is None:               # (inv() got through on a numerically singular matrix: W is garbage on both sides)
+                a.W = Wb.copy(); o.W = Wb.astype(np.float64).copy()
+        elif op == 11:
             # a tuning knob flipped in mid-life: every setting must give the reference's numbers, and no cached state of the
             # other setting (Gram-space images, cached V H^T, slabs of another layout) may leak into the next call
             name_o, val = [("force_tiled", int(rs.randint(2))), ("snmf_gram", int(rs.randint(3))), ("rowgemm_stream", int(rs.randint(2))),
@@ -100,6 +124,10 @@ for case in range(ncase):
                 # iteration (1.1^130 = 2.4e5), entries driven to 0 UNDERFLOW in float32 where float64 keeps 1e-50s, and the
                 # rules' 1e-9 lets those regrow by 1e10 per iteration once the penalty is reset -- a float32 range effect
                 kw["niter"] = 34 if name == "BNMF" else int(rs.choice([34, 70, 130]))
+                # (sensitivity to the float32 STORAGE of the factors grows with the iteration count: seed 801 / case 40 of the SNMF
+                # sweep -- 7 x 256, 3 bases, 130 iterations -- ends 8.75e-4 / 3.08e-3 from the float64 oracle, and the oracle
+                # with its factors rounded to float32 after every update ends at exactly the same distance)
+                tol = max(tol, 20 * CLASSES[[c[0] for c in CLASSES].index(name)][3])
             if sparse:
                 kw["compute_err"] = False     # (the reference's frobenius_norm() is its -123456 sentinel on sparse data; ours refuses the flag)
             log.append("factorize(%s)" % kw)
@@ -167,6 +195,9 @@ for case in range(ncase):
             ok = False; log.append("relW %.2e relH %.2e" % (eW, eH))
         if not ok:
             break
+    if not ok and os.environ.get("FUZZ_DUMP_DIR"):
+        np.savez(os.path.join(os.environ["FUZZ_DUMP_DIR"], "fuzz_seq_seed%d_case%d.npz" % (seed, case)), V=V, W0=W0 if "W0" in dir() else 0,
+                 H0=H0 if "H0" in dir() else 0, log=np.array(log, dtype=object).astype(str), name=name, k=k, variant=np.array(variant).astype(str))
     if not ok:
         bad += 1
         print("BAD case %d: %s %s %dx%d k=%d: %s" % (case, name, variant, m, n, k, " -> ".join(log[-8:])), flush=True)

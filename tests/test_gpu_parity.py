@@ -3,6 +3,8 @@
 Tolerances (float32 device arithmetic vs the float64-default reference):
   ||X_gpu - X_ref||_F / ||X_ref||_F <= 2e-5 for X in {W, H};  |ferr_gpu - ferr_ref|/ferr_ref <= 1e-5.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1316,3 +1318,29 @@ def test_stale_gram_partials_after_an_early_exit(pm, shape, k):
     a.factorize(niter=3, compute_w=True, compute_h=False, compute_err=False); o.factorize(niter=3, compute_w=True, compute_h=False, compute_err=False)
     assert rel_fro(a.W, o.W, what="W after the W-only loop behind it") < 5e-6
     assert rel_fro(a.H, o.H, what="H untouched") < 1e-6
+
+
+def test_long_run_equals_the_reference_arithmetic_on_float32_stored_factors(pm):
+    """Round 4 (tests/sweeps/fuzz_sequences.py, seed 801 / case 40): 130 SNMF iterations on a 7 x 256 matrix end 8.8e-4 (W) / 3.1e-3 (H)
+    from the float64 oracle -- and the oracle ITSELF ends at exactly that distance when its factors are rounded to float32 after every
+    update.  So the comparison that says something after many iterations on a storage-sensitive problem is against the reference's
+    arithmetic on float32-STORED factors (what north_star sanctions): there the library agrees to 1e-5.
+    The inputs are the sweep's (tests/golden/snmf_storage_sensitive_7x256_k3.npz: data only)."""
+    from oracle import SNMFOracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snmf_storage_sensitive_7x256_k3.npz"))
+    V, W0, H0, k = g["V"], g["W0"], g["H0"], int(g["k"])
+    a = pm.SNMF(V.copy(), num_bases=k)
+    a.W, a.H = W0.copy(), H0.copy()
+    a.factorize(niter=130, compute_err=False)
+    exact, stored = SNMFOracle(V.astype(np.float64), num_bases=k), SNMFOracle(V.astype(np.float64), num_bases=k)
+    for o in (exact, stored):
+        o.W, o.H = W0.copy(), H0.copy()
+    for _ in range(130):
+        exact.update_w(); exact.update_h()
+        stored.update_w(); stored.W = stored.W.astype(np.float32).astype(np.float64)
+        stored.update_h(); stored.H = stored.H.astype(np.float32).astype(np.float64)
+    # the float64 oracle and its float32-stored twin have drifted apart by about 1e-3 ...
+    assert 1e-4 < np.linalg.norm(stored.W - exact.W) / np.linalg.norm(exact.W) < 1e-2
+    # ... and the library is where the float32-stored twin is
+    assert rel_fro(a.W, stored.W, what="W vs the oracle on float32-stored factors, 130 iterations") < 1e-5
+    assert rel_fro(a.H, stored.H, what="H vs the oracle on float32-stored factors, 130 iterations") < 1e-5
