@@ -2776,7 +2776,15 @@ int pmf_stream_tile(pmf_ctx* c, int64_t row0, int64_t rows, const float* tile, i
   const int b = c->st_tiles & 1;
   const int64_t rows_p = round_up(rows, 64);
   float* T = c->dTile[b];
-  if (c->st_tiles >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_consumed[b], 0));
+  if (c->st_tiles >= 2) {
+    // The copy below is enqueued BEHIND the consumer of this buffer's previous tile and reads the caller's memory when it
+    // runs, not now: without a bound the host gets many tiles ahead of the device and a caller that hands over temporaries
+    // (a float64 or strided `data` converted tile by tile) frees them long before they are read -- garbage tiles, NaN factors
+    // (found by tests/sweeps/fuzz_sequences.py).  Waiting here for the COPY of the tile two calls back bounds the host's lead
+    // to the two device tiles: a caller's tile must stay valid until the second-next call (or pmf_stream_end) has returned.
+    HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_consumed[b], 0));
+  }
   HIPCHK(c, hipMemcpy2DAsync(T, (size_t)c->np * sizeof(float), tile, (size_t)ld * sizeof(float),
                              (size_t)c->n * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, c->copy_stream));
   if (rows_p > rows)

@@ -297,3 +297,31 @@ def test_streamed_frobenius_norm_beyond_128_bases(pm, cls_name, shape, k, rows):
     else:
         a.update_w(); a.update_h()
     close(a.frobenius_norm(), f64(a.W, a.H), rtol=2e-5, what="streamed frobenius_norm after one iteration")
+
+
+@pytest.mark.parametrize("cls_name", ["NMF", "NMFALS", "SNMF"])
+@pytest.mark.parametrize("layout", ["C float64", "F float32", "strided float32"])
+def test_streamed_tiles_converted_on_the_fly(pm, cls_name, layout):
+    """Round 4 (found by tests/sweeps/fuzz_sequences.py): `data` that is float64, Fortran-ordered or a strided view reaches
+    pmf_stream_tile as a TEMPORARY float32 copy per tile.  The tile's host-to-device copy is enqueued behind the consumer of the
+    device buffer's previous tile and read the host memory when it ran -- with the host many tiles ahead, long after the binding's
+    three-deep keep-alive had let the temporary go: NaN / 1e17 factors (float32 C-ordered data, a view of the caller's array, was
+    never affected).  pmf_stream_tile now waits for the copy of the tile two calls back, which makes the documented lifetime
+    (valid until the next but one call) sufficient."""
+    import oracle
+    m, n, k = 3000, 300, 4
+    rs = np.random.RandomState(1)
+    Vn = rs.random_sample((m, n)).astype(np.float32) - (0.4 if cls_name == "SNMF" else 0.0)
+    Vd = {"C float64": Vn.astype(np.float64), "F float32": np.asfortranarray(Vn), "strided float32": np.repeat(Vn, 2, axis=1)[:, ::2]}[layout]
+    W0, H0 = rs.random_sample((m, k)), rs.random_sample((k, n))
+    a, o = getattr(pm, cls_name)(Vd, num_bases=k), getattr(oracle, cls_name + "Oracle")(Vn.astype(np.float64), num_bases=k)
+    a.stream_rows = 64
+    a.W, a.H = W0.copy(), H0.copy(); o.W, o.H = W0.copy(), H0.copy()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a.factorize(niter=3)
+    o.factorize(niter=3)
+    tol = 2e-5 if cls_name != "NMFALS" else 1e-4
+    assert rel_fro(a.W, o.W, what="mdl.W") < tol and rel_fro(a.H, o.H, what="mdl.H") < tol
+    close(a.ferr, o.ferr, rtol=1e-5, what="mdl.ferr")
