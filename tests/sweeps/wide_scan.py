@@ -10,8 +10,11 @@ import oracle
 from test_gpu_parity import _synthetic_rows
 
 bad = 0
-for (algo, name, mw, nw, k) in ((_lib.ALGO_NMF, "NMF", 1024, 32768, 16), (_lib.ALGO_NMF, "NMF", 1024, 65536, 16), (_lib.ALGO_NMF, "NMF", 1024, 131072, 16),
-                                (_lib.ALGO_NMF, "NMF", 1024, 1000000, 16), (_lib.ALGO_NMF, "NMF", 256, 1000000, 64), (_lib.ALGO_NMF, "NMF", 300, 200000, 130)):
+SHAPES = ((_lib.ALGO_NMF, "NMF", 1024, 32768, 16), (_lib.ALGO_NMF, "NMF", 1024, 65536, 16), (_lib.ALGO_NMF, "NMF", 1024, 131072, 16),
+          (_lib.ALGO_NMF, "NMF", 1024, 1000000, 16), (_lib.ALGO_NMF, "NMF", 256, 1000000, 64), (_lib.ALGO_NMF, "NMF", 300, 200000, 130))
+if "--quick" in sys.argv:                   # (the GPU suite's sample)
+    SHAPES = (SHAPES[0], SHAPES[2], (_lib.ALGO_NMF, "NMF", 512, 1000000, 16), SHAPES[5])
+for (algo, name, mw, nw, k) in SHAPES:
     c = _lib.Context(algo, mw, nw, k)
     c.fill_v_uniform(7); c.fill_w_uniform(8); c.fill_h_uniform(9)
     V = _synthetic_rows(7, np.arange(mw), nw).astype(np.float64)

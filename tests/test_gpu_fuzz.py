@@ -16,15 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                        ("fuzz_tiled.py", ["2027", "20"]),        # two-pass kernels, stream forms on and off: bit-identical
                                        ("fuzz_wide.py", ["2028", "12"]),         # every inverse kernel, > 128 bases
                                        ("fuzz_misc.py", ["2029"]),               # streamed passes, NNDSVD
-                                       ("fuzz_sequences.py", ["2030", "80"]),    # random call sequences on one object against its oracle twin
-                                       ("fuzz_sequences.py", ["2031", "80"]),
-                                       ("fuzz_sequences.py", ["2032", "80"]),
+                                       ("fuzz_sequences.py", ["2030", "50"]),    # random call sequences on one object against its oracle twin
+                                       ("fuzz_sequences.py", ["2031", "30"]),
                                        ("threads_probe.py", []),                 # 24 host threads, one object each: bit-identical to sequential
                                        ("stress_leaks.py", []),                  # 180 contexts, 20 000-iteration loops: memory comes back
                                        ("huge_probe.py", ["20971520"]),          # V of 5.4e9 elements (> 2^32): W rows vs the oracle, one-pass vs two-pass
                                        ("huge_probe2.py", ["20971520"]),         # ... NMFALS (KKT), SNMF on it; NMF 1 024 x 1 000 000
                                        ("huge_probe3.py", ["20971520", "256"]),  # ... 256 bases: W of 5.4e9 elements on the wide-base path
-                                       ("wide_scan.py", []),                     # 32 768 ... 1 000 000 columns: chunked accumulation chains
+                                       ("wide_scan.py", ["--quick"]),                     # 32 768 ... 1 000 000 columns: chunked accumulation chains
                                        ("degenerate_values.py", [])])            # zero / constant / low-rank data, zero bases, 1e-6 ... 1e+12
 def test_seeded_sample_of_the_randomised_sweeps(tool, args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", tool)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
