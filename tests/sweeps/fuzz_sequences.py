@@ -43,7 +43,8 @@ for case in range(ncase):
         m, n = (70000, int(rs.choice([128, 256]))) if rs.randint(2) else (3000, 1100)
         k = min(k, 64)
     if name == "NMFALS":
-        k = min(k, 8, m, n)                   # (well-posed QPs: comparisons of the factors themselves need unique minimisers)
+        # (well-posed QPs: comparisons of the factors themselves need unique minimisers -- many more rows and columns than bases)
+        k = min(k, 64, m, n) if (m >= 600 and n >= 256 and m <= 3000) else min(k, 8, m, n)
     if name == "SNMF":
         k = max(1, min(k, n // 2, m // 2))    # (k = n or k = m makes every invertible factor an exact fit and the inverse a float32 conditioning test)
     V = rs.random_sample((m, n)).astype(np.float32) - (0.4 if name == "SNMF" else 0.0)
