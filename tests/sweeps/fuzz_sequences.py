@@ -63,7 +63,23 @@ for case in range(ncase):
         import scipy.sparse as sp
         V = V * (rs.random_sample(V.shape) < 0.2)
         variant.append("csr")
-    a, o = use_cls(sp.csr_matrix(V) if sparse else V.copy(), num_bases=k, **kwc), ocls(V.astype(np.float64), num_bases=k, **kwc)
+    use_ocls = ocls
+    if name in ("NMF", "BNMF") and rs.randint(5) == 0:
+        # hooks that EDIT the factors in the middle of factorize()'s loop (a rescaling after every W step, the kind of thing
+        # subclasses do): the device copy handed out by the hook must come back before the next hook runs
+        class Editing(cls):
+            def update_w(self):
+                cls.update_w(self)
+                self.W *= 1.01
+                self.H[0, :] *= 0.99
+
+        class EditingO(ocls):
+            def update_w(self):
+                ocls.update_w(self)
+                self.W *= 1.01
+                self.H[0, :] *= 0.99
+        use_cls, use_ocls = Editing, EditingO; variant.append("editing-hooks")
+    a, o = use_cls(sp.csr_matrix(V) if sparse else V.copy(), num_bases=k, **kwc), use_ocls(V.astype(np.float64), num_bases=k, **kwc)
     if name != "RNMF" and not sparse and rs.randint(4) == 0:
         a.stream_rows = int(rs.choice([64, 256])); variant.append("stream_rows=%d" % a.stream_rows)
     if rs.randint(5) == 0:
@@ -191,7 +207,7 @@ for case in range(ncase):
             a.data = sp.csr_matrix(Vn) if sparse else Vd; o.data = Vn.astype(np.float64)
         else:
             how = int(rs.randint(3))
-            if "hooked" in variant and how == 2:
+            if ("hooked" in variant or "editing-hooks" in variant) and how == 2:
                 how = 1                       # (a class defined inside a function does not pickle)
             log.append(["copy.copy", "copy.deepcopy", "pickle"][how])
             a = copy.copy(a) if how == 0 else copy.deepcopy(a) if how == 1 else pickle.loads(pickle.dumps(a))
