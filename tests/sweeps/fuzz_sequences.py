@@ -79,7 +79,26 @@ for case in range(ncase):
                 self.W *= 1.01
                 self.H[0, :] *= 0.99
         use_cls, use_ocls = Editing, EditingO; variant.append("editing-hooks")
+    if name in ("NMF", "SNMF") and not sparse and "editing-hooks" not in variant and rs.randint(6) == 0:
+        # a hook that RAISES in the middle of a loop: W and H must be what the completed hooks left (the reference's state)
+        base_c, base_o = use_cls, use_ocls
+
+        class Raising(base_c):
+            def update_h(self):
+                self._calls = getattr(self, "_calls", 0) + 1
+                if self._calls == self._raise_at:
+                    raise RuntimeError("hook failed")
+                base_c.update_h(self)
+
+        class RaisingO(base_o):
+            def update_h(self):
+                self._calls = getattr(self, "_calls", 0) + 1
+                if self._calls == self._raise_at:
+                    raise RuntimeError("hook failed")
+                base_o.update_h(self)
+        use_cls, use_ocls = Raising, RaisingO; variant.append("raising-hook")
     a, o = use_cls(sp.csr_matrix(V) if sparse else V.copy(), num_bases=k, **kwc), use_ocls(V.astype(np.float64), num_bases=k, **kwc)
+    a._raise_at = o._raise_at = int(rs.randint(2, 9)) if "raising-hook" in variant else -1
     if name != "RNMF" and not sparse and rs.randint(4) == 0:
         a.stream_rows = int(rs.choice([64, 256])); variant.append("stream_rows=%d" % a.stream_rows)
     if rs.randint(5) == 0:
@@ -148,7 +167,20 @@ for case in range(ncase):
             if sparse:
                 kw["compute_err"] = False     # (the reference's frobenius_norm() is its -123456 sentinel on sparse data; ours refuses the flag)
             log.append("factorize(%s)" % kw)
-            a.factorize(show_progress=bool(rs.randint(4) == 0), **kw); o.factorize(**kw)
+            sp_flag = bool(rs.randint(4) == 0)
+            errs = []
+            for obj, kk in ((a, dict(show_progress=sp_flag, **kw)), (o, kw)):
+                try:
+                    obj.factorize(**kk); errs.append(None)
+                except RuntimeError as e:
+                    if "hook failed" not in str(e):
+                        raise
+                    errs.append("hook failed")
+            if errs[0] != errs[1]:
+                ok = False; log.append("hook failure on one side only: %s" % errs)
+            if errs[1] is not None:
+                kw["compute_err"] = False      # (ferr of an aborted call: not compared)
+                log.append("(the hook raised)")
             if kw["compute_err"]:
                 L = min(len(a.ferr), len(o.ferr))
                 same = np.allclose(a.ferr[:L], o.ferr[:L], rtol=1e-4 * tol / CLASSES[[c[0] for c in CLASSES].index(name)][3], atol=floor32(o, V))
@@ -173,7 +205,13 @@ for case in range(ncase):
         elif op == 3:
             log.append("update_w"); a.update_w(); o.update_w()
         elif op == 4:
-            log.append("update_h"); a.update_h(); o.update_h()
+            log.append("update_h")
+            for obj in (a, o):
+                try:
+                    obj.update_h()
+                except RuntimeError as e:
+                    if "hook failed" not in str(e):
+                        raise
         elif op == 5:
             log.append("frobenius_norm")
             fa, fo = a.frobenius_norm(), o.frobenius_norm()
@@ -207,7 +245,7 @@ for case in range(ncase):
             a.data = sp.csr_matrix(Vn) if sparse else Vd; o.data = Vn.astype(np.float64)
         else:
             how = int(rs.randint(3))
-            if ("hooked" in variant or "editing-hooks" in variant) and how == 2:
+            if ("hooked" in variant or "editing-hooks" in variant or "raising-hook" in variant) and how == 2:
                 how = 1                       # (a class defined inside a function does not pickle)
             log.append(["copy.copy", "copy.deepcopy", "pickle"][how])
             a = copy.copy(a) if how == 0 else copy.deepcopy(a) if how == 1 else pickle.loads(pickle.dumps(a))
