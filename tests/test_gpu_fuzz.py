@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                        ("fuzz_misc.py", ["2029"]),               # streamed passes, NNDSVD
                                        ("fuzz_sequences.py", ["2030", "50"]),    # random call sequences on one object against its oracle twin
                                        ("fuzz_sequences.py", ["2031", "30"]),
+                                       ("fuzz_abi_sequences.py", ["2040", "50"]),  # ... of C-ABI calls on one context, resident and streamed passes mixed
                                        ("threads_probe.py", []),                 # 24 host threads, one object each: bit-identical to sequential
                                        ("stress_leaks.py", []),                  # 180 contexts, 20 000-iteration loops: memory comes back
                                        ("huge_probe.py", ["20971520"]),          # V of 5.4e9 elements (> 2^32): W rows vs the oracle, one-pass vs two-pass
