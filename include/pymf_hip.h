@@ -150,7 +150,8 @@ int pmf_rnmf_set_s_f32(pmf_ctx* ctx, const float* S);
  *   pmf_stream_tile(ctx, row0, rows, tile, ld)    row tiles in order; row0 and rows multiples of 64
  *                                                 (the last tile may be ragged); `tile` is row-major
  *                                                 host memory that must stay valid until the next but
- *                                                 one pmf_stream_tile call or pmf_stream_end
+ *                                                 one pmf_stream_tile call (or pmf_stream_end) has RETURNED:
+ *                                                 the call waits for the copy of the tile two calls back
  *   pmf_stream_end(ctx, &ferr, &needs_direct)     H step; ferr = ||V - W H|| by the trace identity
  * needs_direct = 1 reports that the identity cancels (residual energy below 1e-3 of ||V||^2): a pass with
  * flags = PMF_STREAM_RESID evaluates sum((V - W H)^2) tile by tile instead (no update). */
