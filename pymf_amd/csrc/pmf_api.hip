@@ -2397,7 +2397,7 @@ int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
 int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dW, c->KP, c->m, c->k, row0, seed));
-  c->have_w = true; c->ps_valid = false;
+  c->have_w = true; c->ps_valid = false; c->trace_ready = false;   // (the trace terms <P,H>, <S,G> belong to the old W as well)
   return PMF_OK;
 }
 int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
@@ -2424,7 +2424,7 @@ int pmf_set_w_f32(pmf_ctx* c, const float* W) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(zero_padding(c, c->dW, c->KP, c->mp, c->m, c->k));
   PMFCHK(upload_padded(c, c->dW, c->KP, W, c->k, c->m, c->k));
-  c->have_w = true; c->ps_valid = false; c->w_implicit = false;
+  c->have_w = true; c->ps_valid = false; c->trace_ready = false; c->w_implicit = false;
   return PMF_OK;
 }
 int pmf_set_w_f64(pmf_ctx* c, const double* W) {
@@ -2432,7 +2432,7 @@ int pmf_set_w_f64(pmf_ctx* c, const double* W) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(zero_padding(c, c->dW, c->KP, c->mp, c->m, c->k));
   PMFCHK(upload_rows<double>(c, c->dW, c->KP, W, c->k, c->m, c->k));
-  c->have_w = true; c->ps_valid = false; c->w_implicit = false;
+  c->have_w = true; c->ps_valid = false; c->trace_ready = false; c->w_implicit = false;
   return PMF_OK;
 }
 int pmf_get_w_f64(pmf_ctx* c, double* W) {
@@ -2892,6 +2892,7 @@ int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
     HIPCHK(c, hipGetLastError());
     PMFCHK(allreduce_ps(c));
     c->ps_valid = true;
+    c->trace_ready = false;       // (terms an earlier H step left belong to an earlier (P | S))
   }
   if (c->st_flags & PMF_COMPUTE_H) {
     c->want_trace = (c->st_flags & PMF_COMPUTE_ERR) != 0;

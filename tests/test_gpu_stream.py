@@ -325,3 +325,33 @@ def test_streamed_tiles_converted_on_the_fly(pm, cls_name, layout):
     tol = 2e-5 if cls_name != "NMFALS" else 1e-4
     assert rel_fro(a.W, o.W, what="mdl.W") < tol and rel_fro(a.H, o.H, what="mdl.H") < tol
     close(a.ferr, o.ferr, rtol=1e-5, what="mdl.ferr")
+
+
+def test_error_only_streamed_pass_after_a_new_w(pm):
+    """Round 4 (tests/sweeps/fuzz_abi_sequences.py): pmf_set_w_* dropped (P | S) but left the trace terms <P,H>, <S,G> of the last
+    H step marked current; an error-only streamed pass then rebuilt (P | S) for the NEW W and evaluated ||V - W H|| from the OLD
+    terms (79.31 for 79.60).  Directly on the C ABI: full streamed pass, new W, error-only streamed pass."""
+    from pymf_amd import _lib
+    from oracle import NMFOracle
+    rs = np.random.RandomState(3)
+    m, n, k = 700, 1100, 33
+    V = rs.random_sample((m, n)).astype(np.float32)
+    o = NMFOracle(V.astype(np.float64), num_bases=k)
+    o.W, o.H = rs.random_sample((m, k)), rs.random_sample((k, n))
+    c = _lib.Context(_lib.ALGO_NMF, m, n, k)
+    c.set_w(o.W.copy()); c.set_h(o.H.copy())
+
+    def streamed_pass(rows, **kw):
+        c.stream_begin(max_tile_rows=rows, **kw)
+        for r0 in range(0, m, rows):
+            c.stream_tile(r0, V[r0:r0 + rows])
+        return c.stream_end()[0]
+
+    f1 = streamed_pass(256, compute_w=True, compute_h=True, compute_err=True)
+    o.factorize(niter=1)
+    close(f1, o.ferr[-1], rtol=1e-5, what="ferr of a full streamed pass")
+    Wn = o.W * (1.0 + 0.1 * rs.random_sample(o.W.shape))
+    c.set_w(Wn.copy()); o.W = Wn.copy()
+    f2 = streamed_pass(64, compute_w=False, compute_h=False, compute_err=True)
+    close(f2, o.frobenius_norm(), rtol=1e-5, what="error-only streamed pass after pmf_set_w")
+    c.close()
