@@ -22,18 +22,27 @@ def rel(a, b):
 
 
 for case in range(ncase):
-    snmf = bool(rs.randint(3) == 0)
+    kind = ["NMF", "NMF", "SNMF", "NMFALS", "BNMF"][int(rs.randint(5))]
+    snmf = kind == "SNMF"
     m = int(rs.choice([70, 300, 1000, 2100, 5000])); n = int(rs.choice([64, 100, 256, 300, 520, 1100])); k = int(rs.choice([1, 4, 16, 33, 64, 100, 130]))
     if snmf:
         k = max(1, min(k, n // 2, m // 2))
+    if kind == "NMFALS":
+        k = min(k, 8)
     V = rs.random_sample((m, n)).astype(np.float32) - (0.4 if snmf else 0.0)
-    o = (oracle.SNMFOracle if snmf else oracle.NMFOracle)(V.astype(np.float64), num_bases=k)
+    if kind == "BNMF":
+        V = (V < 0.35).astype(np.float32)
+    ocls = {"NMF": oracle.NMFOracle, "SNMF": oracle.SNMFOracle, "NMFALS": oracle.NMFALSOracle, "BNMF": oracle.BNMFOracle}[kind]
+    o = ocls(V.astype(np.float64), num_bases=k)
     o.W, o.H = rs.random_sample((m, k)), rs.random_sample((k, n))
-    c = _lib.Context(_lib.ALGO_SNMF if snmf else _lib.ALGO_NMF, m, n, k)
+    c = _lib.Context({"NMF": _lib.ALGO_NMF, "SNMF": _lib.ALGO_SNMF, "NMFALS": _lib.ALGO_NMFALS, "BNMF": _lib.ALGO_BNMF}[kind], m, n, k)
     c.set_v_dense(V); c.set_w(o.W.copy()); c.set_h(o.H.copy())
+    if kind == "BNMF":                        # the penalty weights are plain state at this level (bnmf.py:84-85: x 1.1 per H step)
+        o._lamb_W = o._lamb_H = 0.3
+        c.set_lambda(0.3, 0.3)
     log, ok = [], True
     snap = None
-    tol = 2e-4 if snmf else 2e-5
+    tol = {"NMF": 2e-5, "SNMF": 2e-4, "NMFALS": 2e-3, "BNMF": 5e-5}[kind]
     for step in range(int(rs.randint(5, 14))):
         op = int(rs.randint(11))
         if op <= 1:
@@ -41,7 +50,7 @@ for case in range(ncase):
             niter = int(rs.randint(1, 6))
             log.append("factorize(%d, %s)" % (niter, kw))
             fe, done, conv = c.factorize(niter, **kw)
-            o.factorize(niter=niter, **kw)
+            oracle.NMFOracle.factorize(o, niter=niter, **kw)
             if kw["compute_err"]:
                 L = min(done, len(o.ferr))
                 floor = 5e-6 * max(np.linalg.norm(V), np.linalg.norm(o.W) * np.linalg.norm(o.H))
@@ -49,6 +58,8 @@ for case in range(ncase):
                     ok = False; log.append("ferr %s vs %s" % (np.asarray(fe)[:done], o.ferr))
                 if done != len(o.ferr):        # stationary to float32 noise: carry on from the library's state
                     o.W, o.H = c.get_w().astype(np.float64), c.get_h().astype(np.float64)
+                    if kind == "BNMF":
+                        o._lamb_W, o._lamb_H = c.get_lambda()
         elif op == 2:
             log.append("update_w"); c.update_w(); o.update_w()
         elif op == 3:
@@ -84,7 +95,7 @@ for case in range(ncase):
             for r0 in range(0, m, rows):
                 c.stream_tile(r0, V[r0:r0 + rows])
             fe, nd = c.stream_end()
-            o.factorize(niter=1, **kw)
+            oracle.NMFOracle.factorize(o, niter=1, **kw)
             if not nd and abs(fe - o.ferr[-1]) > 1e-4 * o.ferr[-1] + 5e-6 * max(np.linalg.norm(V), np.linalg.norm(o.W) * np.linalg.norm(o.H)):
                 ok = False; log.append("streamed ferr %r vs %r" % (fe, o.ferr[-1]))
             c.set_v_dense(V)                  # (the resident calls that follow need V on the device again)
@@ -99,7 +110,7 @@ for case in range(ncase):
             break
     if not ok:
         bad += 1
-        print("BAD case %d: %s %dx%d k=%d (%s): %s" % (case, "SNMF" if snmf else "NMF", m, n, k, c.path_name, " -> ".join(log[-8:])), flush=True)
+        print("BAD case %d: %s %dx%d k=%d (%s): %s" % (case, kind, m, n, k, c.path_name, " -> ".join(log[-8:])), flush=True)
     c.close()
 print("seed %d: %d cases" % (seed, ncase))
 print("bad %d" % bad)
