@@ -192,6 +192,87 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0):
     return out
 
 
+def _visible_devices(timeout=180.0):
+    """The number of GPUs a rank process will see, counted by a CHILD process (pmf_device_count): the launcher itself makes
+    no HIP call (a process that has initialised the GPU must not be the parent that replaces / outlives the ranks)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from pymf_amd import _lib; print(_lib.device_count())" % ROOT)
+    try:
+        p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        return int(p.stdout.decode().strip().splitlines()[-1]) if p.returncode == 0 else 0
+    except (subprocess.TimeoutExpired, ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(args, child=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): start the N rank processes ourselves -- one
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as `torch.distributed.run`
+    would -- relay rank 0's JSON line as our own stdout, and return the job's exit status: non-zero if any rank failed
+    (the others are then killed by PID) or the wall-clock limit passed.  Fewer visible GPUs than ranks is an error, never a
+    silent 1-GPU line (--debug-share-gpu: every rank on device 0, a plumbing check).  This process never touches the GPU."""
+    import socket
+    import subprocess
+    import threading
+    n = int(args.gpus)
+    if not args.debug_share_gpu:
+        have = _visible_devices()
+        if have < n:
+            print("bench.py: --gpus %d but %d GPU(s) are visible to pmf_device_count(); refusing to print a line that would "
+                  "not be an N-GPU measurement (use --debug-share-gpu for the plumbing check on one GPU)" % (n, have),
+                  file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs, out0 = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYMF_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        procs.append(subprocess.Popen(child or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+
+    def _drain():
+        for line in procs[0].stdout:
+            out0.append(line.decode("utf-8", "replace"))
+    t = threading.Thread(target=_drain, daemon=True)
+    t.start()
+    deadline = time.time() + float(args.launch_timeout)
+    status, why = 0, ""
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            status, why = 3, "rank %d exited with status %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            status, why = 4, "the ranks did not finish within --launch-timeout %.0f s" % args.launch_timeout
+            break
+        time.sleep(0.05)
+    if status:
+        for p in procs:                       # exactly the processes started above, by PID
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+        print("bench.py: %s; the other ranks were stopped" % why, file=sys.stderr)
+    t.join(timeout=10)
+    lines = [l for l in out0 if l.startswith("{")]
+    if status == 0 and len(lines) != 1:
+        print("bench.py: rank 0 printed %d JSON lines" % len(lines), file=sys.stderr)
+        status = 5
+    if status == 0:
+        sys.stdout.write(lines[0])
+        sys.stdout.flush()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,7 +300,13 @@ def main():
                          "through the one-shot IPC all-reduce (RCCL refuses two ranks on one GPU); NOT a measurement")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="pmf_set_option(NAME, VALUE) on the bench context (A/B measurements of tuning knobs)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 without a launcher: wall-clock limit (s) for the N rank processes this script starts")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (never touching the GPU in THIS process) and exit with the job's status
+        sys.exit(launch_ranks(args))
 
     from pymf_amd import _lib, dist
     if args.debug_share_gpu:
@@ -234,15 +321,15 @@ def main():
     m, n, k = args.m or m, args.n or n, args.k or k
     algo = getattr(_lib, "ALGO_" + algo_name)
     lo, hi = w.row_range(m)
-    if args.debug_share_gpu:
-        ctx = _lib.Context(algo, hi - lo, n, k, device=0)
-    else:
-        ctx = _lib.Context(algo, hi - lo, n, k, device=w.local_rank, rank=w.rank,
-                           nranks=w.size, nccl_id=w.nccl_id)
+    if w.size > 1 and not args.debug_share_gpu and _lib.device_count() < w.size:
+        if w.rank == 0:
+            print("bench.py: %d ranks but %d visible GPU(s): not an N-GPU measurement (--debug-share-gpu for the plumbing "
+                  "check on one GPU)" % (w.size, _lib.device_count()), file=sys.stderr)
+        sys.exit(2)
+    # RCCL communicator (time-boxed), with the one-shot IPC all-reduce in front of it where it passes its self-test
+    ctx = dist.make_context(algo, hi - lo, n, k, share_gpu=args.debug_share_gpu)
     for ov in args.option:
         ctx.set_option(ov.split("=")[0], int(ov.split("=")[1]))
-    if w.size > 1:
-        dist.setup_collectives(ctx)          # RCCL, with the one-shot IPC all-reduce in front of it where it passes its self-test
     data = "synthetic"
     nnz_local = 0
     host = {}                    # host copies for the class-level measurement (1 rank, numpy fill)
@@ -505,6 +592,10 @@ def main():
                                    "compute_err=False" % (args.config, cfg_index, cfg_desc, m, n, k, w.size),
                        "m": m, "n": n, "k": k, "algo": algo_name, "path": ctx.path_name,
                        "collective": collective,
+                       "collective_setup": dict(dist.LAST_SETUP) if w.size > 1 else None,   # transport, ranks, one-shot self-test verdict
+                       "ipc_selftest": dist.LAST_SETUP.get("oneshot") if w.size > 1 else None,
+                       "launched_by": ("bench.py itself (N rank processes, no launcher)" if os.environ.get("PYMF_BENCH_SELF_LAUNCHED")
+                                       else "external launcher (WORLD_SIZE in the environment)") if w.size > 1 else None,
                        "collective_mean_ms": coll_ms if coll_n else None,      # HIP events around the per-iteration sum, this rank
                        "collective_launches": coll_n,
                        "compute_err_true_iters_per_sec": rate_err,

@@ -173,6 +173,9 @@ struct pmf_ctx {
   bool ipc_exported = false;
   unsigned long long ipc_wait_ticks = PMF_IPC_WAIT_TICKS;
   int ipc_nranks_ready = 0;                  // ranks mapped by pmf_ipc_import (ipc.nranks = 0 while the path is switched off)
+  int ipc_export_nranks = 0;                 // the rank count pmf_ipc_export sized the receive area for
+  float *dIpcTestA = nullptr, *dIpcTestB = nullptr;   // pmf_ipc_selftest's payloads, allocated by pmf_ipc_export (no allocation -- nothing
+                                                      // that can fail locally -- between the self-test's collectives)
   unsigned ipc_seq = 0;
   int* dIpcErr = nullptr;
   int64_t ipc_calls = 0, rccl_calls = 0, host_calls = 0;   // which transport the cross-rank sums took (pmf_collective_name)
@@ -494,7 +497,7 @@ int allreduce_sum(pmf_ctx* c, void* p, size_t count, bool f64) {
 
 bool multi_rank(const pmf_ctx* c) { return c->comm != nullptr || c->host_ar != nullptr || c->ipc.nranks > 1; }
 
-// a peer that never raised its flags (k_ipc_allreduce gave up after about a second of polling)
+// a peer that never raised its flags (k_ipc_allreduce gave up after ipc_wait_ticks of polling: 30 s in the loops, 2 s in the self-test)
 int ipc_check(pmf_ctx* c) {
   if (c->ipc.nranks <= 1 || !c->dIpcErr) return PMF_OK;
   int e = 0;
@@ -510,7 +513,10 @@ int ipc_check(pmf_ctx* c) {
 // The per-iteration collective: (W^T V | W^T W) summed over the ranks.  With pmf_profile_enable its launches are bracketed by
 // HIP events of their own (pmf_collective_ms: what the exchange costs an iteration at N > 1, next to the dominant kernel).
 int allreduce_ps(pmf_ctx* c) {
-  const bool timed = c->profile && multi_rank(c) && !c->host_ar_only();
+  // (timed only where the sum is a device operation on the stream: the one-shot kernel or ncclAllReduce -- a payload that
+  //  falls back to the blocking host round trip has nothing for HIP events to bracket)
+  const bool on_stream = (c->ipc.nranks > 1 && (size_t)ps_elems(c) * sizeof(float) <= PMF_IPC_MAX_BYTES) || (!c->host_ar && c->comm);
+  const bool timed = c->profile && multi_rank(c) && on_stream;
   if (timed) {
     if (c->coll_used + 2 > c->coll_ev.size())
       for (int q = 0; q < 2; ++q) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) c->coll_ev.push_back(e); }
@@ -2278,11 +2284,13 @@ int pmf_ctx_destroy(pmf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->ipc_exported) {
-    for (int r = 0; r < c->ipc_nranks_ready; ++r)
+    for (int r = 0; r < PMF_IPC_MAX_RANKS; ++r)
       if (r != c->ipc.me && c->ipc.area[r]) (void)hipIpcCloseMemHandle(c->ipc.area[r]);
     if (c->ipc.area[c->ipc.me]) (void)hipFree(c->ipc.area[c->ipc.me]);
   }
   if (c->dIpcErr) (void)hipFree(c->dIpcErr);
+  if (c->dIpcTestA) (void)hipFree(c->dIpcTestA);
+  if (c->dIpcTestB) (void)hipFree(c->dIpcTestB);
   for (void* p : {(void*)c->dV, (void*)c->dW, (void*)c->dH, (void*)c->dG, (void*)c->dPS, (void*)c->dSlab,
                   (void*)c->dW1, (void*)c->dGinvT, (void*)c->dD, (void*)c->dGd, (void*)c->dPart, (void*)c->dScal,
                   (void*)c->dIndptr, (void*)c->dIndices, (void*)c->dVals})
@@ -2396,6 +2404,7 @@ int pmf_fill_v_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
 }
 int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
   if (!c) return PMF_EINVAL;
+  PMFCHK(w_pipe_join(c));        // (a pipelined W = V M write still in flight on the side stream must not land on the new W)
   PMFCHK(fill(c, c->dW, c->KP, c->m, c->k, row0, seed));
   c->have_w = true; c->ps_valid = false; c->trace_ready = false;   // (the trace terms <P,H>, <S,G> belong to the old W as well)
   return PMF_OK;
@@ -2422,6 +2431,7 @@ static int zero_padding(pmf_ctx* c, float* buf, int64_t ld, int64_t rows_total, 
 int pmf_set_w_f32(pmf_ctx* c, const float* W) {
   if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f32: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(w_pipe_join(c));
   PMFCHK(zero_padding(c, c->dW, c->KP, c->mp, c->m, c->k));
   PMFCHK(upload_padded(c, c->dW, c->KP, W, c->k, c->m, c->k));
   c->have_w = true; c->ps_valid = false; c->trace_ready = false; c->w_implicit = false;
@@ -2430,6 +2440,7 @@ int pmf_set_w_f32(pmf_ctx* c, const float* W) {
 int pmf_set_w_f64(pmf_ctx* c, const double* W) {
   if (!c || !W) return fail(c, PMF_EINVAL, "pmf_set_w_f64: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(w_pipe_join(c));
   PMFCHK(zero_padding(c, c->dW, c->KP, c->mp, c->m, c->k));
   PMFCHK(upload_rows<double>(c, c->dW, c->KP, W, c->k, c->m, c->k));
   c->have_w = true; c->ps_valid = false; c->trace_ready = false; c->w_implicit = false;
@@ -2511,6 +2522,16 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   PMFCHK(need(c, true, true, true));
   const bool cw = flags & PMF_COMPUTE_W, ch = flags & PMF_COMPUTE_H, ce = flags & PMF_COMPUTE_ERR;
   if (niter < 0 || (ce && !ferr)) return fail(c, PMF_EINVAL, "pmf_factorize: bad arguments");
+  // every early (error) return below leaves no pipelined W = V M write in flight on the side stream: a caller that then
+  // re-uploads W must not see the stale product land on top of it
+  struct WPipeGuard {
+    pmf_ctx* c; bool ok = false;
+    ~WPipeGuard() {
+      if (ok || !c->w_stream) return;
+      (void)hipStreamSynchronize(c->w_stream);
+      c->ev_w_pending[0] = c->ev_w_pending[1] = false;
+    }
+  } wguard{c};
   if (iters_done) *iters_done = 0;
   if (converged_at) *converged_at = -1;
   c->want_trace = ce;
@@ -2534,7 +2555,10 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   const bool gram = cw && ch && snmf_gram_ok(c, niter);
   if (gram) PMFCHK(ensure_vgram(c));
   choose_stat_site(c, gram);
-  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !use_csr(c) && c->nb == 1)) && ce) || h_only) && !(c->host_ar && c->ipc.nranks <= 1);   // NMF, BNMF, SNMF on the fused kernel
+  const bool can_free_run = ((((fused && c->algo != PMF_ALGO_RNMF) || (gram && !use_csr(c) && c->nb == 1)) && ce) || h_only) &&
+                            !(c->host_ar && !(c->ipc.nranks > 1 && (size_t)ps_elems(c) * sizeof(float) <= PMF_IPC_MAX_BYTES));   // NMF, BNMF, SNMF on the fused kernel
+  // (a host transport blocks on the host in every iteration -- nothing to free-run -- unless the per-iteration payload
+  //  (P | S) fits the one-shot IPC all-reduce in front of it)
   constexpr int kHostIters = 1, kChunk = 32;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
@@ -2663,6 +2687,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   c->last_loop_ms = ms;
   if (ce) for (int q = done; q < niter; ++q) ferr[q] = 0.0;   // as np.zeros(niter) leaves them (nmf.py:179-180)
   if (iters_done) *iters_done = done;
+  wguard.ok = true;              // (materialize_w above joined the side stream)
   PMFCHK(ipc_check(c));
   return check_singular(c);
 }
@@ -3159,6 +3184,10 @@ int pmf_ipc_export(pmf_ctx* c, int32_t rank, int32_t nranks, void* handle_out) {
   }
   HIPCHK(c, hipMemsetAsync(area, 0, bytes, c->stream));
   if (!c->dIpcErr) PMFCHK(dalloc(c, &c->dIpcErr, 1));
+  // the self-test's two payload buffers, here: everything that can fail on ONE rank alone happens before the ranks vote on
+  // "exported"; between the self-test's collectives nothing is allocated
+  if (!c->dIpcTestA) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dIpcTestA), PMF_IPC_MAX_BYTES));
+  if (!c->dIpcTestB) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dIpcTestB), PMF_IPC_MAX_BYTES));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memset(handle_out, 0, PMF_IPC_HANDLE_BYTES);
   std::memcpy(handle_out, &h, sizeof(h));
@@ -3167,20 +3196,28 @@ int pmf_ipc_export(pmf_ctx* c, int32_t rank, int32_t nranks, void* handle_out) {
   c->ipc.me = rank;
   c->ipc.nranks = 0;                          // ready only after pmf_ipc_import
   c->ipc_exported = true;
+  c->ipc_export_nranks = nranks;              // the receive area is sized for THIS many ranks
   c->ipc_seq = 0;
   return PMF_OK;
 }
 
 int pmf_ipc_import(pmf_ctx* c, const void* handles, int32_t nranks) {
-  if (!c || !handles || !c->ipc_exported || nranks < 2 || nranks > PMF_IPC_MAX_RANKS || c->ipc.me >= nranks)
-    return fail(c, PMF_EINVAL, "pmf_ipc_import: call pmf_ipc_export first; handles = nranks x PMF_IPC_HANDLE_BYTES in rank order");
+  if (!c || !handles || !c->ipc_exported || nranks != c->ipc_export_nranks || c->ipc_nranks_ready > 0)
+    return fail(c, PMF_EINVAL, "pmf_ipc_import: call pmf_ipc_export first, once; handles = nranks x PMF_IPC_HANDLE_BYTES in rank "
+                               "order with the nranks given to pmf_ipc_export (the receive areas are sized for it)");
   HIPCHK(c, hipSetDevice(c->device));
   for (int r = 0; r < nranks; ++r) {
     if (r == c->ipc.me) continue;
     hipIpcMemHandle_t h;
     std::memcpy(&h, static_cast<const char*>(handles) + (size_t)r * PMF_IPC_HANDLE_BYTES, sizeof(h));
     void* p = nullptr;
-    HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {                     // give back what was mapped so far: nothing half-open survives a failed import
+      (void)hipGetLastError();
+      for (int q = 0; q < nranks; ++q)
+        if (q != c->ipc.me && c->ipc.area[q]) { (void)hipIpcCloseMemHandle(c->ipc.area[q]); c->ipc.area[q] = nullptr; }
+      return fail(c, PMF_EHIP, std::string("pmf_ipc_import: hipIpcOpenMemHandle of rank ") + std::to_string(r) + ": " + hipGetErrorString(e));
+    }
     c->ipc.area[r] = static_cast<char*>(p);
   }
   c->ipc.nranks = nranks;
@@ -3198,13 +3235,11 @@ int pmf_ipc_selftest(pmf_ctx* c, int32_t rounds, int32_t* ok) {
   *ok = 0;
   if (c->ipc_nranks_ready <= 1) return fail(c, PMF_EINVAL, "pmf_ipc_selftest: no one-shot all-reduce set up (pmf_ipc_import)");
   if (!c->comm && !c->host_ar) return fail(c, PMF_EINVAL, "pmf_ipc_selftest: needs a second transport to compare with");
-  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->dIpcTestA || !c->dIpcTestB) return fail(c, PMF_EINVAL, "pmf_ipc_selftest: no test buffers (pmf_ipc_export allocates them)");
   const size_t count = std::min<size_t>((size_t)ps_elems(c), PMF_IPC_MAX_BYTES / sizeof(float));
-  float *dA = nullptr, *dB = nullptr;
-  HIPCHK(c, hipMalloc(&dA, count * sizeof(float)));
-  HIPCHK(c, hipMalloc(&dB, count * sizeof(float)));
+  float *dA = c->dIpcTestA, *dB = c->dIpcTestB;
   std::vector<float> x(count), a(count), b(count);
-  bool good = true;
+  bool good = hipSetDevice(c->device) == hipSuccess;
   int rc = PMF_OK;
   c->ipc_wait_ticks = 2ull * 100000000ull;             // 2 s: the ranks enter the test together
   // EVERY rank runs EVERY round whatever it has seen so far: a rank that left early would leave its peers waiting in the
@@ -3227,7 +3262,6 @@ int pmf_ipc_selftest(pmf_ctx* c, int32_t rounds, int32_t* ok) {
       if (!(std::fabs(a[i] - b[i]) <= 1e-5f * std::fabs(b[i]))) good = false;
   }
   c->ipc_wait_ticks = PMF_IPC_WAIT_TICKS;
-  (void)hipFree(dA); (void)hipFree(dB);
   (void)rc;                                            // (a failing call is a failed test, not an error of this function)
   *ok = good ? 1 : 0;
   return PMF_OK;
@@ -3267,6 +3301,7 @@ int pmf_restore_w(pmf_ctx* c) {
   if (!c) return PMF_EINVAL;
   if (!c->wsnap_valid) return fail(c, PMF_EINVAL, "pmf_restore_w: no snapshot (pmf_snapshot_w)");
   HIPCHK(c, hipSetDevice(c->device));
+  PMFCHK(w_pipe_join(c));
   HIPCHK(c, hipMemcpyAsync(c->dW, c->dWsnap, (size_t)c->mp * c->KP * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->w_implicit = false;

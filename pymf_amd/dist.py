@@ -26,6 +26,8 @@ import json
 import os
 import socket
 import struct
+import sys
+import threading
 import time
 
 import numpy as np
@@ -82,42 +84,127 @@ def oneshot():
     return int(os.environ.get("LOCAL_WORLD_SIZE", str(_WORLD.size)) or _WORLD.size) == _WORLD.size
 
 
+class Watchdog(object):
+    """Time-box for the start-up steps nobody can interrupt from inside: `ncclCommInitRank` (inside pmf_ctx_create),
+    `hipIpcOpenMemHandle`, the transports' self-test.  They are collective -- a rank that waits for a peer which died, or for
+    a fabric that never answers, would sit there for ever (RCCL) or for the in-kernel polling limit -- so a rank that is
+    still inside after `seconds` (env PYMF_DIST_INIT_TIMEOUT, default 240) says so on stderr and ends its PROCESS with
+    status 70: the launcher (torch.distributed.run, or bench.py's own) then stops the other ranks and reports a failed
+    job instead of hanging.  ctypes releases the GIL during the C calls, so the timer thread does get to run."""
+
+    EXIT_STATUS = 70
+
+    def __init__(self, what, seconds=None):
+        self.what = what
+        self.seconds = float(seconds if seconds is not None else os.environ.get("PYMF_DIST_INIT_TIMEOUT", "240"))
+        self._t = None
+
+    def _fire(self):
+        try:
+            sys.stderr.write("pymf_amd.dist: rank %d of %d is still in '%s' after %.0f s (PYMF_DIST_INIT_TIMEOUT); a peer rank died or "
+                             "the transport does not come up -- giving up instead of hanging\n"
+                             % (_WORLD.rank, _WORLD.size, self.what, self.seconds))
+            sys.stderr.flush()
+        finally:
+            os._exit(self.EXIT_STATUS)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self._t = threading.Timer(self.seconds, self._fire)
+            self._t.daemon = True
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._t is not None:
+            self._t.cancel()
+        return False
+
+
+LAST_SETUP = {}      # what setup_collectives() decided on this rank (bench.py prints it: config.collective_setup)
+
+
+def same_node():
+    """True iff every rank runs on the same host (one all-gather of hostname + boot id): HIP IPC handles mean nothing on
+    another node, and LOCAL_WORLD_SIZE is not set by every launcher (srun, mpirun)."""
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as fh:
+            boot = fh.read().strip()
+    except OSError:
+        boot = ""
+    me = (socket.gethostname() + "|" + boot).encode()
+    return all(p == me for p in allgather_bytes(me, tag="node"))
+
+
+def make_context(algo, m_local, n, k, share_gpu=False):
+    """The device context of this rank, with the transports behind its cross-rank sums set up: RCCL communicator (inside
+    pmf_ctx_create) unless the transport is "host" / "ipc" (ranks that cannot form one, e.g. sharing a GPU), then
+    setup_collectives().  Collective over all ranks; time-boxed (Watchdog)."""
+    from . import _lib
+    w = _WORLD
+    if w.size == 1:
+        return _lib.Context(algo, m_local, n, k, device=w.local_rank)
+    with Watchdog("context creation (ncclCommInitRank) + transport set-up"):
+        if transport() in ("host", "ipc"):
+            dev = 0 if share_gpu else w.local_rank % max(1, _lib.device_count())
+            ctx = _lib.Context(algo, m_local, n, k, device=dev)
+        else:
+            ctx = _lib.Context(algo, m_local, n, k, device=w.local_rank, rank=w.rank, nranks=w.size, nccl_id=w.nccl_id)
+        setup_collectives(ctx)
+    return ctx
+
+
 def setup_collectives(ctx):
     """After a multi-rank Context exists on every rank: the transports behind its cross-rank sums.  Collective (every
     rank calls it at the same point).  Returns Context.collective_name."""
     w, t = _WORLD, transport()
+    LAST_SETUP.clear()
+    LAST_SETUP.update(transport=t, ranks=w.size if w else 1, oneshot="not attempted")
     if w is None or w.size == 1:
         return getattr(ctx, "collective_name", "none")
+    with Watchdog("transport set-up (IPC export / import / self-test)"):
+        return _setup_collectives(ctx, w, t)
+
+
+def _setup_collectives(ctx, w, t):
     if t in ("host", "ipc"):
         ctx.set_host_allreduce(allreduce_sum_array)
-    if t == "ipc" or (t == "rccl" and oneshot()):
+    want = t == "ipc" or (t == "rccl" and oneshot())
+    if want and not same_node():
+        want = False
+        LAST_SETUP["oneshot"] = "not attempted: the ranks are not all on one node"
+    if want:
         # Every rank makes the SAME sequence of exchanges here whatever fails locally -- a rank that skipped one would leave
         # the others waiting: export (local) -> all-gather of the handles (an empty one = "could not") -> import (local) ->
         # vote -> self-test against the other transport (all ranks, all rounds) -> vote.
-        handle = b""
+        handle, stage = b"", "export"
         try:
-            handle = ctx.ipc_export(w.rank, w.size)
+            handle = ctx.ipc_export(w.rank, w.size)        # (also allocates the self-test's buffers: nothing below allocates)
         except Exception:
             handle = b""
-        parts = allgather_bytes(handle)
+        parts = allgather_bytes(handle, tag="ipc-hdl")
         ok = len(parts) == w.size and all(len(p) == len(parts[0]) and len(p) > 0 for p in parts)
         if ok:
+            stage = "import"
             try:
                 ctx.ipc_import(parts)
             except Exception:
                 ok = False
-        ok = allreduce_max(0.0 if ok else 1.0) == 0.0
+        ok = allreduce_max(0.0 if ok else 1.0, tag="ipc-map") == 0.0
         if ok:
+            stage = "self-test"
             try:
                 ok = bool(ctx.ipc_selftest())
             except Exception:
                 ok = False
-            ok = allreduce_max(0.0 if ok else 1.0) == 0.0
+            ok = allreduce_max(0.0 if ok else 1.0, tag="ipc-test") == 0.0
         if not ok:
             try:
                 ctx.set_option("oneshot_allreduce", 0)
             except Exception:
                 pass
+        other = "rccl" if t == "rccl" else "host"
+        LAST_SETUP["oneshot"] = "passed" if ok else "failed at %s -> %s" % (stage, other)
     return getattr(ctx, "collective_name", "")
 
 
@@ -241,7 +328,7 @@ def _join(addr, base_port, rank, key, timeout):
 
 def init_from_env(make_nccl_id=None, timeout=None):
     """Read the launcher's env, connect the ranks, hand rank 0's RCCL unique id to every rank."""
-    global _WORLD, _PEERS
+    global _WORLD, _PEERS, _SEQ
     size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -268,31 +355,62 @@ def init_from_env(make_nccl_id=None, timeout=None):
                            % (size, local_size, addr, bind_ip))
     key = _key(addr, mport, size, bind_ip)
     _WORLD = World(rank, size, local_rank, None)
+    _SEQ = 0
     _PEERS = _serve(bind_ip, base, size, key, timeout) if rank == 0 else _join(bind_ip, base, rank, key, timeout)
     if make_nccl_id is None and transport() in ("host", "ipc"):
         return _WORLD                                  # no RCCL communicator will be created
     if make_nccl_id is None:
         from . import _lib
         make_nccl_id = _lib.nccl_unique_id
-    ident = broadcast_bytes(bytes(make_nccl_id()) if rank == 0 else b"")
+    ident = broadcast_bytes(bytes(make_nccl_id()) if rank == 0 else b"", tag="ncclid")
     _WORLD.nccl_id = ident
     return _WORLD
 
 
 # ---- collectives (star through rank 0; every rank must make the same calls in the same order) --
-def allgather_bytes(payload):
-    """list of every rank's payload, in rank order, on every rank."""
+_SEQ = 0             # collectives made so far on this rank (every frame carries it, with the operation's tag)
+
+
+class CollectiveMismatch(RuntimeError):
+    """The ranks made DIFFERENT collective calls at the same point (e.g. one rank alone called something collective):
+    raised on every rank instead of pairing unrelated payloads or waiting for ever."""
+
+
+def allgather_bytes(payload, tag=""):
+    """list of every rank's payload, in rank order, on every rank.  Every frame carries (sequence number, tag): rank 0
+    checks that all ranks are making the SAME call and otherwise fails the collective on every rank (CollectiveMismatch)."""
+    global _SEQ
     w = _WORLD
     if w.size == 1:
         return [bytes(payload)]
+    _SEQ += 1
+    head = struct.pack("<Q8s", _SEQ, tag.encode()[:8])
     if w.rank == 0:
-        parts = [bytes(payload)] + [_recv(_PEERS[r]) for r in range(1, w.size)]
-        blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+        frames = [_recv(_PEERS[r]) for r in range(1, w.size)]
+        bad = [(r + 1, f[:16]) for r, f in enumerate(frames) if f[:16] != head]
+        if bad:
+            r, h = bad[0]
+            try:
+                q, tg = struct.unpack("<Q8s", h)
+                theirs = "call %d '%s'" % (q, tg.rstrip(b"\0").decode("utf-8", "replace"))
+            except struct.error:
+                theirs = "a malformed frame"
+            msg = ("pymf_amd.dist: the ranks disagree about the collective at hand: rank 0 is in call %d '%s', rank %d in %s "
+                   "-- a collective entry point (factorize, update_w / update_h, frobenius_norm, update_s, the lazy init) was "
+                   "called on some ranks only" % (_SEQ, tag, r, theirs))
+            for q in range(1, w.size):
+                _send(_PEERS[q], b"\x01" + msg.encode())
+            raise CollectiveMismatch(msg)
+        parts = [bytes(payload)] + [f[16:] for f in frames]
+        blob = b"\x00" + b"".join(struct.pack("<Q", len(p)) + p for p in parts)
         for r in range(1, w.size):
             _send(_PEERS[r], blob)
         return parts
-    _send(_PEERS[0], bytes(payload))
+    _send(_PEERS[0], head + bytes(payload))
     blob = _recv(_PEERS[0])
+    if blob[:1] != b"\x00":
+        raise CollectiveMismatch(blob[1:].decode("utf-8", "replace"))
+    blob = blob[1:]
     parts, off = [], 0
     while off < len(blob):
         (n,) = struct.unpack_from("<Q", blob, off)
@@ -301,35 +419,36 @@ def allgather_bytes(payload):
     return parts
 
 
-def broadcast_bytes(payload, src=0):
-    return allgather_bytes(payload if _WORLD.rank == src else b"")[src]
+def broadcast_bytes(payload, src=0, tag="bcast"):
+    return allgather_bytes(payload if _WORLD.rank == src else b"", tag=tag)[src]
 
 
 def barrier():
     if _WORLD.size > 1:
-        allgather_bytes(b"")
+        allgather_bytes(b"", tag="barrier")
 
 
-def allreduce_max(x):
+def allreduce_max(x, tag="max"):
     if _WORLD.size == 1:
         return float(x)
-    return max(struct.unpack("<d", p)[0] for p in allgather_bytes(struct.pack("<d", float(x))))
+    return max(struct.unpack("<d", p)[0] for p in allgather_bytes(struct.pack("<d", float(x)), tag=tag))
 
 
 def allgather_int(x):
-    return [struct.unpack("<q", p)[0] for p in allgather_bytes(struct.pack("<q", int(x)))]
+    return [struct.unpack("<q", p)[0] for p in allgather_bytes(struct.pack("<q", int(x)), tag="ints")]
 
 
 def allgather_float(x):
-    return [struct.unpack("<d", p)[0] for p in allgather_bytes(struct.pack("<d", float(x)))]
+    return [struct.unpack("<d", p)[0] for p in allgather_bytes(struct.pack("<d", float(x)), tag="floats")]
 
 
-def allreduce_sum_array(a):
-    """Sum of a float array over the ranks, added in rank order (the same bits on every rank)."""
+def allreduce_sum_array(a, tag=None):
+    """Sum of a float array over the ranks, added in rank order (the same bits on every rank).  The default tag carries
+    dtype and size, so that two ranks summing DIFFERENT things at the same point fail loudly instead of mixing payloads."""
     a = np.ascontiguousarray(a)
     if _WORLD.size == 1:
         return a
-    parts = allgather_bytes(a.tobytes())
+    parts = allgather_bytes(a.tobytes(), tag=tag or ("s%s%d" % (a.dtype.char, a.size))[:8])
     out = np.zeros(a.shape, dtype=a.dtype)
     for p in parts:
         out += np.frombuffer(p, dtype=a.dtype).reshape(a.shape)
@@ -346,7 +465,7 @@ def broadcast_array(a, src=0):
         blob = struct.pack("<I", len(head)) + head + a.tobytes()
     else:
         blob = b""
-    blob = broadcast_bytes(blob, src)
+    blob = broadcast_bytes(blob, src, tag="array")
     (hl,) = struct.unpack_from("<I", blob, 0)
     head = json.loads(blob[4:4 + hl].decode())
     return np.frombuffer(blob[4 + hl:], dtype=np.dtype(head["dtype"])).reshape(head["shape"]).copy()
@@ -366,7 +485,7 @@ def share_rng_state(src=0):
         blob = struct.pack("<I", len(head)) + head + np.asarray(keys, dtype=np.uint32).tobytes()
     else:
         blob = b""
-    blob = broadcast_bytes(blob, src)
+    blob = broadcast_bytes(blob, src, tag="rng")
     (hl,) = struct.unpack_from("<I", blob, 0)
     head = json.loads(blob[4:4 + hl].decode())
     keys = np.frombuffer(blob[4 + hl:], dtype=np.uint32).copy()
@@ -374,7 +493,7 @@ def share_rng_state(src=0):
 
 
 def shutdown():
-    global _WORLD, _PEERS, _LISTENER
+    global _WORLD, _PEERS, _LISTENER, _SEQ
     if _PEERS is not None:
         try:
             barrier()                    # nobody closes while another rank still reads
@@ -392,3 +511,4 @@ def shutdown():
             pass
     _PEERS, _LISTENER = None, None
     _WORLD = World()
+    _SEQ = 0

@@ -211,19 +211,9 @@ class NMF(object):
     def _context(self):
         if self._ctx is None:
             t0 = time.perf_counter()
-            w = self._world()
-            if w.size > 1 and _dist.transport() in ("host", "ipc"):
-                # ranks that cannot form an RCCL communicator (e.g. sharing one GPU): the sums of (W^T V | W^T W) cross
-                # the ranks through the host (pmf_set_host_allreduce) -- "ipc": through the one-shot IPC all-reduce
-                dev = w.local_rank % max(1, _lib.device_count())
-                self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
-                                         self._num_bases, device=dev)
-            else:
-                self._ctx = _lib.Context(self._ALGO, self._data_dimension, self._num_samples,
-                                         self._num_bases, device=w.local_rank, rank=w.rank,
-                                         nranks=w.size, nccl_id=w.nccl_id)
-            if w.size > 1:
-                _dist.setup_collectives(self._ctx)
+            # one rank: a plain context; more: RCCL communicator (or, for ranks that cannot form one -- e.g. sharing a GPU --
+            # the host / one-shot IPC transports) set up and self-tested under a time-box: pymf_amd.dist.make_context
+            self._ctx = _dist.make_context(self._ALGO, self._data_dimension, self._num_samples, self._num_bases)
             self._tick("ctx", t0)
         return self._ctx
 
@@ -296,14 +286,23 @@ class NMF(object):
         t0 = time.perf_counter()
         try:
             self._uploaded = False
-            ctx = self._sync_to_device_timed(ctx, with_data)
-            if self._world().size > 1:
-                # Which cached sums are current ((W^T V | W^T W), ||V||^2, the trace terms) decides which COLLECTIVES the next
-                # call runs -- and a rank whose rows were not touched keeps its caches when another rank's data or W rows were
-                # edited: the ranks would then disagree about the next all-reduce (one waits for a peer that never comes).
-                # So the ranks agree here: if anything was uploaded anywhere, everybody drops the derived state.
-                if _dist.allreduce_sum_array(np.array([1.0 if self._uploaded else 0.0]))[0] > 0:
-                    ctx.invalidate_v()
+            try:
+                ctx = self._sync_to_device_timed(ctx, with_data)
+            except BaseException:
+                self._uploaded = True             # (whatever was half done: the peers drop their derived state too)
+                raise
+            finally:
+                if self._world().size > 1:
+                    # Which cached sums are current ((W^T V | W^T W), ||V||^2, the trace terms) decides which COLLECTIVES the
+                    # next call runs -- and a rank whose rows were not touched keeps its caches when another rank's data or W
+                    # rows were edited: the ranks would then disagree about the next all-reduce (one waits for a peer that
+                    # never comes).  So the ranks agree here: if anything was uploaded anywhere, everybody drops the derived
+                    # state.  The vote runs in a `finally`: a rank whose upload RAISED (a bad dtype) still takes part, so its
+                    # peers are not stranded.  Only the entry points that run collectives anyway come through here
+                    # (factorize, update_w / update_h, frobenius_norm, update_s); reads of local state (RNMF.S, copies,
+                    # pickles) do not -- a rank-0-only checkpoint must not become a collective.
+                    if _dist.allreduce_sum_array(np.array([1.0 if self._uploaded else 0.0]), tag="uploaded")[0] > 0:
+                        ctx.invalidate_v()
             return ctx
         finally:
             self._tick("upload", t0)

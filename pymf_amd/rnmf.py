@@ -36,7 +36,15 @@ class RNMF(NMF):
     def S(self):
         if not self._has_s:
             raise AttributeError("'RNMF' object has no attribute 'S'")   # rnmf.py: S is created by update_s
-        return self._sync_to_device().rnmf_get_s()
+        # LOCAL: no upload, no vote.  The device keeps D = S - data against the data IT holds, so S = D + V(device) is the
+        # attribute's value whatever happened to the host's `data` / W / H since (the reference's S is a plain attribute
+        # that only update_s changes) -- and a rank-0-only `model.S` / pickle must not be a collective (advisor, round 4)
+        pend = self.__dict__.get("_s_host")
+        if pend is not None or self._ctx is None:
+            if pend is None:
+                raise AttributeError("'RNMF' object has no attribute 'S'")
+            return pend                                          # a copy / unpickled object whose context has not seen S yet
+        return self._ctx.rnmf_get_s()
 
     # The reference's S is an attribute: a copy or a pickle of the object carries it, and new `data` leaves it as it is
     # (update_w / update_h then work on S - new data until the next update_s).  Here S lives on the device as D = S - data:

@@ -16,6 +16,31 @@ from oracle import NMFOracle, nmf_update_w      # noqa: E402
 def main():
     fake_id = bytes((7 * i + 3) % 251 for i in range(128))
     w = dist.init_from_env(make_nccl_id=lambda: fake_id)
+    if "--mismatch" in sys.argv:
+        # rank 0 alone makes a collective call (the "rank-0-only checkpoint" pattern); the peers' NEXT, unrelated collective
+        # meets it: every rank must get CollectiveMismatch instead of mixed payloads or a hang
+        try:
+            if w.rank == 0:
+                dist.allreduce_sum_array(np.ones(3))
+            dist.allreduce_max(1.0)
+            print("rank %d: no error" % w.rank)
+        except dist.CollectiveMismatch as e:
+            assert "disagree" in str(e), str(e)
+            print("rank %d ok (mismatch caught)" % w.rank)
+        return
+    if "--watchdog" in sys.argv:
+        import time
+        assert dist.same_node()
+        with dist.Watchdog("a step that returns in time", 30.0):
+            pass
+        dist.barrier()
+        with dist.Watchdog("the step under test", 1.0):
+            if w.rank == 1:
+                time.sleep(30.0)              # stands for a rank stuck in ncclCommInitRank / an IPC wait
+        print("rank %d ok" % w.rank)
+        if w.rank == 0:
+            time.sleep(3.0)                   # (outlives the peer's time-box)
+        return
     assert w.size == int(os.environ["WORLD_SIZE"]) and w.rank == int(os.environ["RANK"])
     assert w.nccl_id == fake_id, "rank 0's unique id must reach every rank unchanged"
     m, n, k = 203, 40, 6

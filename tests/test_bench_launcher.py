@@ -1,0 +1,63 @@
+"""`python bench.py --gpus N` without a launcher starts its own N ranks: the launcher's mechanics on CPU,
+with stand-in rank programs -- the parent never touches the GPU, relays rank 0's one JSON line, and a failing or stuck rank
+ends the job with a non-zero status (the other ranks are stopped by PID)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+from conftest import ROOT
+
+import bench
+
+
+def _args(n, **kw):
+    d = dict(gpus=n, debug_share_gpu=True, launch_timeout=60.0)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+RANK_OK = ("import os, json, sys; r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE']); "
+           "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0 and os.environ['LOCAL_RANK'] == str(r); "
+           "print('noise from rank %d' % r); "
+           "print(json.dumps({'n_gpus': w, 'rank': r})) if r == 0 else None")
+
+
+def test_launcher_relays_rank_zero_line(capfd):
+    rc = bench.launch_ranks(_args(4), child=[sys.executable, "-c", RANK_OK])
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 4, "rank": 0}, out     # ONE line on stdout
+    assert "noise from rank 3" in err                                                     # the other ranks' stdout -> stderr
+
+
+def test_a_failing_rank_fails_the_job_and_stops_the_others(capfd):
+    prog = ("import os, sys, time; r = int(os.environ['RANK']);\n"
+            "if r == 1: sys.exit(7)\n"
+            "time.sleep(120)")
+    t0 = time.time()
+    rc = bench.launch_ranks(_args(3), child=[sys.executable, "-c", prog])
+    out, err = capfd.readouterr()
+    assert rc != 0 and time.time() - t0 < 60 and out.strip() == ""
+    assert "rank 1 exited with status 7" in err
+
+
+def test_stuck_ranks_hit_the_wall_clock_limit(capfd):
+    rc = bench.launch_ranks(_args(2, launch_timeout=2.0), child=[sys.executable, "-c", "import time; time.sleep(120)"])
+    out, err = capfd.readouterr()
+    assert rc != 0 and out.strip() == "" and "did not finish within" in err
+
+
+def test_fewer_gpus_than_ranks_is_an_error_not_a_one_gpu_line():
+    """No GPU in this container: `bench.py --gpus 2` (no launcher, no --debug-share-gpu) must exit non-zero with a message
+    and print NO JSON line -- never a silent 1-rank measurement labelled as it pleases."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert p.returncode != 0
+    assert p.stdout.decode().strip() == "" and "GPU(s) are visible" in p.stderr.decode()

@@ -68,6 +68,41 @@ def test_world_under_the_torchrun_launcher():
     assert "rank 0 ok" in out and "rank 1 ok" in out
 
 
+def _run_world(size, args):
+    port = _free_port()
+    procs = []
+    for rank in range(size):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(size),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py")] + list(args),
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode())
+    return procs, outs
+
+
+def test_a_collective_called_on_one_rank_only_fails_loudly_on_every_rank():
+    """the TCP star carries (sequence number, tag) in every frame; a rank-0-only collective paired with
+    the peers' next unrelated one raises CollectiveMismatch everywhere -- no mixed payloads, no hang."""
+    procs, outs = _run_world(3, ["--mismatch"])
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok (mismatch caught)" % rank in out, "rank %d:\n%s" % (rank, out)
+
+
+def test_a_rank_stuck_in_a_start_up_step_ends_its_process_with_status_70():
+    """ncclCommInitRank / the IPC self-test are time-boxed (dist.Watchdog): the stuck rank leaves
+    with status 70 and a message, the launcher sees a failed job instead of a hang."""
+    procs, outs = _run_world(2, ["--watchdog"])
+    assert procs[0].returncode == 0 and "rank 0 ok" in outs[0], outs[0]
+    assert procs[1].returncode == 70 and "still in 'the step under test'" in outs[1], outs[1]
+
+
 def _spawn_workers(script, size, extra_args=(), extra_env=None, timeout=600):
     port = _free_port()
     procs = []

@@ -59,3 +59,34 @@ def test_two_rank_bench_line_on_one_gpu():
     assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None
     assert "one-shot IPC all-reduce" in j["config"]["collective"] and "ipc 0," not in j["config"]["collective"], j["config"]["collective"]
     assert j["config"]["collective_launches"] == 20 and 0.0 < j["config"]["collective_mean_ms"] < 5.0, j["config"]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2 --debug-share-gpu` with NO launcher around it (WORLD_SIZE unset) brings up
+    two rank processes by itself and prints ONE line with n_gpus = 2, both ranks' step times, the transports the sums took
+    with call counts, and the one-shot self-test's verdict.  Without --debug-share-gpu on this 1-GPU box the same command
+    must refuse (non-zero status, no JSON line) instead of printing a 1-GPU number."""
+    import json
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--rows", "131072",
+           "--fill", "device", "--no-cpu-baseline", "--preroll-ms", "20"]
+    p = subprocess.run(cmd + ["--debug-share-gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    j = lines[0]
+    assert j["n_gpus"] == 2 and len(j["rank_ms_per_step"]) == 2 and j["steps"] == 20
+    cfgj = j["config"]
+    assert cfgj["ipc_selftest"] == "passed" and cfgj["collective_setup"]["ranks"] == 2, cfgj
+    assert "bench.py itself" in cfgj["launched_by"]
+    assert "one-shot IPC all-reduce" in cfgj["collective"] and "ipc 0," not in cfgj["collective"], cfgj["collective"]
+    assert cfgj["collective_launches"] == 20 and cfgj["collective_mean_ms"] is not None
+    from pymf_amd import _lib
+    if _lib.device_count() < 2:
+        q = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+        assert q.returncode != 0 and q.stdout.decode().strip() == "", (q.returncode, q.stdout.decode())
+        assert "GPU(s) are visible" in q.stderr.decode()
