@@ -192,6 +192,10 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
 /* Tuning knobs (results agree to rounding whatever they say).  Known names:
  *   "oneshot_allreduce" 1 / 0: small cross-rank sums on the one-shot IPC all-reduce (after pmf_ipc_import) or on the
  *                context's other transport.
+ *   "fold_exchange" 1 (default) / 0: inside pmf_factorize's one-pass NMF / BNMF loop the per-iteration sum of
+ *                (W^T V | W^T W) rides on the launches around it -- the slab reduce pushes this rank's partial tiles into
+ *                every peer's receive area, the H-step launch waits for the peers' flags in its prologue and adds the N
+ *                partials in rank order -- instead of a k_ipc_allreduce launch of its own.  Bit-identical either way.
  *   "snmf_w_pipe" snmf_gram = 2 on CSR data: the W = V M write of iteration i runs on a stream of its own beside the k x n
  *                sized kernels of iteration i + 1 (they never read W; M is double buffered); the value is the number of
  *                workgroup slots the write launch leaves free so that those kernels can be placed while it runs (default

@@ -24,6 +24,7 @@
 
 #include "../../include/pymf_hip.h"
 #include "pmf_dev.h"
+#include "pmf_ipc.h"
 #include "pmf_small.h"
 #include "pmf_tiled.h"
 #include "pmf_fused_api.h"  // the one-pass kernels themselves: pmf_fused_tu.hip
@@ -32,7 +33,6 @@
 #include "pmf_csr.h"
 #include "pmf_nndsvd.h"
 #include "pmf_topk.h"
-#include "pmf_ipc.h"
 
 namespace {
 
@@ -177,6 +177,15 @@ struct pmf_ctx {
   float *dIpcTestA = nullptr, *dIpcTestB = nullptr;   // pmf_ipc_selftest's payloads, allocated by pmf_ipc_export (no allocation -- nothing
                                                       // that can fail locally -- between the self-test's collectives)
   unsigned ipc_seq = 0;
+  // the folded exchange (round 5): inside pmf_factorize's one-pass loop the push rides on k_reduce_slabs_tiles and the wait +
+  // rank-ordered sum on k_nmf_h_gram's prologue -- no launch for the exchange (pmf_set_option("fold_exchange", 0): the
+  // k_ipc_allreduce launch of round 4 instead)
+  int opt_fold = 1;
+  bool fold_loop = false;                    // set by nmf_fused_iteration around its two launches
+  unsigned fold_seq = 0;                     // != 0: k_reduce_slabs_tiles has pushed exchange fold_seq, the next k_nmf_h_gram consumes it
+  int fold_flags = 0;                        // tiles (= flags) of that push
+  unsigned long long* dIpcWait = nullptr;    // [2]: ticks of the 100 MHz counter the consumer spent waiting, exchanges counted
+  int64_t fold_calls = 0;
   int* dIpcErr = nullptr;
   int64_t ipc_calls = 0, rccl_calls = 0, host_calls = 0;   // which transport the cross-rank sums took (pmf_collective_name)
   pmf_host_allreduce_fn host_ar = nullptr;   // host transport for the cross-rank sums (pmf_set_host_allreduce)
@@ -469,7 +478,7 @@ int allreduce_sum(pmf_ctx* c, void* p, size_t count, bool f64) {
     // one kernel: every rank writes its partial into every peer's receive area and adds the N partials in rank order
     const unsigned seq = ++c->ipc_seq;
     const int64_t vec = (int64_t)(count + 1023) / 1024;                         // ~1024 elements per workgroup
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vec, PMF_IPC_MAX_WGS));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vec, PMF_IPC_AR_MAX_WGS));
     if (f64) hipLaunchKernelGGL((k_ipc_allreduce<double>), dim3(grid), dim3(256), 0, c->stream, (double*)p, (int64_t)count, c->ipc, seq, c->dIpcErr, c->ipc_wait_ticks);
     else hipLaunchKernelGGL((k_ipc_allreduce<float>), dim3(grid), dim3(256), 0, c->stream, (float*)p, (int64_t)count, c->ipc, seq, c->dIpcErr, c->ipc_wait_ticks);
     HIPCHK(c, hipGetLastError());
@@ -1239,7 +1248,10 @@ int launch_h_gram(pmf_ctx* c) {
   const int final_sum = c->gram_partial_ok ? 0 : 1;
   hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
                      c->dG, (double*)nullptr /* no reader of the float64 copy on the NMF/BNMF paths */, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
-                     c->dGpart, c->dT1part, c->dTicket, c->stop_arg, final_sum);
+                     c->dGpart, c->dT1part, c->dTicket, c->stop_arg, final_sum,
+                     c->fold_seq ? c->ipc : IpcPeers{}, c->fold_seq, c->fold_flags, c->dIpcErr, c->ipc_wait_ticks,
+                     c->profile ? c->dIpcWait : nullptr);
+  c->fold_seq = 0;                    // consumed
   HIPCHK(c, hipGetLastError());
   c->g_parts = final_sum ? 0 : wgs;
   c->trace_parts = final_sum ? 0 : wgs;
@@ -1389,9 +1401,21 @@ int nmf_fused_pass(pmf_ctx* c) {
   {
     const int NTP = c->np / 16;
     const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
+    // the folded exchange: this launch pushes the rank's partial tiles to every peer, the H-step launch behind it waits for
+    // the peers' and adds them in rank order (h_step_from_ps -> launch_h_gram) -- only inside nmf_fused_iteration, where that
+    // launch is certain to follow on every rank
+    const bool fold = c->fold_loop && c->opt_fold && c->ipc.nranks > 1 && ntu <= PMF_IPC_MAX_WGS &&
+                      (size_t)ps_elems(c) * sizeof(float) <= PMF_IPC_MAX_BYTES &&
+                      (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->nb == 1;
+    const unsigned seq = fold ? ++c->ipc_seq : 0u;
     hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
-                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, c->stop_arg);
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, c->stop_arg, fold ? c->ipc : IpcPeers{}, seq);
     HIPCHK(c, hipGetLastError());
+    if (fold) {
+      c->fold_seq = seq; c->fold_flags = ntu;
+      ++c->ipc_calls; ++c->fold_calls;
+      return PMF_OK;                  // dPS becomes the all-rank sum in the prologue of the H-step launch (ps_valid is set there)
+    }
   }
   PMFCHK(allreduce_ps(c));
   c->ps_valid = true;
@@ -1399,7 +1423,10 @@ int nmf_fused_pass(pmf_ctx* c) {
 }
 
 int nmf_fused_iteration(pmf_ctx* c) {
-  PMFCHK(nmf_fused_pass(c));
+  c->fold_loop = true;
+  const int prc = nmf_fused_pass(c);
+  c->fold_loop = false;
+  PMFCHK(prc);
   PMFCHK(h_step_from_ps(c));
   if (c->algo == PMF_ALGO_RNMF) {               // rnmf.py:107: update_h ends with update_s
     c->ps_valid = false;                        // (P | S) were built from D, not from V
@@ -1487,7 +1514,7 @@ int snmf_fused_pass(pmf_ctx* c) {
     const int NTP = c->np / 16;
     const int ntu = c->NT * NTP + c->NT * (c->NT + 1) / 2;
     hipLaunchKernelGGL(k_reduce_slabs_tiles, dim3((unsigned)ntu), dim3(1024), 0, c->stream, c->dSlab,
-                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, c->stop_arg);
+                       c->fused_wgs, c->NT, NTP, c->np, c->dPS, c->stop_arg, IpcPeers{}, 0u);
     HIPCHK(c, hipGetLastError());
   }
   PMFCHK(allreduce_ps(c));
@@ -2289,6 +2316,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (c->ipc.area[c->ipc.me]) (void)hipFree(c->ipc.area[c->ipc.me]);
   }
   if (c->dIpcErr) (void)hipFree(c->dIpcErr);
+  if (c->dIpcWait) (void)hipFree(c->dIpcWait);
   if (c->dIpcTestA) (void)hipFree(c->dIpcTestA);
   if (c->dIpcTestB) (void)hipFree(c->dIpcTestB);
   for (void* p : {(void*)c->dV, (void*)c->dW, (void*)c->dH, (void*)c->dG, (void*)c->dPS, (void*)c->dSlab,
@@ -2971,6 +2999,14 @@ int pmf_collective_ms(pmf_ctx* c, double* mean_ms, int64_t* count) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->coll_ev[q], c->coll_ev[q + 1]) == hipSuccess) { sum += ms; ++n; }
   }
+  if (c->dIpcWait) {
+    // the folded exchanges have no launch to bracket: what they cost an iteration is the consumer's wait for the slowest
+    // peer's flags in k_nmf_h_gram's prologue (ticks of the 100 MHz counter, summed on the device since pmf_profile_enable)
+    unsigned long long w[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(w, c->dIpcWait, sizeof(w), hipMemcpyDeviceToHost));
+    sum += (double)w[0] * 1e-5;        // 100 MHz ticks -> ms
+    n += (int64_t)w[1];
+  }
   *mean_ms = n ? sum / (double)n : 0.0;
   *count = n;
   return PMF_OK;
@@ -2981,6 +3017,7 @@ int pmf_profile_enable(pmf_ctx* c, int32_t on) {
   c->profile = on != 0;
   c->stat.used = 0;
   c->coll_used = 0;
+  if (c->dIpcWait) HIPCHK(c, hipMemsetAsync(c->dIpcWait, 0, 2 * sizeof(unsigned long long), c->stream));
   return PMF_OK;
 }
 
@@ -3099,6 +3136,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     choose_stat_site(c, false);
     return PMF_OK;
   }
+  if (std::strcmp(name, "fold_exchange") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "fold_exchange: 0 or 1");
+    c->opt_fold = (int)value;
+    return PMF_OK;
+  }
   if (std::strcmp(name, "oneshot_allreduce") == 0) {
     if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "oneshot_allreduce: 0 or 1");
     if (value == 1 && c->ipc_nranks_ready <= 1) return fail(c, PMF_EINVAL, "oneshot_allreduce: not set up (pmf_ipc_export / pmf_ipc_import)");
@@ -3184,6 +3226,10 @@ int pmf_ipc_export(pmf_ctx* c, int32_t rank, int32_t nranks, void* handle_out) {
   }
   HIPCHK(c, hipMemsetAsync(area, 0, bytes, c->stream));
   if (!c->dIpcErr) PMFCHK(dalloc(c, &c->dIpcErr, 1));
+  if (!c->dIpcWait) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dIpcWait), 2 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->dIpcWait, 0, 2 * sizeof(unsigned long long), c->stream));
+  }
   // the self-test's two payload buffers, here: everything that can fail on ONE rank alone happens before the ranks vote on
   // "exported"; between the self-test's collectives nothing is allocated
   if (!c->dIpcTestA) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dIpcTestA), PMF_IPC_MAX_BYTES));
@@ -3250,7 +3296,16 @@ int pmf_ipc_selftest(pmf_ctx* c, int32_t rounds, int32_t* ok) {
     if (hipMemcpyAsync(dA, x.data(), cnt * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
         hipMemcpyAsync(dB, x.data(), cnt * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = PMF_EHIP; good = false; }
     c->ipc.nranks = c->ipc_nranks_ready;
-    if (allreduce_sum(c, dA, cnt, false) != PMF_OK) { rc = PMF_EHIP; good = false; }
+    if (t & 1) {
+      // the SPLIT form the loop uses (push inside a producer launch of many workgroups, wait + rank-ordered sum inside a
+      // consumer launch): same slots, flags and sequence counter
+      const unsigned seq = ++c->ipc_seq;
+      const int nfl = 74;                              // the tile count of k_reduce_slabs_tiles at 64 bases x 256 columns
+      hipLaunchKernelGGL(k_ipc_fold_push, dim3(nfl), dim3(256), 0, c->stream, dA, (int64_t)cnt, c->ipc, seq);
+      hipLaunchKernelGGL(k_ipc_fold_pull, dim3(4), dim3(1024), 0, c->stream, dA, (int64_t)cnt, c->ipc, seq, nfl, c->dIpcErr, c->ipc_wait_ticks);
+      if (hipGetLastError() != hipSuccess) { rc = PMF_EHIP; good = false; }
+      ++c->ipc_calls;
+    } else if (allreduce_sum(c, dA, cnt, false) != PMF_OK) { rc = PMF_EHIP; good = false; }
     c->ipc.nranks = 0;                                 // the other transport
     if (allreduce_sum(c, dB, cnt, false) != PMF_OK) { rc = PMF_EHIP; good = false; }
     c->ipc.nranks = c->ipc_nranks_ready;
@@ -3275,8 +3330,9 @@ const char* pmf_collective_name(pmf_ctx* c) {
   if (c->comm) s += std::string(ipc ? " + " : "") + "ncclAllReduce (RCCL)" + (ipc ? " for larger payloads" : "");
   if (c->host_ar) s += std::string(s.empty() ? "" : " + ") + "host transport (pmf_set_host_allreduce)" + (ipc ? " for larger payloads" : "");
   if (s.empty()) s = "none";
-  char buf[96];
-  snprintf(buf, sizeof(buf), " [calls: ipc %lld, rccl %lld, host %lld]", (long long)c->ipc_calls, (long long)c->rccl_calls, (long long)c->host_calls);
+  char buf[160];
+  snprintf(buf, sizeof(buf), " [calls: ipc %lld (%lld of them folded into the slab-reduce / H-step launches), rccl %lld, host %lld]",
+           (long long)c->ipc_calls, (long long)c->fold_calls, (long long)c->rccl_calls, (long long)c->host_calls);
   s += buf;
   return s.c_str();
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_cooperative_groups.h>
 #include "pmf_dev.h"
+#include "pmf_ipc.h"
 
 // NMF H step (pymf/nmf.py:122-126): H <- (H * P) / (S H + 1e-9), P = W^T V, S = W^T W.
 // PS: [KP][np + KP] (P | S).  One block per 16 columns of H; in place.
@@ -71,13 +72,22 @@ constexpr size_t hgram_smem_bytes() { return (size_t)(16 * NT * (16 * NT + 4) + 
 
 template <int NT, bool BNMF>
 __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int np,
-                                                     const float* __restrict__ PS,
+                                                     float* __restrict__ PS,
                                                      float* __restrict__ Gf, double* __restrict__ Gd,
                                                      float lamb, double* __restrict__ tout,
                                                      float* Gpart, double* t1part, unsigned* ticket,
-                                                     const int* __restrict__ stop, int final_sum) {
+                                                     const int* __restrict__ stop, int final_sum,
+                                                     IpcPeers pr, unsigned seq, int nflags, int* __restrict__ ipc_err,
+                                                     unsigned long long wait_ticks, unsigned long long* __restrict__ waitstat) {
+  // pr.nranks > 1 (round 5, the folded exchange): PS is NOT yet summed over the ranks -- every rank's k_reduce_slabs_tiles has
+  // pushed its partial into slot [seq & 1] of this rank's receive area (nflags tiles, one flag each).  The prologue waits for
+  // the flags of all ranks, forms S and its P panels as the sums of the N partials IN RANK ORDER (the bits of
+  // k_ipc_allreduce and of the host transport) while loading them, and writes the sums to PS (S: workgroup 0, P: the owner
+  // of the panel) for whoever reads (W^T V | W^T W) later.
   __shared__ double red[2][16];
   __shared__ unsigned s_last;
+  __shared__ int s_ipc_ok;
+  const bool fold = pr.nranks > 1;
   constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
   constexpr int HT = NT * 4;                  // H-step tiles of a panel
   constexpr int HTW = (HT + 15) / 16;         // ... per wave
@@ -99,13 +109,31 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
   // latencies (a k x n sized problem on a handful of CUs), three of them in a row before this order.
   f32x4 sreg[SQ], hreg[HQ];
   float pv[HTW][4];
-  auto load_panel = [&](int p) {
+  auto load_hpanel = [&](int p) {
     const int c0 = 64 * p;
 #pragma unroll
     for (int u = 0; u < HQ; ++u) {
       const int q = tid + 1024 * u, r = q >> 4, c4 = q & 15;
       if (q < KP * 16) hreg[u] = *reinterpret_cast<const f32x4*>(H + (int64_t)r * np + c0 + 4 * c4);
     }
+  };
+  auto load_pv_fold = [&](int p) {                  // this wave's P values: sums of the ranks' partials, written back to PS
+    const int c0 = 64 * p;
+#pragma unroll
+    for (int h = 0; h < HTW; ++h) {
+      const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t e = (int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i;
+        pv[h][r] = 0.f;
+        if (q < HT) { pv[h][r] = ipc_sum1(pr, seq, e); PS[e] = pv[h][r]; }
+      }
+    }
+  };
+  auto load_panel = [&](int p) {
+    const int c0 = 64 * p;
+    load_hpanel(p);
+    if (fold) { load_pv_fold(p); return; }
     // (an opaque zero in the row index: otherwise the 2 x 4 row pointers of this wave's P values are hoisted out of the
     // panel loop as eight 64-bit registers that live through the whole kernel -- the scratch of the 128-base instantiations)
     int z = 0;
@@ -118,12 +146,33 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
         pv[h][r] = q < HT ? PS[(int64_t)(16 * mt + 4 * kq + r + z) * ldp + c0 + 16 * ct + i] : 0.f;
     }
   };
+  if (fold) {
+    if (stop != nullptr && *stop != 0) return;      // (before the wait: a stopped chunk pushed nothing, on any rank)
+    if (blockIdx.x < npanel) load_hpanel(blockIdx.x);                 // H does not depend on the exchange: in flight during the wait
+    const unsigned long long t0 = wall_clock64();
+    if (!ipc_wait_all(pr, seq, nflags, wait_ticks, &s_ipc_ok)) { if (tid == 0) atomicExch(ipc_err, 1); return; }
+    if (waitstat != nullptr && blockIdx.x == 0 && tid == 0) {         // what the exchange cost this iteration: the wait for the slowest peer
+      atomicAdd(waitstat, wall_clock64() - t0);
+      atomicAdd(waitstat + 1, 1ull);
+    }
 #pragma unroll
-  for (int u = 0; u < SQ; ++u) {
-    const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
-    if (q < KP * (KP / 4)) sreg[u] = *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
+    for (int u = 0; u < SQ; ++u) {
+      const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
+      if (q < KP * (KP / 4)) {
+        const int64_t e = (int64_t)r * ldp + np + 4 * c4;
+        sreg[u] = ipc_sum4(pr, seq, e);
+        if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(PS + e) = sreg[u];
+      }
+    }
+    if (blockIdx.x < npanel) load_pv_fold(blockIdx.x);
+  } else {
+#pragma unroll
+    for (int u = 0; u < SQ; ++u) {
+      const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
+      if (q < KP * (KP / 4)) sreg[u] = *reinterpret_cast<const f32x4*>(PS + (int64_t)r * ldp + np + 4 * c4);
+    }
   }
-  if (blockIdx.x < npanel) load_panel(blockIdx.x);
+  if (!fold && blockIdx.x < npanel) load_panel(blockIdx.x);
   if (stop != nullptr && *stop != 0) return;
 #pragma unroll
   for (int u = 0; u < SQ; ++u) {

@@ -13,6 +13,7 @@
 //   k_resid<NT>        sum((V - W H)^2) partials (pymf/nmf.py:110)
 #pragma once
 #include "pmf_dev.h"
+#include "pmf_ipc.h"
 
 enum { EPI_STORE = 0, EPI_NMF_W = 1, EPI_BNMF_W = 2, EPI_RNMF_W = 3,
        EPI_NMF_W_SAVE = 4,     // EPI_NMF_W + store Num = V H^T to C (first iteration of a fixed-H loop)
@@ -757,12 +758,16 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__
 // Fused-kernel slabs are tile-major (pmf_fused.h): block b sums tile b of every slab (float64,
 // fixed order, wave w takes slabs w, w+16, ...) and scatters it into the row-major (P | S)
 // buffer; S tiles above the diagonal are mirrored.
+// pr.nranks > 1 (round 5, the folded exchange): the reduced tile is this rank's PARTIAL of the cross-rank sum -- instead of
+// `out` it goes straight into slot [seq & 1][me] of every rank's receive area (same row-major (P | S) indices), flag `tile`
+// is raised there, and the consumer (k_nmf_h_gram's prologue) adds the N partials in rank order: no launch for the exchange.
 __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __restrict__ slab, int nslabs,
                                                              int NT, int NTP, int np,
                                                              float* __restrict__ out,
-                                                             const int* __restrict__ stop) {
+                                                             const int* __restrict__ stop, IpcPeers pr, unsigned seq) {
   __shared__ double part[16][64][4];
-  if (stop != nullptr && *stop != 0) return;
+  if (stop != nullptr && *stop != 0) return;       // (rank-consistent: every rank skips the push AND the wait of this exchange)
+  const bool push = pr.nranks > 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int KP = 16 * NT;
   const int NTU = NT * NTP + NT * (NT + 1) / 2;
@@ -787,16 +792,19 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __rest
       // P tile (mt, nt = 4p + e) of the fused kernel holds columns {64p + 4c + e} (lane c) and, in
       // tile row m, basis NT m + mt (the NT tiles of a lane are NT consecutive bases)
       const int mt = tile / NTP, nt = tile % NTP;
-      out[(int64_t)(NT * (4 * kq + r) + mt) * ldp + 64 * (nt >> 2) + 4 * i + (nt & 3)] = v;
+      const int64_t e0 = (int64_t)(NT * (4 * kq + r) + mt) * ldp + 64 * (nt >> 2) + 4 * i + (nt & 3);
+      if (push) ipc_push_f32(pr, seq, e0, v); else out[e0] = v;
     } else {
       int sidx = tile - NT * NTP, mt = 0;
       while (sidx >= NT - mt) { sidx -= NT - mt; ++mt; }
       const int nt = mt + sidx;
       const int row = NT * (4 * kq + r) + mt, col = NT * i + nt;
-      out[(int64_t)row * ldp + np + col] = v;
-      if (nt > mt) out[(int64_t)col * ldp + np + row] = v;
+      const int64_t e0 = (int64_t)row * ldp + np + col, e1 = (int64_t)col * ldp + np + row;
+      if (push) { ipc_push_f32(pr, seq, e0, v); if (nt > mt) ipc_push_f32(pr, seq, e1, v); }
+      else { out[e0] = v; if (nt > mt) out[e1] = v; }
     }
   }
+  if (push) ipc_raise(pr, seq, tile);
 }
 
 // Residual pass over 64 rows per block: R = V - W H with W H on MFMA.

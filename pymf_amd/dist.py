@@ -205,6 +205,11 @@ def _setup_collectives(ctx, w, t):
                 pass
         other = "rccl" if t == "rccl" else "host"
         LAST_SETUP["oneshot"] = "passed" if ok else "failed at %s -> %s" % (stage, other)
+        if ok and os.environ.get("PYMF_DIST_FOLD", "1") == "0":
+            # A/B knob: the per-iteration sum as a k_ipc_allreduce launch of its own instead of folded into the slab-reduce
+            # and H-step launches (bit-identical either way)
+            ctx.set_option("fold_exchange", 0)
+        LAST_SETUP["fold_exchange"] = bool(ok) and os.environ.get("PYMF_DIST_FOLD", "1") != "0"
     return getattr(ctx, "collective_name", "")
 
 

@@ -154,11 +154,19 @@ def test_one_shot_ipc_allreduce_processes_on_one_gpu(size):
                               extra_env={"PYMF_DIST_TRANSPORT": "ipc", "LOCAL_RANK": "0"})
     outs_host = _spawn_workers("_dist_class_worker.py", size, extra_args=["--digest"],
                                extra_env={"PYMF_DIST_TRANSPORT": "host", "LOCAL_RANK": "0"})
-    for a, b in zip(outs_ipc, outs_host):
+    # round 5: by default the loop's exchange is FOLDED into the slab-reduce launch (push) and the H-step launch (wait + sum in
+    # rank order); PYMF_DIST_FOLD=0 runs it as round 4's launch of its own -- all three must give the same bits
+    outs_nofold = _spawn_workers("_dist_class_worker.py", size, extra_args=["--digest"],
+                                 extra_env={"PYMF_DIST_TRANSPORT": "ipc", "LOCAL_RANK": "0", "PYMF_DIST_FOLD": "0"})
+    for a, b, c in zip(outs_ipc, outs_host, outs_nofold):
         da = [l for l in a.splitlines() if l.startswith("digest ")]
         db = [l for l in b.splitlines() if l.startswith("digest ")]
-        assert da and da == db, (da, db)
-        assert any("one-shot IPC all-reduce" in l and "ipc 0," not in l for l in a.splitlines() if l.startswith("collective ")), a
+        dc = [l for l in c.splitlines() if l.startswith("digest ")]
+        assert da and da == db and da == dc, (da, db, dc)
+        assert any("one-shot IPC all-reduce" in l and "ipc 0 " not in l and "(0 of them folded" not in l
+                   for l in a.splitlines() if l.startswith("collective ")), a
+        assert any("one-shot IPC all-reduce" in l and "ipc 0 " not in l and "(0 of them folded" in l
+                   for l in c.splitlines() if l.startswith("collective ")), c
         assert all("one-shot" not in l for l in b.splitlines() if l.startswith("collective ")), b
 
 

@@ -57,7 +57,7 @@ def test_two_rank_bench_line_on_one_gpu():
     assert abs(a - b) <= 0.5 * max(a, b), j["rank_ms_per_step"]       # two processes time-slicing one GPU
     assert abs(j["ms_per_step"] - max(a, b)) < 1e-9 and abs(j["value"] - 1e3 / max(a, b)) < 1e-6 * j["value"]
     assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None
-    assert "one-shot IPC all-reduce" in j["config"]["collective"] and "ipc 0," not in j["config"]["collective"], j["config"]["collective"]
+    assert "one-shot IPC all-reduce" in j["config"]["collective"] and "ipc 0 (" not in j["config"]["collective"], j["config"]["collective"]
     assert j["config"]["collective_launches"] == 20 and 0.0 < j["config"]["collective_mean_ms"] < 5.0, j["config"]
 
 
@@ -83,7 +83,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     cfgj = j["config"]
     assert cfgj["ipc_selftest"] == "passed" and cfgj["collective_setup"]["ranks"] == 2, cfgj
     assert "bench.py itself" in cfgj["launched_by"]
-    assert "one-shot IPC all-reduce" in cfgj["collective"] and "ipc 0," not in cfgj["collective"], cfgj["collective"]
+    assert "one-shot IPC all-reduce" in cfgj["collective"] and "ipc 0 (" not in cfgj["collective"], cfgj["collective"]
     assert cfgj["collective_launches"] == 20 and cfgj["collective_mean_ms"] is not None
     from pymf_amd import _lib
     if _lib.device_count() < 2:

@@ -19,7 +19,7 @@ int main(int argc, char** argv){
   for (int wgs = 1; wgs <= NP/64; wgs *= 2){
     for (int rep=0; rep<2; ++rep){
       hipEventRecord(e0);
-      for(int it=0; it<200; ++it) k_nmf_h_gram<NT,false><<<wgs,1024,smem>>>(H,NP,PS,G,(argc>2)?nullptr:Gd,0.f,(it&1)?tout:nullptr,Gpart,t1p,ticket,nullptr,(argc>3)?0:1);
+      for(int it=0; it<200; ++it) k_nmf_h_gram<NT,false><<<wgs,1024,smem>>>(H,NP,PS,G,(argc>2)?nullptr:Gd,0.f,(it&1)?tout:nullptr,Gpart,t1p,ticket,nullptr,(argc>3)?0:1,IpcPeers{},0u,0,nullptr,0ull,nullptr);
       hipEventRecord(e1); CK(hipDeviceSynchronize());
       float ms; hipEventElapsedTime(&ms,e0,e1);
       if (rep) printf("np=%d wgs=%d: %.2f us/launch back to back\n", NP, wgs, ms*1000/200);
