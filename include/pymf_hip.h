@@ -192,6 +192,8 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
 /* Tuning knobs (results agree to rounding whatever they say).  Known names:
  *   "oneshot_allreduce" 1 / 0: small cross-rank sums on the one-shot IPC all-reduce (after pmf_ipc_import) or on the
  *                context's other transport.
+ *   "profile_every" N >= 1 (default 1): with pmf_profile_enable only every N-th launch of the dominant kernel (and of the
+ *                per-iteration collective) carries HIP events -- a timed launch costs the loop about 5 us.
  *   "fold_exchange" 1 (default) / 0: inside pmf_factorize's one-pass NMF / BNMF loop the per-iteration sum of
  *                (W^T V | W^T W) rides on the launches around it -- the slab reduce pushes this rank's partial tiles into
  *                every peer's receive area, the H-step launch waits for the peers' flags in its prologue and adds the N

@@ -50,6 +50,11 @@ struct KernelStat {
   double flops = 0.0, bytes = 0.0, exec_flops = 0.0;
   std::vector<hipEvent_t> ev;   // pairs
   size_t used = 0;              // events recorded since reset
+  int every = 1;                // pmf_set_option("profile_every", N): only every N-th launch of the site carries events -- a pair costs
+                                // the loop ~5 us (the queue processes two more packets and the dispatch's completion signal): 8 % of a
+                                // 60 us iteration when every launch is timed (tools/loop_probe.py, profiles/r05_experiments.md)
+  int64_t seen = 0;             // launches of the site since reset
+  bool open = false;            // stat_begin recorded, stat_end to follow
 };
 
 }  // namespace
@@ -187,6 +192,7 @@ struct pmf_ctx {
   unsigned long long* dIpcWait = nullptr;    // [2]: ticks of the 100 MHz counter the consumer spent waiting, exchanges counted
   int64_t fold_calls = 0;
   int* dIpcErr = nullptr;
+  int64_t coll_seen = 0;
   int64_t ipc_calls = 0, rccl_calls = 0, host_calls = 0;   // which transport the cross-rank sums took (pmf_collective_name)
   pmf_host_allreduce_fn host_ar = nullptr;   // host transport for the cross-rank sums (pmf_set_host_allreduce)
   void* host_ar_user = nullptr;
@@ -256,6 +262,8 @@ int ensure_dv(pmf_ctx* c) {
 void stat_begin(pmf_ctx* c, int site) {
   if (!c->profile || c->stat.site != site) return;
   KernelStat& s = c->stat;
+  s.open = false;
+  if (s.seen++ % s.every != 0) return;
   if (s.used + 2 > s.ev.size()) {
     for (int q = 0; q < 2; ++q) {
       hipEvent_t e;
@@ -264,11 +272,29 @@ void stat_begin(pmf_ctx* c, int site) {
     }
   }
   (void)hipEventRecord(s.ev[s.used], c->stream);   // profiling aid: a failed record only loses a sample
+  s.open = true;
+}
+// The next pair of events of site `site`, to be attached to a dispatch (hipExtLaunchKernelGGL); nullptr when not profiling.
+void stat_pair(pmf_ctx* c, int site, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!c->profile || c->stat.site != site) return;
+  KernelStat& s = c->stat;
+  if (s.seen++ % s.every != 0) return;
+  if (s.used + 2 > s.ev.size()) {
+    for (int q = 0; q < 2; ++q) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      s.ev.push_back(e);
+    }
+  }
+  *e0 = s.ev[s.used]; *e1 = s.ev[s.used + 1];
+  s.used += 2;
 }
 void stat_end(pmf_ctx* c, int site) {
   if (!c->profile || c->stat.site != site) return;
   KernelStat& s = c->stat;
-  if (s.used + 2 > s.ev.size()) return;
+  if (!s.open || s.used + 2 > s.ev.size()) return;
+  s.open = false;
   (void)hipEventRecord(s.ev[s.used + 1], c->stream);
   s.used += 2;
 }
@@ -525,7 +551,7 @@ int allreduce_ps(pmf_ctx* c) {
   // (timed only where the sum is a device operation on the stream: the one-shot kernel or ncclAllReduce -- a payload that
   //  falls back to the blocking host round trip has nothing for HIP events to bracket)
   const bool on_stream = (c->ipc.nranks > 1 && (size_t)ps_elems(c) * sizeof(float) <= PMF_IPC_MAX_BYTES) || (!c->host_ar && c->comm);
-  const bool timed = c->profile && multi_rank(c) && on_stream;
+  const bool timed = c->profile && multi_rank(c) && on_stream && (c->coll_seen++ % c->stat.every == 0);   // sampled like the kernel's
   if (timed) {
     if (c->coll_used + 2 > c->coll_ev.size())
       for (int q = 0; q < 2; ++q) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) c->coll_ev.push_back(e); }
@@ -1391,11 +1417,11 @@ int nmf_fused_pass(pmf_ctx* c) {
     return PMF_OK;
   }
   const FusedCtl ctl = take_fused_ctl(c);
-  stat_begin(c, SITE_FUSED);
+  hipEvent_t se0 = nullptr, se1 = nullptr;
+  stat_pair(c, SITE_FUSED, &se0, &se1);          // (profiling: the pair rides on the dispatch itself, no barrier packets in the loop)
   const int lrc = pmf_launch_fused(c->stream, rn ? FUSED_RNMF : c->algo == PMF_ALGO_BNMF ? FUSED_BNMF : FUSED_NMF, c->NT,
                                c->np, rn ? c->dD : c->dV, c->dW, c->dH, Gsrc, c->mp, c->fused_wgs, (float)c->lamb_w,
-                               c->dSlab, ctl, ngp);
-  stat_end(c, SITE_FUSED);
+                               c->dSlab, ctl, ngp, se0, se1);
   if (lrc != PMF_OK) return fail(c, lrc, "fused kernel launch failed");
   HIPCHK(c, hipGetLastError());
   {
@@ -3016,6 +3042,9 @@ int pmf_profile_enable(pmf_ctx* c, int32_t on) {
   if (!c) return PMF_EINVAL;
   c->profile = on != 0;
   c->stat.used = 0;
+  c->stat.seen = 0;
+  c->stat.open = false;
+  c->coll_seen = 0;
   c->coll_used = 0;
   if (c->dIpcWait) HIPCHK(c, hipMemsetAsync(c->dIpcWait, 0, 2 * sizeof(unsigned long long), c->stream));
   return PMF_OK;
@@ -3134,6 +3163,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     c->ps_valid = false; c->num_valid = false; c->trace_ready = false;
     if (c->g_parts > 0) { c->g_valid = false; c->g_parts = 0; }
     choose_stat_site(c, false);
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "profile_every") == 0) {
+    if (value < 1 || value > 1 << 20) return fail(c, PMF_EINVAL, "profile_every: 1 .. 2^20");
+    c->stat.every = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "fold_exchange") == 0) {

@@ -30,6 +30,7 @@
 // (__launch_bounds__(256, 1)) so the 512-entry unified VGPR/AGPR file holds them.
 #pragma once
 #include "pmf_dev.h"
+#include <hip/hip_ext.h>
 #include "../../include/pymf_hip.h"
 #include "pmf_fused_api.h"   // FUSED_*, FusedCtl
 
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   if (ctl.stop != nullptr && *ctl.stop != 0) return;
 #ifdef PMF_STAMPS
   unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+  const unsigned long long rt0 = wall_clock64();     // 100 MHz constant-rate counter: comparable across CUs and with the host's events
   PMF_STAMP(tk0);
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -605,6 +607,10 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
   __syncthreads();
   if (wv < 2) put(wv);
   __syncthreads();
+  // (round 5, tools/r05_ab.sh: a tail in which every tile is finished by ONE wave -- the others hand it over through LDS once, three
+  //  rounds over two buffers, slab stores beside the next round's LDS traffic, same summation order and bits -- measured 84.5 -> 83.9 us
+  //  on the 131 072-row shard and 594.0 -> 596.0 us at 1 048 576 rows: the tail is bound by the 18.5 MiB of slab stores all 256
+  //  workgroups issue at the same moment, not by its LDS traffic or its three barriers.  Not kept.)
   if (SPLIT == 1) {
     f32x4* out = reinterpret_cast<f32x4*>(slab) + (size_t)blockIdx.x * NTU * 64 + lane;
     for (int t = wv; t < NTU; t += 4)
@@ -624,9 +630,10 @@ __global__ __launch_bounds__(256, 1) void k_nmf_fused(const float* __restrict__ 
 #ifdef PMF_STAMPS
   PMF_STAMP(tk3);
   if (dbg && lane == 0) {
-    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + wv) * 12;
     d[0] = acc_wait; d[1] = acc_a; d[2] = acc_dma; d[3] = acc_epi; d[4] = acc_b; d[5] = (unsigned long long)nb;
     d[6] = tk1 - tk0; d[7] = tk3 - tk2;
+    d[8] = rt0; d[9] = wall_clock64(); d[10] = tk3 - tk0; d[11] = tk2 - tk1;
   }
 #endif
 }
@@ -673,7 +680,8 @@ static inline const char* fused_kernel_name(int NT, int np, int mode = FUSED_NMF
 
 template <int NT, int NPANEL, int MODE, int SPLIT = 1>
 static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* H, const float* G,
-                          int64_t mp, int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp) {
+                          int64_t mp, int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp,
+                          hipEvent_t e0, hipEvent_t e1) {
   const int nblk = (int)(mp / 16), nw = wgs * (SPLIT == 2 ? 2 : 4);   // waves, or pairs of waves
   const int blk_per = nblk / nw, blk_extra = nblk % nw;
   const size_t smem = fused_smem_bytes<NT, NPANEL, SPLIT>();
@@ -685,22 +693,29 @@ static int launch_fused_t(hipStream_t s, const float* V, float* W, const float* 
       return PMF_EHIP;
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE, SPLIT>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
-                     blk_extra, lamb, slab, ctl, ngp);
+  // e0 / e1 (pmf_profile_enable): the events ride on the DISPATCH packet itself (hipExtLaunchKernelGGL: start / stop stamps of
+  // this kernel, what rocprofv3 reports) instead of two hipEventRecord barrier packets around it -- those cost the loop 6 us per
+  // iteration (65 536 x 512, k = 32: 59.3 -> 65.3 us; profiles/r05_experiments.md) and read 5 us long
+  if (e0 != nullptr && e1 != nullptr)
+    hipExtLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE, SPLIT>), dim3(wgs), dim3(256), (uint32_t)smem, s, e0, e1, 0u, V, W, H, G, blk_per,
+                          blk_extra, lamb, slab, ctl, ngp);
+  else
+    hipLaunchKernelGGL((k_nmf_fused<NT, NPANEL, MODE, SPLIT>), dim3(wgs), dim3(256), smem, s, V, W, H, G, blk_per,
+                       blk_extra, lamb, slab, ctl, ngp);
   return PMF_OK;
 }
 
 // G: H H^T [KP][KP] float32 (NMF, BNMF, RNMF).  FUSED_SNMF: H is M^T = inv(H H^T) H and G is unused.
 static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W,
                                const float* H, const float* G, int64_t mp, int wgs, float lamb,
-                               float* slab, const FusedCtl& ctl, int ngp = 0) {
+                               float* slab, const FusedCtl& ctl, int ngp = 0, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (!fused_shape_ok(NT, np) && fused_shape_split(NT, np) && mode != FUSED_SNMF) {
     const int skey = NT * 10 + np / 128;
 #define PMF_FUSED_SPLIT_CASE(K, A, B)                                                                   \
   case K:                                                                                               \
-    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
-           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
-                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp);
+    return mode == FUSED_BNMF   ? launch_fused_t<A, B, FUSED_BNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1) \
+                                : launch_fused_t<A, B, FUSED_NMF, 2>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1);
     switch (skey) {
       PMF_FUSED_SPLIT_CASE(14, 1, 4)
       PMF_FUSED_SPLIT_CASE(23, 2, 3)
@@ -712,10 +727,10 @@ static inline int launch_fused(hipStream_t s, int mode, int NT, int np, const fl
   const int key = NT * 10 + np / 64;
 #define PMF_FUSED_CASE(K, A, B)                                                                  \
   case K:                                                                                        \
-    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
-           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
-           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp) \
-                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp);
+    return mode == FUSED_SNMF   ? launch_fused_t<A, B, FUSED_SNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1) \
+           : mode == FUSED_BNMF ? launch_fused_t<A, B, FUSED_BNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1) \
+           : mode == FUSED_RNMF ? launch_fused_t<A, B, FUSED_RNMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1) \
+                                : launch_fused_t<A, B, FUSED_NMF>(s, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1);
   switch (key) {
     PMF_FUSED_CASE(11, 1, 1)
     PMF_FUSED_CASE(12, 1, 2)

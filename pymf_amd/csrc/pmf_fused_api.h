@@ -29,7 +29,7 @@ int pmf_fused_grid_for(int NT, int np, int64_t mp, bool allow_split);
 const char* pmf_fused_kernel_name(int NT, int np, int mode);
 // G: H H^T [KP][KP] float32 (NMF, BNMF, RNMF).  FUSED_SNMF: H is M^T = inv(H H^T) H and G is unused.
 int pmf_launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W, const float* H, const float* G, int64_t mp,
-                     int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp);
+                     int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // the cooperative form (64 < k <= 128, or k <= 64 with 256 < n <= 512)
 bool pmf_coop_shape(int NT, int np, int* bt, int* rb, int* npanel);
 int pmf_coop_pad_np(int NT, int np);

@@ -8,8 +8,8 @@
 int pmf_fused_grid_for(int NT, int np, int64_t mp, bool allow_split) { return fused_grid_for(NT, np, mp, allow_split); }
 const char* pmf_fused_kernel_name(int NT, int np, int mode) { return fused_kernel_name(NT, np, mode); }
 int pmf_launch_fused(hipStream_t s, int mode, int NT, int np, const float* V, float* W, const float* H, const float* G, int64_t mp,
-                     int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp) {
-  return launch_fused(s, mode, NT, np, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp);
+                     int wgs, float lamb, float* slab, const FusedCtl& ctl, int ngp, hipEvent_t e0, hipEvent_t e1) {
+  return launch_fused(s, mode, NT, np, V, W, H, G, mp, wgs, lamb, slab, ctl, ngp, e0, e1);
 }
 bool pmf_coop_shape(int NT, int np, int* bt, int* rb, int* npanel) { return coop_shape(NT, np, bt, rb, npanel); }
 int pmf_coop_pad_np(int NT, int np) { return coop_pad_np(NT, np); }

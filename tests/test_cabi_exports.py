@@ -152,7 +152,7 @@ def test_every_documented_option_is_known_to_the_library(lib):
     block = text[text.index("Tuning knobs"):text.index("int pmf_set_option")]
     names = re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)
     assert set(names) >= {"snmf_gram", "nnqp_quad", "force_tiled", "rowgemm_stream", "colgemm_stream", "nndsvd_topk", "nnqp_frame16"}, names
-    defaults = {"snmf_gram": -1, "nnqp_quad": 1, "force_tiled": 0, "rowgemm_stream": 1, "colgemm_stream": 1, "nndsvd_topk": -1, "nnqp_frame16": 1}
+    defaults = {"snmf_gram": -1, "nnqp_quad": 1, "force_tiled": 0, "rowgemm_stream": 1, "colgemm_stream": 1, "nndsvd_topk": -1, "nnqp_frame16": 1, "profile_every": 1, "fold_exchange": 1}
     ctx = _lib.Context(_lib.ALGO_NMF, 256, 64, 8)
     for name in names:
         ctx.set_option(name, defaults.get(name, 0))
