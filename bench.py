@@ -115,13 +115,15 @@ def _time_loop(step, budget_s, min_iters=3, max_iters=50):
             return it, dt
 
 
-def cpu_baseline(cfg, m, n, k, budget_s=24.0):
+def cpu_baseline(cfg, m, n, k, budget_s=24.0, sample=None):
     """The oracle (NumPy restatement of the reference, its op order) on this host's cores.
     cfg4 / cfg2: FULL size, reference-default operands (float64 W/H, float32 V) = `value`, the all-float32
     variant alongside.  cfg3 / cfg5: a bounded row sample, scaled -- stated in `sample`."""
     import oracle
     algo = CONFIGS[cfg][0]
-    out = {"unit": "iter/s", "cores": _blas_threads(), "kind": "port"}
+    out = {"unit": "iter/s", "cores": _blas_threads(), "kind": "port", "host_cpus": os.cpu_count() or 1}
+    # (BASELINE.md section 3 says "all host cores": the BLAS build caps its pool -- OpenBLAS: 64 threads on these boxes)
+    out["threads_note"] = "%d BLAS threads (the BLAS build's thread cap) of %d CPUs" % (out["cores"], out["host_cpus"])
     host = "numpy %s, host cpu_count=%d" % (np.__version__, os.cpu_count() or 1)
     if algo == "NMF":
         V = gen_rows(np.random.RandomState(1234), m, n, 0, m)
@@ -140,15 +142,52 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0):
         it, dt = _time_loop(step64, budget_s * 0.7)
         # the float64-default factors after 1 + it iterations from W0 / H0: what the device is compared with at FULL size
         # (main(): `parity_full_size`); the timing loop is the parity run -- nothing is thrown away
-        keep = {"iters": 1 + it, "W": W.copy(), "H": H.copy()}
+        keep = {"iters": 1 + it, "W": W.copy(), "H": H.copy(),
+                "ferr": float(oracle.frobenius_norm(V, W, H))}       # nmf.py:100-114 at full size, float64
         it32, dt32 = _time_loop(step32, budget_s * 0.3)
         out["_oracle_factors"] = keep
         out.update(value=it / dt, value_all_fp32=it32 / dt32,
                    sample="oracle NMF (reference op order, float64 W/H, float32 V) at FULL size %dx%d k=%d: "
                           "1 warm-up + %d iterations in %.2f s; all-float32 variant: %d iterations in %.2f s; %s"
                           % (m, n, k, it, dt, it32, dt32, host))
-    elif algo == "NMFALS":
-        ms = min(m, 256)                          # rows of the W half step in the sample
+    elif algo == "NMFALS" and sample is not None:
+        # The QPs timed here ARE the full-size parity check: `sample` holds, from the device's first iteration
+        # at FULL size from the seeded W0 / H0, (a) 256 rows of V spread over the matrix and the device's W rows for them --
+        # the row QPs of nmfals.py:85-97 depend on H0 and the row alone --, (b) for 256 columns the Hessian W1^T W1 and the
+        # right-hand sides W1^T v_i over ALL 262 144 rows of the device's W1 (float64 on the host) and the device's H columns.
+        ms, ns = len(sample["rows"]), len(sample["cols"])
+        H0 = np.asarray(sample["H0"], dtype=np.float64)
+        HAw = np.float64(np.dot(H0, H0.T))                                    # nmfals.py:93
+        t0 = time.time()
+        Wo = np.empty((ms, k))
+        for q in range(ms):
+            Wo[q] = oracle.nnqp_solve(HAw, np.float64(np.dot(-H0, sample["Vrows"][q].astype(np.float64))))   # :88-90
+        tw = time.time() - t0
+        t0 = time.time()
+        Ho = np.empty((k, ns))
+        for q in range(ns):
+            Ho[:, q] = oracle.nnqp_solve(sample["HA_h"], -sample["FA_cols"][:, q])    # :73-75 (HA = W^T W, FA = -W^T v)
+        th = time.time() - t0
+        per_iter = tw * m / ms + th * n / ns
+        Wd, Hd = sample["Wd_rows"].astype(np.float64), sample["Hd_cols"].astype(np.float64)
+        out["_parity"] = {
+            "iters": 1, "rows": int(ms), "cols": int(ns),
+            "relW_rows": float(np.linalg.norm(Wd - Wo) / np.linalg.norm(Wo)),
+            "relH_cols": float(np.linalg.norm(Hd - Ho) / np.linalg.norm(Ho)),
+            "max_abs_W": float(np.max(np.abs(Wd - Wo))), "max_abs_H": float(np.max(np.abs(Hd - Ho))),
+            "zero_pattern_mismatches_W": int(np.sum((Wd == 0) != (Wo == 0))),
+            "tolerance": 1e-4,
+            "against": "oracle.nnqp_solve (exact float64 active set; nmfals.py:70-97) on %d rows / %d columns spread over the "
+                       "FULL %dx%d problem, k=%d, first iteration from the seeded W0 / H0: the row QPs with HA = H0 H0^T, the "
+                       "column QPs with HA = W1^T W1 and W1^T v_i over all rows of the device's W1 (float64 on the host); "
+                       "||X_gpu - X_ref||_F / ||X_ref||_F over the sampled rows / columns" % (ms, ns, m, n, k)}
+        out.update(value=1.0 / per_iter,
+                   sample="oracle NMFALS (exact active-set QP per row / column, float64, one Python-level solve per "
+                          "sub-problem like the reference's cvxopt calls): %d of %d W rows in %.2f s, %d of %d H columns "
+                          "in %.2f s, scaled to %d + %d QPs of dimension %d per iteration; %s"
+                          % (ms, m, tw, ns, n, th, m, n, k, host))
+    elif algo == "NMFALS":                        # no host copy of V at hand (device fill): a sample problem, timing only
+        ms = min(m, 256)
         V = gen_rows(np.random.RandomState(1234), m, n, 0, ms)
         np.random.seed(42)
         W = np.random.random((m, k))[:ms]
@@ -157,19 +196,16 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0):
         o.W, o.H = W.copy(), H.copy()
         t0 = time.time()
         o.update_w()
-        tw = time.time() - t0                     # ms QPs of the W half step
+        tw = time.time() - t0
         ns = min(n, 256)
         o2 = oracle.NMFALSOracle(V[:, :ns], num_bases=k)
         o2.W, o2.H = o.W.copy(), H[:, :ns].copy()
         t0 = time.time()
         o2.update_h()
-        th = time.time() - t0                     # ns QPs of the H half step (Hessian of the sample's W)
-        per_iter = tw * m / ms + th * n / ns
-        out.update(value=1.0 / per_iter,
-                   sample="oracle NMFALS (exact active-set QP per row / column, float64, one Python-level solve per "
-                          "sub-problem like the reference's cvxopt calls): %d of %d W rows in %.2f s, %d of %d H columns "
-                          "in %.2f s, scaled to %d + %d QPs of dimension %d per iteration; %s"
-                          % (ms, m, tw, ns, n, th, m, n, k, host))
+        th = time.time() - t0
+        out.update(value=1.0 / (tw * m / ms + th * n / ns),
+                   sample="oracle NMFALS on a sample problem (%d rows, %d columns), scaled to %d + %d QPs of dimension %d; %s"
+                          % (ms, ns, m, n, k, host))
     else:                                         # SNMF on the densified sample (the reference cannot take CSR)
         ms = min(m, 131072)
         ip, ix, vv = gen_csr(m, n, 0.01, 0, ms, fast=True)
@@ -185,6 +221,9 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0):
             o.update_w()
             o.update_h()
         it, dt = _time_loop(step, budget_s)
+        # what the device is compared with (main(): `parity_full_size`): the same 131 072-row block as a problem of its own,
+        # same W0 / H0, same 1 + it iterations -- H is replicated, so its H is what any rank of the sharded run iterates on
+        out["_oracle_factors"] = {"iters": 1 + it, "W": np.array(o.W), "H": np.array(o.H), "csr": (ip, ix, vv), "ms": ms}
         out.update(value=(it / dt) * ms / float(m),
                    sample="oracle SNMF (snmf.py:67-91) on V.toarray() of the first %d of %d rows (the reference has no "
                           "sparse path), n=%d k=%d: %d iterations in %.2f s, scaled by %d/%d (cost is linear in rows); %s"
@@ -556,6 +595,25 @@ def main():
             if mdl._ctx is not None:
                 mdl._ctx.close()
         del mdl
+    als_sample = None
+    if (algo_name == "NMFALS" and w.size == 1 and not args.no_cpu_baseline and "W0" in host and "V" in host
+            and not hasattr(host["V"], "tocsr")):
+        # one iteration at FULL size from the seeded start, kept for the oracle (cpu_baseline times exactly these QPs)
+        ctx.set_w(host["W0"]); ctx.set_h(host["H0"])
+        ctx.update_w()
+        Wd = ctx.get_w()
+        ctx.update_h()
+        Hd = ctx.get_h()
+        rows = np.arange(0, m, max(m // 256, 1))[:256]
+        cols = np.arange(0, n, max(n // 256, 1))[:256]
+        HA_h = np.zeros((k, k)); FA = np.zeros((k, len(cols)))
+        for r0 in range(0, m, 32768):                      # float64 on the host, in row chunks
+            Wc = Wd[r0:r0 + 32768].astype(np.float64)
+            HA_h += Wc.T.dot(Wc)
+            FA += Wc.T.dot(host["V"][r0:r0 + 32768][:, cols].astype(np.float64))
+        als_sample = {"rows": rows, "cols": cols, "Vrows": host["V"][rows].copy(), "H0": np.array(host["H0"]),
+                      "Wd_rows": Wd[rows].copy(), "Hd_cols": Hd[:, cols].copy(), "HA_h": HA_h, "FA_cols": FA}
+        del Wd, Hd
     host.clear()
 
     if w.rank == 0:
@@ -689,10 +747,40 @@ def main():
                                      "own beside the k x n sized kernels of iteration i + 1 (option snmf_w_pipe; 0 = stream order)"
                                      if stats["name"].startswith("k_csr_w") else "one pass over the CSR rows per iteration")
         if w.size == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.config, m, n, k)
+            cb = cpu_baseline(args.config, m, n, k, sample=als_sample)
             fac = cb.pop("_oracle_factors", None)
+            par = cb.pop("_parity", None)
             out["cpu_baseline"] = cb
-            if fac is not None and args.fill == "numpy":
+            if par is not None:
+                out["parity_full_size"] = par
+            if fac is not None and "csr" in fac:
+                # cfg5: the oracle's row block fed to the device as its own CSR problem, same seeded
+                # W0 / H0, same iteration count, the headline loop (W written every iteration)
+                ip, ix, vv = fac["csr"]
+                c2 = _lib.Context(algo, fac["ms"], n, k, device=0 if args.debug_share_gpu else w.local_rank)
+                try:
+                    c2.set_v_csr(ip, ix, vv)
+                    c2.set_option("snmf_gram", args.snmf_gram if args.snmf_gram >= 0 else 2)
+                    np.random.seed(42)
+                    c2.set_w(np.random.random((fac["ms"], k)))
+                    c2.set_h(np.random.random((k, n)))
+                    _, done_p, _ = c2.factorize(fac["iters"], compute_err=False)
+                    Wd, Hd = c2.get_w(), c2.get_h()
+                finally:
+                    c2.close()
+                rows = np.arange(0, fac["ms"], 257)
+                out["parity_full_size"] = {
+                    "iters": int(done_p),
+                    "relW": float(np.linalg.norm(Wd - fac["W"]) / np.linalg.norm(fac["W"])),
+                    "relW_rows_sampled": float(np.linalg.norm(Wd[rows] - fac["W"][rows]) / np.linalg.norm(fac["W"][rows])),
+                    "relH": float(np.linalg.norm(Hd - fac["H"]) / np.linalg.norm(fac["H"])),
+                    "H_min": float(Hd.min()), "tolerance": 1e-4,
+                    "against": "oracle SNMF (snmf.py:67-91, float64 W/H) on V.toarray() of a %d-row block of the cfg5 matrix (n=%d, "
+                               "k=%d) fed to the device as its own CSR problem: same seeded W0/H0, same %d iterations; H is "
+                               "replicated in the row-sharded run, so this is the H every rank iterates on for that block; "
+                               "||X_gpu - X_ref||_F / ||X_ref||_F (W crosses zero: Frobenius-relative only)" % (fac["ms"], n, k, fac["iters"])}
+                del Wd, Hd, fac
+            elif fac is not None and args.fill == "numpy":
                 # FULL-SIZE parity: the device from the same W0 / H0 for the same number of iterations as the
                 # float64-default oracle just ran for its timing -- every row of W, all of H
                 np.random.seed(42)
@@ -701,8 +789,11 @@ def main():
                 ctx.set_h(np.random.random((k, n)))
                 _, done_p, _ = ctx.factorize(fac["iters"], compute_err=False)
                 Wd, Hd = ctx.get_w(), ctx.get_h()
+                ferr_d = ctx.frobenius()                   # frobenius_norm() of the same state (nmf.py:100-114)
                 out["parity_full_size"] = {
                     "iters": int(done_p),
+                    "relferr": float(abs(ferr_d - fac["ferr"]) / fac["ferr"]), "ferr_gpu": float(ferr_d), "ferr_ref": fac["ferr"],
+                    "tolerance_ferr": 1e-5,
                     "relW": float(np.linalg.norm(Wd - fac["W"]) / np.linalg.norm(fac["W"])),
                     "relH": float(np.linalg.norm(Hd - fac["H"]) / np.linalg.norm(fac["H"])),
                     "max_abs_W": float(np.max(np.abs(Wd - fac["W"]))),

@@ -294,6 +294,12 @@ int pmf_kernel_launch_ms(pmf_ctx* ctx, double* out_ms, int64_t cap, int64_t* cou
 int pmf_nnqp_counters(pmf_ctx* ctx, int64_t* out8, int32_t reset);
 
 int pmf_synchronize(pmf_ctx* ctx);
+/* The ONE entry point that may be called from a second host thread while pmf_factorize runs on the context: on = 1 makes the
+ * running (or the next) pmf_factorize return at its next iteration / chunk boundary with *iters_done = what it completed;
+ * on = 0 clears the request.  The host class runs its digest of `data` (the reference re-reads self.data[:,:] in every hook,
+ * nmf.py:123,129) BESIDE the device loop and, should the bytes have changed since the upload, stops the loop, puts W / H back
+ * (pmf_restore_w, pmf_set_h_*), uploads and starts again. */
+int pmf_abort(pmf_ctx* ctx, int32_t on);
 
 /* Introspection used by tests: which code path update_w/update_h take for this shape.
  * Returns a static string such as "fused_k64_n256" or "tiled". */

@@ -28,6 +28,17 @@ def nmf_update_h(V, W, H):
     return H
 
 
+def _issparse(x):
+    """scipy.sparse.issparse (nmf.py:109) without importing scipy for dense data: a sparse matrix is never an ndarray."""
+    if isinstance(x, np.ndarray):
+        return False
+    try:
+        import scipy.sparse
+        return bool(scipy.sparse.issparse(x))
+    except ImportError:
+        return False
+
+
 def frobenius_norm(V, W, H):
     """nmf.py:100-114 -- sqrt(sum((V - W H)^2))."""
     return np.sqrt(np.sum((V - np.dot(W, H)) ** 2))   # :110
@@ -46,7 +57,7 @@ class NMFOracle(object):
         (self._data_dimension, self._num_samples) = data.shape   # :97
 
     def frobenius_norm(self):
-        if hasattr(self, 'H') and hasattr(self, 'W'):      # :109
+        if hasattr(self, 'H') and hasattr(self, 'W') and not _issparse(self.data):   # :109 (both halves of the condition)
             return frobenius_norm(self.data[:, :], self.W, self.H)
         return SENTINEL                                    # :112
 

@@ -83,6 +83,7 @@ SYMBOLS = [
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("pmf_nnqp_counters", _c.c_int, [_ctx, _c.POINTER(_c.c_int64), _c.c_int32]),
     ("pmf_synchronize", _c.c_int, [_ctx]),
+    ("pmf_abort", _c.c_int, [_ctx, _c.c_int32]),
     ("pmf_path_name", _c.c_char_p, [_ctx]),
 ]
 
@@ -427,3 +428,8 @@ class Context(object):
 
     def synchronize(self):
         self._chk(self._lib.pmf_synchronize(self._h))
+
+    def abort(self, on=True):
+        """Ask the running (or next) factorize() of this context to return early / clear the request (pmf_abort; the one
+        call that may come from a second thread)."""
+        self._chk(self._lib.pmf_abort(self._h, 1 if on else 0))

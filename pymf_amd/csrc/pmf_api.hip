@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -182,6 +183,7 @@ struct pmf_ctx {
   float *dIpcTestA = nullptr, *dIpcTestB = nullptr;   // pmf_ipc_selftest's payloads, allocated by pmf_ipc_export (no allocation -- nothing
                                                       // that can fail locally -- between the self-test's collectives)
   unsigned ipc_seq = 0;
+  std::atomic<int> abort_flag{0};            // pmf_abort: another host thread asks the running pmf_factorize loop to return early
   // the folded exchange (round 5): inside pmf_factorize's one-pass loop the push rides on k_reduce_slabs_tiles and the wait +
   // rank-ordered sum on k_nmf_h_gram's prologue -- no launch for the exchange (pmf_set_option("fold_exchange", 0): the
   // k_ipc_allreduce launch of round 4 instead)
@@ -2616,6 +2618,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
   constexpr int kHostIters = 1, kChunk = 32;
   bool free_run = false;
   for (int i = 0; i < niter; ++i) {                       // nmf.py:182
+    if (c->abort_flag.load(std::memory_order_relaxed) != 0) break;   // pmf_abort: the caller discards this run (iters_done says how far it got)
     if (free_run) {
       const int chunk = std::min(kChunk, niter - i);
       c->stop_arg = c->dStop;
@@ -3417,6 +3420,12 @@ int pmf_kernel_launch_ms(pmf_ctx* c, double* out_ms, int64_t cap, int64_t* count
     out_ms[q] = ms;
   }
   if (count) *count = pairs;
+  return PMF_OK;
+}
+
+int pmf_abort(pmf_ctx* c, int32_t on) {
+  if (!c) return PMF_EINVAL;
+  c->abort_flag.store(on ? 1 : 0, std::memory_order_relaxed);
   return PMF_OK;
 }
 

@@ -69,6 +69,43 @@ class PrecisionWarning(UserWarning):
     """float64 `data` is computed on in float32 (see NMF's class docstring)."""
 
 
+class _LateDataCheck(object):
+    """The digest of `data` on a second thread while pmf_factorize runs (NMF._late_data_check_ok).  Before the loop starts
+    the device's W is copied device to device (pmf_snapshot_w) and H (k x n) is fetched: what a restart puts back."""
+
+    def __init__(self, owner, ctx, arr):
+        import threading
+        self.owner, self.ctx, self.arr = owner, ctx, arr
+        self.fp, self.err = None, None
+        ctx.snapshot_w()
+        self.h_keep = ctx.get_h()
+        self.thread = threading.Thread(target=self._run, name="pymf_amd-data-digest", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            self.fp = _fingerprint(self.arr)                 # C, multi-threaded, the GIL released
+            if self.fp != self.owner._v_fp:
+                self.ctx.abort(True)                         # the loop is running on stale bytes: no point in finishing it
+        except BaseException as e:                           # (never lose an error on the side thread)
+            self.err = e
+
+    def data_changed(self):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        return self.fp != self.owner._v_fp
+
+    def restart(self):
+        o, ctx = self.owner, self.ctx
+        ctx.abort(False)
+        ctx.restore_w()
+        ctx.set_h(self.h_keep)
+        o._warn_if_float64(self.arr)
+        ctx.set_v_dense(self.arr)
+        o._v_fp = self.fp
+
+
 class NMF(object):
     """Non-negative matrix factorization, multiplicative updates (Lee & Seung).
 
@@ -504,8 +541,11 @@ class NMF(object):
         if self._hooks_overridden() or (show_progress and not rows):
             # the hooks synchronise what THEY need: a subclass that computes on the host never pays for an upload
             return self._factorize_by_hooks(niter, compute_w, compute_h, compute_err)
-        ctx = self._sync_to_device()
+        late = None if rows else self._late_data_check_ok(niter)
+        ctx = self._sync_to_device(with_data=late is None)
         snap = compute_w and self._snapshot_w_if_the_step_may_fail(ctx, whole_loop=True)
+        if late is not None:
+            late = _LateDataCheck(self, ctx, late)             # W / H kept aside on the device, the digest of `data` under way
         if rows:                                               # a Python loop already: logs as it runs
             ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
             self._last_iters = done
@@ -517,8 +557,19 @@ class NMF(object):
             return
         else:
             try:
-                ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
-                                                    conv_eps=self._EPS)
+                try:
+                    ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
+                                                        conv_eps=self._EPS)
+                except Exception:
+                    if late is None or not late.data_changed():
+                        raise
+                if late is not None and late.data_changed():
+                    # `data` was edited in place since its upload: the loop above ran on the OLD bytes (it was asked to stop
+                    # as soon as the digest knew).  W and H go back to what they were, the new bytes go up, and the call
+                    # starts again -- what the reference computes, which reads self.data[:,:] afresh (nmf.py:123,129)
+                    late.restart()
+                    ferr, done, conv_at = ctx.factorize(niter, compute_w, compute_h, compute_err,
+                                                        conv_eps=self._EPS)
             except Exception:
                 # the device factors are in an unknown state (e.g. behind a singular H H^T): W goes back to the
                 # snapshot (or to the host array where that is the current one), H to the host array (a class
@@ -540,6 +591,25 @@ class NMF(object):
                 self._logger.info('Iteration ' + str(i + 1) + '/' + str(niter))
         if compute_err and conv_at >= 0:                       # nmf.py:198-202
             self.ferr = self.ferr[:conv_at]
+
+    #: The digest of a large `data` before every factorize() (check_data) runs BESIDE the device loop instead of in front of
+    #: it: the loop starts on the resident copy at once; if the bytes turn out to have changed since the upload the loop is
+    #: stopped, W / H are put back from copies kept on the device, the new bytes go up and the call starts again
+    #: (_LateDataCheck).  Same results as checking first -- the common case (nothing changed) no longer pays 4-6 ms per GiB.
+    _LATE_DATA_CHECK = True
+    _LATE_DATA_CHECK_MIN_BYTES = 64 << 20
+
+    def _late_data_check_ok(self, niter):
+        """The dense ndarray to digest beside the loop, or None where the data are checked in front of it as before: small
+        data, first upload, another object bound to `data`, check_data off, several ranks (the ranks vote on uploads before
+        the loop), classes with device state derived from data (RNMF) or a schedule that a restart would have to rewind (BNMF)."""
+        if (not self._LATE_DATA_CHECK or not self.check_data or niter < 1 or self._world().size > 1
+                or self._ALGO not in (_lib.ALGO_NMF, _lib.ALGO_SNMF, _lib.ALGO_NMFALS)
+                or self._v_src is not self.data or self._v_fp is None or _is_sparse(self.data)
+                or type(self.data) is not np.ndarray or self.data.nbytes < self._LATE_DATA_CHECK_MIN_BYTES
+                or self._ctx is None or not hasattr(self._ctx, "abort") or not hasattr(self._ctx, "snapshot_w")):
+            return None
+        return self.data
 
     def _factorize_by_hooks(self, niter, compute_w, compute_h, compute_err):
         """The reference's loop (nmf.py:182-202), one hook call at a time, log lines as it runs.

@@ -877,6 +877,42 @@ def test_data_edited_in_place_is_noticed(pm, cls_name):
     assert np.all(a.H[:, 3] == 0.0) or cls_name == "SNMF"
 
 
+@pytest.mark.parametrize("cls_name", ["NMF", "SNMF", "NMFALS"])
+def test_digest_of_data_beside_the_loop_equals_checking_first(pm, cls_name, monkeypatch):
+    """Round 5: the digest of a large `data` runs on a second thread WHILE pmf_factorize iterates on the
+    resident copy; unchanged bytes: nothing else happens; edited bytes: the loop is stopped (pmf_abort), W / H are put back
+    from the copies kept on the device, the new bytes go up and the call starts again.  Both must give the bits of the
+    check-first path (nmf.py:123,129: the reference reads self.data[:,:] afresh in every hook)."""
+    from pymf_amd import nmf as nmfmod
+    rs = np.random.RandomState(21)
+    V = (rs.random_sample((4096, 128)) - (0.3 if cls_name == "SNMF" else 0.0)).astype(np.float32)
+    made, restarted = [], []
+    orig_init, orig_restart = nmfmod._LateDataCheck.__init__, nmfmod._LateDataCheck.restart
+    monkeypatch.setattr(nmfmod._LateDataCheck, "__init__", lambda self, *a: (made.append(1), orig_init(self, *a))[1])
+    monkeypatch.setattr(nmfmod._LateDataCheck, "restart", lambda self: (restarted.append(1), orig_restart(self))[1])
+
+    def run(late):
+        np.random.seed(5)
+        m_ = getattr(pm, cls_name)(V.copy(), num_bases=8)
+        m_._LATE_DATA_CHECK, m_._LATE_DATA_CHECK_MIN_BYTES = late, 0
+        m_.factorize(niter=3)                                  # first call: the upload
+        m_.factorize(niter=4)                                  # data unchanged
+        a = (m_.W.copy(), m_.H.copy(), m_.ferr.copy())
+        m_.data[7, 3] += 0.25
+        m_.data[100:200] *= 0.5                                # edited in place: same object, new bytes
+        m_.factorize(niter=5)
+        b = (m_.W.copy(), m_.H.copy(), m_.ferr.copy())
+        m_.factorize(niter=2, compute_err=False)               # and on from there, unchanged again
+        return a, b, (m_.W.copy(), m_.H.copy())
+    first = run(False)
+    assert not made
+    beside = run(True)
+    assert len(made) == 3 and len(restarted) == 1, (made, restarted)
+    for x, y in zip(first, beside):
+        for u, v in zip(x, y):
+            assert u.shape == v.shape and np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("shape,k,sparse", [((6000, 256), 64, False), ((3000, 320), 20, False), ((5000, 128), 128, True),
                                             ((4000, 200), 48, True), ((2500, 700), 33, False)])
 def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
@@ -1058,6 +1094,12 @@ def test_full_size_properties_cfg3(pm):
     scale = np.abs(Fm).max()
     assert g.min() > -2e-4 * scale, g.min() / scale   # dual feasibility (float32 right-hand sides and storage)
     assert np.abs(Ws * g).max() < 2e-4 * scale * max(1.0, Ws.max())     # complementarity
+    # ... and the oracle's minimiser itself on those rows (the KKT band alone would pass with W rows 1e-4 away
+    # from it): the exact float64 active-set solve of the same QP, HA = H0 H0^T, FA = -H0 v^T (nmfals.py:88-93)
+    import oracle
+    Wo = np.array([oracle.nnqp_solve(HA, -Fm[q]) for q in range(len(rows))])
+    assert rel_fro(Ws, Wo, what="cfg3 W rows (every 257th) vs oracle.nnqp_solve, full size") < 2e-5
+    assert int(np.sum((Ws == 0) != (Wo == 0))) <= len(rows) * k // 1000, "active sets differ on more than 0.1 % of the entries"
     f1 = c.frobenius()
     c.update_h()
     f2 = c.frobenius()
