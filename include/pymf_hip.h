@@ -273,6 +273,11 @@ int pmf_invalidate_v(pmf_ctx* ctx);
  * puts it back when the step raised (pmf_restore_w).  No host traffic either way. */
 int pmf_snapshot_w(pmf_ctx* ctx);
 int pmf_restore_w(pmf_ctx* ctx);
+/* The same for H (k x n: small), together with what the device derived from it (NMF / BNMF: the Gram matrix H H^T as the last
+ * H step left it, so that a restored H continues with the same bits).  With pmf_snapshot_w / pmf_restore_w: the pair of factors
+ * a loop started from, for a caller that finds out DURING the loop that it has to start again (pmf_abort). */
+int pmf_snapshot_h(pmf_ctx* ctx);
+int pmf_restore_h(pmf_ctx* ctx);
 
 /* With pmf_profile_enable the per-iteration collective -- the sum of (W^T V | W^T W) over the ranks, what the row sharding of
  * pymf/nmf.py:124-125 costs -- is bracketed by HIP events as well: mean duration (ms) and count since the last enable. */
@@ -298,7 +303,7 @@ int pmf_synchronize(pmf_ctx* ctx);
  * running (or the next) pmf_factorize return at its next iteration / chunk boundary with *iters_done = what it completed;
  * on = 0 clears the request.  The host class runs its digest of `data` (the reference re-reads self.data[:,:] in every hook,
  * nmf.py:123,129) BESIDE the device loop and, should the bytes have changed since the upload, stops the loop, puts W / H back
- * (pmf_restore_w, pmf_set_h_*), uploads and starts again. */
+ * (pmf_restore_w, pmf_restore_h), uploads and starts again. */
 int pmf_abort(pmf_ctx* ctx, int32_t on);
 
 /* Introspection used by tests: which code path update_w/update_h take for this shape.

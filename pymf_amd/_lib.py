@@ -78,6 +78,8 @@ SYMBOLS = [
     ("pmf_invalidate_v", _c.c_int, [_ctx]),
     ("pmf_snapshot_w", _c.c_int, [_ctx]),
     ("pmf_restore_w", _c.c_int, [_ctx]),
+    ("pmf_snapshot_h", _c.c_int, [_ctx]),
+    ("pmf_restore_h", _c.c_int, [_ctx]),
     ("pmf_collective_ms", _c.c_int, [_ctx, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
     ("pmf_kernel_exec_flops", _c.c_int, [_ctx, _c.POINTER(_c.c_double)]),
     ("pmf_kernel_launch_ms", _c.c_int, [_ctx, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64)]),
@@ -405,6 +407,13 @@ class Context(object):
 
     def restore_w(self):
         self._chk(self._lib.pmf_restore_w(self._h))
+
+    def snapshot_h(self):
+        """Device-side copy of H and of the Gram state derived from it (pmf_snapshot_h)."""
+        self._chk(self._lib.pmf_snapshot_h(self._h))
+
+    def restore_h(self):
+        self._chk(self._lib.pmf_restore_h(self._h))
 
     def kernel_launch_ms(self, cap=65536):
         """Durations (ms) of the dominant kernel's launches since profile_enable(), in launch order."""

@@ -100,6 +100,9 @@ struct pmf_ctx {
   double* dGramPart = nullptr;  // k_gram_splitk: per-slice partial Gram matrices, [8][KP][KP]
   unsigned* dGramTickets = nullptr;
   float* dGpart = nullptr;      // k_nmf_h_gram: per-workgroup partial G, [PMF_HGRAM_MAX_WGS][KP][KP]
+  float* dHsnap = nullptr;      // pmf_snapshot_h: H, then G, then the partial Gs
+  bool hsnap_valid = false, hsnap_g_valid = false;
+  int hsnap_g_parts = 0;
   double* dT1part = nullptr;    // ... and partial <P, H_new>
   unsigned* dTicket = nullptr;  // ... arrival counter (the kernel resets it)
   // free-running pmf_factorize loop: device-side error history and stop flag
@@ -2344,6 +2347,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (c->ipc.area[c->ipc.me]) (void)hipFree(c->ipc.area[c->ipc.me]);
   }
   if (c->dIpcErr) (void)hipFree(c->dIpcErr);
+  if (c->dHsnap) (void)hipFree(c->dHsnap);
   if (c->dIpcWait) (void)hipFree(c->dIpcWait);
   if (c->dIpcTestA) (void)hipFree(c->dIpcTestA);
   if (c->dIpcTestB) (void)hipFree(c->dIpcTestB);
@@ -3400,6 +3404,46 @@ int pmf_restore_w(pmf_ctx* c) {
   c->w_implicit = false;
   c->ps_valid = false; c->trace_ready = false; c->num_valid = false;
   if (c->dSing) HIPCHK(c, hipMemsetAsync(c->dSing, 0, sizeof(int), c->stream));
+  return PMF_OK;
+}
+
+// H with the state derived from it: for NMF / BNMF the Gram matrix G = H H^T as the last H step left it (whole, or as the
+// per-workgroup partial sums the next one-pass launch adds) -- a restored H then continues with the SAME bits of G; the other
+// classes form G from H whenever they need it.
+int pmf_snapshot_h(pmf_ctx* c) {
+  PMFCHK(need(c, false, false, true));
+  const size_t hb = (size_t)c->KP * c->np * sizeof(float), gb = (size_t)c->KP * c->KP * sizeof(float);
+  if (!c->dHsnap) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dHsnap), hb + gb + (size_t)PMF_HGRAM_MAX_WGS * gb));
+  HIPCHK(c, hipMemcpyAsync(c->dHsnap, c->dH, hb, hipMemcpyDeviceToDevice, c->stream));
+  const bool keep_g = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->g_valid && c->dG != nullptr;
+  c->hsnap_g_valid = keep_g;
+  c->hsnap_g_parts = keep_g ? c->g_parts : 0;
+  if (keep_g) {
+    char* gs = reinterpret_cast<char*>(c->dHsnap) + hb;
+    HIPCHK(c, hipMemcpyAsync(gs, c->dG, gb, hipMemcpyDeviceToDevice, c->stream));
+    if (c->g_parts > 0 && c->dGpart)
+      HIPCHK(c, hipMemcpyAsync(gs + gb, c->dGpart, (size_t)c->g_parts * gb, hipMemcpyDeviceToDevice, c->stream));
+  }
+  c->hsnap_valid = true;
+  return PMF_OK;
+}
+
+int pmf_restore_h(pmf_ctx* c) {
+  if (!c) return PMF_EINVAL;
+  if (!c->hsnap_valid) return fail(c, PMF_EINVAL, "pmf_restore_h: no snapshot (pmf_snapshot_h)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t hb = (size_t)c->KP * c->np * sizeof(float), gb = (size_t)c->KP * c->KP * sizeof(float);
+  HIPCHK(c, hipMemcpyAsync(c->dH, c->dHsnap, hb, hipMemcpyDeviceToDevice, c->stream));
+  c->have_h = true; c->num_valid = false; c->trace_ready = false;
+  c->g_valid = false; c->g_parts = 0;
+  if (c->hsnap_g_valid) {
+    const char* gs = reinterpret_cast<const char*>(c->dHsnap) + hb;
+    HIPCHK(c, hipMemcpyAsync(c->dG, gs, gb, hipMemcpyDeviceToDevice, c->stream));
+    if (c->hsnap_g_parts > 0)
+      HIPCHK(c, hipMemcpyAsync(c->dGpart, gs + gb, (size_t)c->hsnap_g_parts * gb, hipMemcpyDeviceToDevice, c->stream));
+    c->g_valid = true; c->g_parts = c->hsnap_g_parts;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return PMF_OK;
 }
 

@@ -71,14 +71,14 @@ class PrecisionWarning(UserWarning):
 
 class _LateDataCheck(object):
     """The digest of `data` on a second thread while pmf_factorize runs (NMF._late_data_check_ok).  Before the loop starts
-    the device's W is copied device to device (pmf_snapshot_w) and H (k x n) is fetched: what a restart puts back."""
+    the device's W and H are copied device to device (pmf_snapshot_w / pmf_snapshot_h): what a restart puts back."""
 
     def __init__(self, owner, ctx, arr):
         import threading
         self.owner, self.ctx, self.arr = owner, ctx, arr
         self.fp, self.err = None, None
         ctx.snapshot_w()
-        self.h_keep = ctx.get_h()
+        ctx.snapshot_h()
         self.thread = threading.Thread(target=self._run, name="pymf_amd-data-digest", daemon=True)
         self.thread.start()
 
@@ -100,7 +100,7 @@ class _LateDataCheck(object):
         o, ctx = self.owner, self.ctx
         ctx.abort(False)
         ctx.restore_w()
-        ctx.set_h(self.h_keep)
+        ctx.restore_h()                                      # (with the Gram matrix the last H step left: the same bits go on)
         o._warn_if_float64(self.arr)
         ctx.set_v_dense(self.arr)
         o._v_fp = self.fp
@@ -597,7 +597,7 @@ class NMF(object):
     #: stopped, W / H are put back from copies kept on the device, the new bytes go up and the call starts again
     #: (_LateDataCheck).  Same results as checking first -- the common case (nothing changed) no longer pays 4-6 ms per GiB.
     _LATE_DATA_CHECK = True
-    _LATE_DATA_CHECK_MIN_BYTES = 64 << 20
+    _LATE_DATA_CHECK_MIN_BYTES = int(os.environ.get("PYMF_LATE_CHECK_MIN_BYTES", str(64 << 20)))   # (0: always -- the test sweeps)
 
     def _late_data_check_ok(self, niter):
         """The dense ndarray to digest beside the loop, or None where the data are checked in front of it as before: small

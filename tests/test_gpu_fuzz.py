@@ -33,3 +33,15 @@ def test_seeded_sample_of_the_randomised_sweeps(tool, args):
     tail = "\n".join(out.strip().splitlines()[-15:])
     assert p.returncode == 0, tail
     assert out.strip().splitlines()[-1].strip() == "bad 0", tail
+
+
+@pytest.mark.parametrize("args", [["2032", "40"], ["2033", "40"]])
+def test_call_sequences_with_the_digest_of_data_beside_the_loop(args):
+    """The random call sequences once more with the late data check (round 5: the digest of `data` on a second thread while
+    pmf_factorize runs; stop + restore + upload + restart when the bytes changed) forced on for data of any size."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", "fuzz_sequences.py")] + args, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600, cwd=ROOT, env=dict(os.environ, PYMF_LATE_CHECK_MIN_BYTES="0"))
+    out = p.stdout.decode("utf-8", "replace")
+    tail = "\n".join(out.strip().splitlines()[-15:])
+    assert p.returncode == 0, tail
+    assert out.strip().splitlines()[-1].strip() == "bad 0", tail
