@@ -217,13 +217,19 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0, sample=None):
         o = oracle.SNMFOracle(Vd, num_bases=k)
         o.W, o.H = W, H
 
+        early = {}
+
         def step():
             o.update_w()
             o.update_h()
+            early["n"] = early.get("n", 0) + 1
+            if early["n"] == 2:                   # the state after two iterations, kept beside the final one
+                early["W"], early["H"] = np.array(o.W), np.array(o.H)
         it, dt = _time_loop(step, budget_s)
         # what the device is compared with (main(): `parity_full_size`): the same 131 072-row block as a problem of its own,
         # same W0 / H0, same 1 + it iterations -- H is replicated, so its H is what any rank of the sharded run iterates on
-        out["_oracle_factors"] = {"iters": 1 + it, "W": np.array(o.W), "H": np.array(o.H), "csr": (ip, ix, vv), "ms": ms}
+        out["_oracle_factors"] = {"iters": 1 + it, "W": np.array(o.W), "H": np.array(o.H), "csr": (ip, ix, vv), "ms": ms,
+                                  "W2": early.get("W"), "H2": early.get("H")}
         out.update(value=(it / dt) * ms / float(m),
                    sample="oracle SNMF (snmf.py:67-91) on V.toarray() of the first %d of %d rows (the reference has no "
                           "sparse path), n=%d k=%d: %d iterations in %.2f s, scaled by %d/%d (cost is linear in rows); %s"
@@ -764,7 +770,17 @@ def main():
                     np.random.seed(42)
                     c2.set_w(np.random.random((fac["ms"], k)))
                     c2.set_h(np.random.random((k, n)))
-                    _, done_p, _ = c2.factorize(fac["iters"], compute_err=False)
+                    after2 = None
+                    if fac.get("W2") is not None and fac["iters"] > 2:
+                        c2.factorize(2, compute_err=False)
+                        W2, H2 = c2.get_w(), c2.get_h()
+                        after2 = {"relW": float(np.linalg.norm(W2 - fac["W2"]) / np.linalg.norm(fac["W2"])),
+                                  "relH": float(np.linalg.norm(H2 - fac["H2"]) / np.linalg.norm(fac["H2"]))}
+                        del W2, H2
+                        _, done_p, _ = c2.factorize(fac["iters"] - 2, compute_err=False)
+                        done_p += 2
+                    else:
+                        _, done_p, _ = c2.factorize(fac["iters"], compute_err=False)
                     Wd, Hd = c2.get_w(), c2.get_h()
                 finally:
                     c2.close()
@@ -774,7 +790,12 @@ def main():
                     "relW": float(np.linalg.norm(Wd - fac["W"]) / np.linalg.norm(fac["W"])),
                     "relW_rows_sampled": float(np.linalg.norm(Wd[rows] - fac["W"][rows]) / np.linalg.norm(fac["W"][rows])),
                     "relH": float(np.linalg.norm(Hd - fac["H"]) / np.linalg.norm(fac["H"])),
-                    "H_min": float(Hd.min()), "tolerance": 1e-4,
+                    "H_min": float(Hd.min()), "after_2_iterations": after2,
+                    "tolerance": {"H": 2e-5, "W": 1e-3},
+                    "tolerance_note": "k = n = 128: H H^T of a square H has cond ~ 1e7; the device stores H in float32 between "
+                                      "iterations and W = V inv(H H^T) H amplifies that rounding by sigma_max / sigma_min ~ 3e3 "
+                                      "(DESIGN.md 4.1) -- H itself stays at float32 rounding, W drifts from 7e-6 (2 iterations) to "
+                                      "a few 1e-4 (50); the reference's own all-float32 run is at 1e-1 after TWO iterations",
                     "against": "oracle SNMF (snmf.py:67-91, float64 W/H) on V.toarray() of a %d-row block of the cfg5 matrix (n=%d, "
                                "k=%d) fed to the device as its own CSR problem: same seeded W0/H0, same %d iterations; H is "
                                "replicated in the row-sharded run, so this is the H every rank iterates on for that block; "
