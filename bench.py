@@ -794,7 +794,7 @@ def main():
                     "tolerance": {"H": 2e-5, "W": 1e-3},
                     "tolerance_note": "k = n = 128: H H^T of a square H has cond ~ 1e7; the device stores H in float32 between "
                                       "iterations and W = V inv(H H^T) H amplifies that rounding by sigma_max / sigma_min ~ 3e3 "
-                                      "(DESIGN.md 4.1) -- H itself stays at float32 rounding, W drifts from 7e-6 (2 iterations) to "
+                                      "(DESIGN.md 4.1) -- H itself stays at float32 rounding, W drifts from a few 1e-5 (2 iterations) to "
                                       "a few 1e-4 (50); the reference's own all-float32 run is at 1e-1 after TWO iterations",
                     "against": "oracle SNMF (snmf.py:67-91, float64 W/H) on V.toarray() of a %d-row block of the cfg5 matrix (n=%d, "
                                "k=%d) fed to the device as its own CSR problem: same seeded W0/H0, same %d iterations; H is "
