@@ -1098,8 +1098,11 @@ def test_full_size_properties_cfg3(pm):
     # from it): the exact float64 active-set solve of the same QP, HA = H0 H0^T, FA = -H0 v^T (nmfals.py:88-93)
     import oracle
     Wo = np.array([oracle.nnqp_solve(HA, -Fm[q]) for q in range(len(rows))])
-    assert rel_fro(Ws, Wo, what="cfg3 W rows (every 257th) vs oracle.nnqp_solve, full size") < 2e-5
-    assert int(np.sum((Ws == 0) != (Wo == 0))) <= len(rows) * k // 1000, "active sets differ on more than 0.1 % of the entries"
+    # (tolerance: DESIGN 4 -- 1e-4 for NMFALS: the right-hand sides V H0^T are float32 MFMA sums over 1 024 columns and the minimiser
+    #  amplifies their rounding by the condition of H0 H0^T; 4e-5 on these device-filled inputs, 2.6e-6 on bench.py's seeded ones)
+    assert rel_fro(Ws, Wo, what="cfg3 W rows (every 257th) vs oracle.nnqp_solve, full size") < 1e-4
+    nz = int(np.sum((Ws == 0) != (Wo == 0)))
+    assert nz <= len(rows) * k // 1000, "active sets differ on %d of %d entries (more than 0.1 %%)" % (nz, len(rows) * k)
     f1 = c.frobenius()
     c.update_h()
     f2 = c.frobenius()
