@@ -444,7 +444,7 @@ def main():
     # dispatch's completion signal; tools/loop_probe.py: 59.3 -> 64.4 us per iteration at cfg2 with every launch timed), so only
     # every `timed_every`-th launch of the timed region carries a pair -- about one per millisecond, at least 8 per region
     timed_every = 1
-    if algo_name == "NMF" and preroll_iters > 4:
+    if algo_name != "NMFALS" and preroll_iters > 4:          # (NMFALS: the counting pass pairs launches with counters one to one)
         est_ms = max(preroll_ms / max(preroll_iters - 4, 1), 1e-3)
         timed_every = max(1, min(args.steps // 8, int(np.ceil(1.0 / est_ms))))
     timed_every = int(dist.allreduce_max(timed_every))
@@ -684,7 +684,7 @@ def main():
                                             "a recorded constant, not counted in this run") if traffic is not None
                                            else "none recorded for this kernel / shape / rank count",
                          "kernel": stats["name"], "launches": stats["launches"],
-                         "launches_in_timed_region": args.steps if algo_name == "NMF" else stats["launches"],
+                         "launches_in_timed_region": args.steps if algo_name != "NMFALS" else stats["launches"],
                          "timed_every": timed_every,
                          "mean_kernel_ms": stats["mean_ms"],
                          "min_kernel_ms": float(launch_ms[0]) if len(launch_ms) else None,
@@ -696,7 +696,7 @@ def main():
                          "executed_TFLOPs": ex / mean_s / 1e12 if mean_s > 0 else 0.0,
                          "algorithmic_bytes_per_launch": by,
                          "achieved_hbm_GBs": by / mean_s / 1e9 if mean_s > 0 else 0.0,
-                         "kernel_share_of_timed_region": (args.steps if algo_name == "NMF" else stats["launches"]) * mean_s / dt if dt > 0 else 0.0},
+                         "kernel_share_of_timed_region": (args.steps if algo_name != "NMFALS" else stats["launches"]) * mean_s / dt if dt > 0 else 0.0},
         }
         if algo_name == "NMFALS":
             # The QP kernel runs float64 VALU code: neither HBM nor MFMA bounds it.  Against the 78.6 TFLOP/s float64 vector

@@ -1646,13 +1646,16 @@ int snmf_gram_iteration(pmf_ctx* c) {
     const int b = (int)(c->w_pipe_it & 1);
     HIPCHK(c, hipEventRecord(c->ev_mt[b], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->w_stream, c->ev_mt[b], 0));
-    if (c->profile && c->stat.site == SITE_MATERIALIZE) {     // the launch's own HIP events, on the stream it runs on
+    // the launch's own HIP events, on the stream it runs on -- sampled like every timed site (profile_every): the pair sits
+    // BETWEEN two writes of a loop that is bound by exactly these writes
+    const bool timed_w = c->profile && c->stat.site == SITE_MATERIALIZE && (c->stat.seen++ % c->stat.every == 0);
+    if (timed_w) {
       KernelStat& st = c->stat;
       if (st.used + 2 > st.ev.size()) for (int q = 0; q < 2; ++q) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) st.ev.push_back(e); }
       if (st.used + 2 <= st.ev.size()) (void)hipEventRecord(st.ev[st.used], c->w_stream);
     }
     PMFCHK(csr_w(c, c->w_stream, mcsr, c->opt_w_pipe));
-    if (c->profile && c->stat.site == SITE_MATERIALIZE && c->stat.used + 2 <= c->stat.ev.size()) {
+    if (timed_w && c->stat.used + 2 <= c->stat.ev.size()) {
       (void)hipEventRecord(c->stat.ev[c->stat.used + 1], c->w_stream);
       c->stat.used += 2;
     }

@@ -545,7 +545,11 @@ class NMF(object):
         ctx = self._sync_to_device(with_data=late is None)
         snap = compute_w and self._snapshot_w_if_the_step_may_fail(ctx, whole_loop=True)
         if late is not None:
-            late = _LateDataCheck(self, ctx, late)             # W / H kept aside on the device, the digest of `data` under way
+            try:
+                late = _LateDataCheck(self, ctx, late)         # W / H kept aside on the device, the digest of `data` under way
+            except _lib.PmfError:                              # (no room for the copies: check first, as before)
+                late = None
+                self._upload_data(ctx)
         if rows:                                               # a Python loop already: logs as it runs
             ferr, done, conv_at = self._factorize_streamed(ctx, rows, niter, compute_w, compute_h, compute_err)
             self._last_iters = done
@@ -607,6 +611,7 @@ class NMF(object):
                 or self._ALGO not in (_lib.ALGO_NMF, _lib.ALGO_SNMF, _lib.ALGO_NMFALS)
                 or self._v_src is not self.data or self._v_fp is None or _is_sparse(self.data)
                 or type(self.data) is not np.ndarray or self.data.nbytes < self._LATE_DATA_CHECK_MIN_BYTES
+                or 2 * self._num_bases > self._num_samples       # (the device-side copy of W must be small beside `data`)
                 or self._ctx is None or not hasattr(self._ctx, "abort") or not hasattr(self._ctx, "snapshot_w")):
             return None
         return self.data
