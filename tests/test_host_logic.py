@@ -318,3 +318,69 @@ def test_float64_data_warns_once_per_object():
         mdl.factorize(niter=1, compute_err=False)
     hits = [r for r in rec if issubclass(r.category, pymf_amd.nmf.PrecisionWarning)]
     assert len(hits) == 1 and "float32" in str(hits[0].message)
+
+
+class _LateCtx(_CountingCtx):
+    """The counting double with the four calls the late data check needs; a log of the boundary traffic in order."""
+
+    def __init__(self, m, n, k):
+        _CountingCtx.__init__(self, m, n, k)
+        self.log, self.aborted = [], False
+
+    def snapshot_w(self):
+        self.log.append("snapshot_w"); self._ws = self.W.copy()
+
+    def snapshot_h(self):
+        self.log.append("snapshot_h"); self._hs = self.H.copy()
+
+    def restore_w(self):
+        self.log.append("restore_w"); self.W = self._ws.copy()
+
+    def restore_h(self):
+        self.log.append("restore_h"); self.H = self._hs.copy()
+
+    def abort(self, on=True):
+        self.log.append("abort(%d)" % (1 if on else 0)); self.aborted = bool(on)
+
+    def set_v_dense(self, V):
+        self.log.append("set_v"); _CountingCtx.set_v_dense(self, V)
+
+    def factorize(self, niter, *a, **kw):
+        import time
+        self.log.append("factorize(%d)" % niter)
+        time.sleep(0.05)                                      # (the digest thread finishes first: its abort is on record)
+        return _CountingCtx.factorize(self, niter, *a, **kw)
+
+
+def test_late_data_check_restarts_the_loop_when_the_bytes_changed():
+    """Round 5: the digest of `data` runs on a second thread beside the device loop.  Unchanged bytes: snapshots, one loop,
+    nothing else.  Bytes edited in place since the upload: the loop is asked to stop, W and H are put back from the device-side
+    copies, the new bytes go up, the loop runs again -- and the result is what a check-first object computes."""
+    import oracle
+    rs = np.random.RandomState(8)
+    V = rs.rand(64, 16).astype(np.float32)
+    W0, H0 = rs.rand(64, 3), rs.rand(3, 16)
+
+    def model(late):
+        mdl = pymf_amd.NMF(V.copy(), num_bases=3)
+        mdl._ctx = _LateCtx(64, 16, 3)
+        mdl._LATE_DATA_CHECK, mdl._LATE_DATA_CHECK_MIN_BYTES = late, 0
+        mdl.W, mdl.H = W0.copy(), H0.copy()
+        return mdl
+    a, b = model(True), model(False)
+    for mdl in (a, b):
+        mdl.factorize(niter=2, compute_err=False)             # the first call uploads: checked in front, in both
+    assert "snapshot_w" not in a._ctx.log
+    a._ctx.log[:] = []
+    a.factorize(niter=2, compute_err=False); b.factorize(niter=2, compute_err=False)
+    assert a._ctx.log == ["snapshot_w", "snapshot_h", "factorize(2)"], a._ctx.log
+    a._ctx.log[:] = []
+    for mdl in (a, b):
+        mdl.data[5, 3] += 0.5                                 # in place: same object, new bytes
+    a.factorize(niter=3, compute_err=False); b.factorize(niter=3, compute_err=False)
+    assert a._ctx.log == ["snapshot_w", "snapshot_h", "factorize(3)", "abort(1)", "abort(0)", "restore_w", "restore_h", "set_v", "factorize(3)"] or \
+        a._ctx.log == ["snapshot_w", "snapshot_h", "abort(1)", "factorize(3)", "abort(0)", "restore_w", "restore_h", "set_v", "factorize(3)"], a._ctx.log
+    assert not a._ctx.aborted and a._ctx.up["V"] == 2 == b._ctx.up["V"]
+    np.testing.assert_array_equal(a._ctx.W, b._ctx.W)
+    np.testing.assert_array_equal(a._ctx.H, b._ctx.H)
+    np.testing.assert_array_equal(a.W, b.W)
