@@ -612,7 +612,7 @@ class NMF(object):
                 or self._v_src is not self.data or self._v_fp is None or _is_sparse(self.data)
                 or type(self.data) is not np.ndarray or self.data.nbytes < self._LATE_DATA_CHECK_MIN_BYTES
                 or 2 * self._num_bases > self._num_samples       # (the device-side copy of W must be small beside `data`)
-                or self._ctx is None or not hasattr(self._ctx, "abort") or not hasattr(self._ctx, "snapshot_w")):
+                or self._ctx is None or not all(hasattr(self._ctx, a) for a in ("abort", "snapshot_w", "snapshot_h", "restore_w", "restore_h"))):
             return None
         return self.data
 
