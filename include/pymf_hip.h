@@ -248,16 +248,21 @@ int pmf_set_host_allreduce(pmf_ctx* ctx, pmf_host_allreduce_fn fn, void* user);
  * its partial of (W^T V | W^T W) into every peer's area, raises a flag there, waits for the peers' flags and adds the N
  * partials in rank order -- bit-identical sums on all ranks, no ring / tree hops.  Payloads up to 256 KiB take it; larger
  * ones (the n x n float64 V^T V of the Gram-space SNMF loop, NNDSVD's Gram matrix) stay on RCCL / the host transport.
- *   pmf_ipc_export(ctx, rank, nranks, handle_out)   allocate + export this rank's area: PMF_IPC_HANDLE_BYTES bytes
+ *   pmf_ipc_export(ctx, rank, nranks, handle_out)   allocate + export this rank's area (sized for nranks; also the self-test's
+ *                                                   buffers, so that nothing is allocated between the test's collectives)
  *   (hand every rank's handle to every rank by any means, in rank order)
- *   pmf_ipc_import(ctx, handles, nranks)            map the peers' areas; from here on small sums take the one-shot path
+ *   pmf_ipc_import(ctx, handles, nranks)            map the peers' areas (the SAME nranks; all or nothing: a failing
+ *                                                   hipIpcOpenMemHandle closes what was opened); from here on small sums take
+ *                                                   the one-shot path -- inside pmf_factorize's one-pass loop folded into the
+ *                                                   slab-reduce and H-step launches (option "fold_exchange")
  * 2 <= nranks <= 8, one node (ranks on different GPUs of one xGMI hive, or -- for plumbing checks -- sharing a GPU).
  * pmf_collective_name: which transports this context's cross-rank sums use and how often each ran. */
 #define PMF_IPC_HANDLE_BYTES 64
 int pmf_ipc_export(pmf_ctx* ctx, int32_t rank, int32_t nranks, void* handle_out);
 int pmf_ipc_import(pmf_ctx* ctx, const void* handles, int32_t nranks);
 /* The one-shot path against the context's other transport (RCCL / host) on rank- and round-dependent payloads, `rounds`
- * times (both slots get reused): *ok = 1 iff all rounds agreed and no wait ran out.  Every rank calls it at the same
+ * times (both slots get reused; odd rounds in the split producer / consumer form the loop uses): *ok = 1 iff all rounds agreed
+ * and no wait ran out (2 s per wait).  Every rank calls it at the same
  * point; the caller combines the verdicts and switches the path off on ALL ranks if any disagreed
  * (pmf_set_option(ctx, "oneshot_allreduce", 0)). */
 int pmf_ipc_selftest(pmf_ctx* ctx, int32_t rounds, int32_t* ok);
