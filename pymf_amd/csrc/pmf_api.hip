@@ -3265,6 +3265,11 @@ int pmf_ipc_export(pmf_ctx* c, int32_t rank, int32_t nranks, void* handle_out) {
   if (e == hipSuccess && hipIpcGetMemHandle(&h, area) != hipSuccess) { (void)hipFree(area); area = nullptr; e = hipErrorUnknown; }
   if (e != hipSuccess) {                       // (a runtime that cannot export fine-grained memory: ordinary device memory)
     (void)hipGetLastError();
+    // ... which is only sound between processes on ONE device: coarse-grained memory is, by the memory model, touched by a single
+    // agent while a kernel runs -- a peer GPU's stores would meet stale L2 lines here.  With an RCCL communicator (ranks on GPUs of
+    // their own) the export fails instead and RCCL keeps carrying the sums.
+    if (c->comm != nullptr)
+      return fail(c, PMF_EHIP, "pmf_ipc_export: fine-grained device memory cannot be allocated / exported on this runtime");
     HIPCHK(c, hipMalloc(&area, bytes));
     HIPCHK(c, hipIpcGetMemHandle(&h, area));
   }
