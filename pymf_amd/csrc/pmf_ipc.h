@@ -53,9 +53,12 @@ __device__ __forceinline__ void ipc_push_f32(const IpcPeers& pr, unsigned seq, i
     __builtin_nontemporal_store(v, reinterpret_cast<float*>(pr.area[r] + slot_off) + idx);
   }
 }
-// after ALL threads of the workgroup have pushed: make the stores visible system-wide, then raise flag g at every rank
+// after ALL threads of the workgroup have pushed: every storing wave drains its stores (vmcnt counts a store until its write is
+// acknowledged), the workgroup meets, and the lanes that raise flag g at the ranks do so with ONE system-scope release (the
+// write-back in front of the flag store) -- not a fence in each of the workgroup's sixteen waves (MI355X_MICROARCH.md: a release
+// costs 1.7-6.5 us and every fencing wave pays it)
 __device__ __forceinline__ void ipc_raise(const IpcPeers& pr, unsigned seq, int g) {
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if ((int)threadIdx.x < pr.nranks) {
     unsigned* f = reinterpret_cast<unsigned*>(pr.area[threadIdx.x] + pmf_ipc_flags_offset(pr.nranks)) +
@@ -73,14 +76,19 @@ __device__ __forceinline__ bool ipc_wait_all(const IpcPeers& pr, unsigned seq, i
   const unsigned long long t0 = wall_clock64();
   for (int q = threadIdx.x; q < nflags * pr.nranks; q += blockDim.x) {
     const unsigned* f = fl + (size_t)(q / nflags) * PMF_IPC_MAX_WGS + (q % nflags);
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+    // (relaxed system-scope polls: a cache-bypassing load each; the ONE acquire follows below)
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > wait_ticks) { *ok = 0; break; }
     }
   }
-  __syncthreads();
+  __syncthreads();                                   // every flag has been seen
   if (!*ok) return false;
-  __threadfence_system();
+  if (threadIdx.x < 64) {                            // one wave acquires for the CU (its L1 is the CU's), the others wait for it
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
   return true;
 }
 // the N partials of 4 consecutive floats at float index idx, added in rank order (0 + p_0 + p_1 + ...: the order, and the
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256) void k_ipc_allreduce(T* __restrict__ p, int64_
     T* dst = reinterpret_cast<T*>(pr.area[r] + slot_off);
     for (int64_t e = lo + tid; e < hi; e += 256) __builtin_nontemporal_store(p[e], dst + e);
   }
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every storing wave drains; the release rides on the flag stores below)
   __syncthreads();
   // 2. raise my flag of this slice at every rank
   if (tid < N) {
@@ -147,14 +155,18 @@ __global__ __launch_bounds__(256) void k_ipc_allreduce(T* __restrict__ p, int64_
   if (tid < N) {
     const unsigned* f = reinterpret_cast<const unsigned*>(pr.area[me] + pmf_ipc_flags_offset(N)) + ((size_t)slot * N + tid) * PMF_IPC_MAX_WGS + g;
     const unsigned long long t0 = wall_clock64();            // the 100 MHz constant-rate counter
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > wait_ticks) { ok = 0; break; }
     }
   }
   __syncthreads();
   if (!ok) { if (tid == 0) atomicExch(err, 1); return; }
-  __threadfence_system();
+  if (tid < 64) {                                    // one wave acquires for the CU, the others wait for it
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
   const char* base = pr.area[me] + (size_t)slot * N * PMF_IPC_MAX_BYTES;
   for (int64_t e = lo + tid; e < hi; e += 256) {
     T s = (T)0;       // (0 + p_0 + p_1 + ...: the order, and the sign of a zero, of the host transport's sum)
