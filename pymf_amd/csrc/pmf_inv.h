@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_gram_splitk(const float* __restrict__ H
       const double v = ((acc[r] + wpart[0][r][lane]) + wpart[1][r][lane]) + wpart[2][r][lane];
       part[((size_t)z * KP + (ra + g + 4 * r)) * KP + gb] = v;
     }
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // (this wave stored the partial: a release is all the ticket needs)
     if (lane == 0) s_last = (atomicAdd(&tickets[tile], 1u) == (unsigned)KS - 1) ? 1u : 0u;
   }
   __syncthreads();

@@ -300,9 +300,14 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
     }
   }
   if (!final_sum) return;
-  __threadfence();                                    // partials visible device-wide before the ticket
+  // partials visible device-wide before the ticket: every storing wave drains its stores, the workgroup meets, ONE agent-scope
+  // release (the write-back of this XCD's L2) in front of the ticket -- not a fence in each of the sixteen waves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
   __syncthreads();
   if (!s_last) return;
   // acquire: drop whatever this CU's L1 holds, then the partials are read with plain 16-byte loads
