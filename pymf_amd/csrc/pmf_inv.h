@@ -62,23 +62,79 @@ __device__ __forceinline__ void inv16_pivot(double (&a)[4], double* __restrict__
   }
 }
 
-// Returns the smallest pivot met (wave-uniform).
+// Round 5: TWO pivots per LDS round trip, as ONE rank-2 update.  One pivot per trip took 214 cycles, nearly all of it a chain of
+// dependent float64 operations (v_readlane -> reciprocal with its Newton steps -> row scaling -> select -> FMA), and a wave
+// alone on its SIMD has nothing to hide that chain behind.  With the 2 x 2 block [[alpha, beta], [beta, gamma]] of rows Q, Q + 1
+// (Q even: both rows sit in the same lane group) inverted in closed form,
+//     D2 = 1 / det [[gamma, -beta], [-beta, alpha]],   det = alpha gamma - beta^2    (the pivots are alpha and det / alpha),
+// the in-place step is  A <- A + PC PR  with  PC = -A[:, Q..Q+1] (+ I in rows Q, Q+1; the sign-symmetric state gives the columns
+// from the rows: + for rows already eliminated, - otherwise)  and  PR = D2 (A[Q..Q+1, :] + I in columns Q, Q+1): the block forms
+// of pc and pr above.  The OWNERS of the two rows put the "+ I"s and the signs in before the rows go to LDS, so the readers have
+// no special cases left: per pair one reciprocal chain (of det), four FMAs for PR and eight for the update.
+template <int Q>
+__device__ __forceinline__ void inv16_pivot2(double (&a)[4], double2* __restrict__ line /*[2][4][16]*/, int g, int cc, double& pmin) {
+  static_assert((Q & 1) == 0, "pairs start at an even pivot");
+  constexpr int QG = Q >> 2, QU = Q & 3, Q1 = Q + 1;
+  const double alpha = readlane_f64(a[QU], 16 * QG + Q);          // a[Q][Q]
+  const double beta = readlane_f64(a[QU], 16 * QG + Q1);          // a[Q][Q+1]
+  const double gamma = readlane_f64(a[QU + 1], 16 * QG + Q1);     // a[Q+1][Q+1]
+  // every lane group stores its rows 4g + QU, 4g + QU + 1 (straight-line code: a store under `if (g == QG)` lets the compiler run
+  // the other groups' reads first); group QG's lines are the pivot rows.  line[0..63]: the rows + I (PR's operand);
+  // line[64..127]: the signed rows + I (PC, read by ROW index).
+  int ccq = cc;
+  asm volatile("" : "+v"(ccq));                                  // (keeps the 8 pairs' lane constants from being formed up front: 48 VGPRs)
+  const double one0 = (ccq == Q) ? 1.0 : 0.0, one1 = (ccq == Q1) ? 1.0 : 0.0, sgn = (ccq < Q) ? 1.0 : -1.0;
+  line[16 * g + cc] = double2{a[QU] + one0, a[QU + 1] + one1};
+  line[64 + 16 * g + cc] = double2{fma(sgn, a[QU], one0), fma(sgn, a[QU + 1], one1)};
+  const double det = fma(alpha, gamma, -(beta * beta));
+  // (the tile arrives with a unit-diagonal matrix's scaling: the pivots ARE pivot / diagonal entry.  The second one, det / alpha,
+  //  only feeds threshold tests: the raw v_rcp_f64 is exact enough and keeps a second Newton chain out of the wave)
+  pmin = fmin(pmin, fmin(alpha, det * __builtin_amdgcn_rcp(alpha)));
+  double rdet = __builtin_amdgcn_rcp(det);                        // about 26 good bits; one cubic step: x (1 + e + e^2), e = 1 - det x
+  const double e = fma(-det, rdet, 1.0);
+  rdet = fma(fma(e, e, e), rdet, rdet);
+  const double w00 = gamma * rdet, w01 = -(beta * rdet), w11 = alpha * rdet;
+  const double2 p = line[16 * QG + cc];
+  const double2 s0 = line[64 + 16 * QG + 4 * g], s1 = line[64 + 16 * QG + 4 * g + 1];
+  const double2 s2 = line[64 + 16 * QG + 4 * g + 2], s3 = line[64 + 16 * QG + 4 * g + 3];
+  const double pr0 = fma(w00, p.x, w01 * p.y), pr1 = fma(w01, p.x, w11 * p.y);
+  a[0] = fma(s0.y, pr1, fma(s0.x, pr0, a[0]));
+  a[1] = fma(s1.y, pr1, fma(s1.x, pr0, a[1]));
+  a[2] = fma(s2.y, pr1, fma(s2.x, pr0, a[2]));
+  a[3] = fma(s3.y, pr1, fma(s3.x, pr0, a[3]));
+}
+
+// Returns the smallest pivot met (wave-uniform).  PAIR: the rank-2 form, what k_inverse_spd_mfma runs; the single pivots stay as
+// the reference form (tools/inv16_test.hip times and checks both).
+template <bool PAIR>
 __device__ __forceinline__ double inv16_wave(const double* __restrict__ src, double* __restrict__ dst,
-                                             double* __restrict__ line /* [4][16] doubles, wave-private */, int lane) {
+                                             double2* __restrict__ line /* [2][4][16] double2, wave-private */, int lane) {
   const int cc = lane & 15, g = lane >> 4;
   double pmin = 1.0e300;
   double a[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) a[u] = src[tile_lds_index(4 * g + u, cc)];
-  inv16_pivot<0>(a, line, g, cc, pmin);   inv16_pivot<1>(a, line, g, cc, pmin);   inv16_pivot<2>(a, line, g, cc, pmin);   inv16_pivot<3>(a, line, g, cc, pmin);
-  inv16_pivot<4>(a, line, g, cc, pmin);   inv16_pivot<5>(a, line, g, cc, pmin);   inv16_pivot<6>(a, line, g, cc, pmin);   inv16_pivot<7>(a, line, g, cc, pmin);
-  inv16_pivot<8>(a, line, g, cc, pmin);   inv16_pivot<9>(a, line, g, cc, pmin);   inv16_pivot<10>(a, line, g, cc, pmin);  inv16_pivot<11>(a, line, g, cc, pmin);
-  inv16_pivot<12>(a, line, g, cc, pmin);  inv16_pivot<13>(a, line, g, cc, pmin);  inv16_pivot<14>(a, line, g, cc, pmin);  inv16_pivot<15>(a, line, g, cc, pmin);
+  if constexpr (PAIR) {
+    inv16_pivot2<0>(a, line, g, cc, pmin);   inv16_pivot2<2>(a, line, g, cc, pmin);   inv16_pivot2<4>(a, line, g, cc, pmin);   inv16_pivot2<6>(a, line, g, cc, pmin);
+    inv16_pivot2<8>(a, line, g, cc, pmin);   inv16_pivot2<10>(a, line, g, cc, pmin);  inv16_pivot2<12>(a, line, g, cc, pmin);  inv16_pivot2<14>(a, line, g, cc, pmin);
+  } else {
+    double* l1 = reinterpret_cast<double*>(line);
+    inv16_pivot<0>(a, l1, g, cc, pmin);   inv16_pivot<1>(a, l1, g, cc, pmin);   inv16_pivot<2>(a, l1, g, cc, pmin);   inv16_pivot<3>(a, l1, g, cc, pmin);
+    inv16_pivot<4>(a, l1, g, cc, pmin);   inv16_pivot<5>(a, l1, g, cc, pmin);   inv16_pivot<6>(a, l1, g, cc, pmin);   inv16_pivot<7>(a, l1, g, cc, pmin);
+    inv16_pivot<8>(a, l1, g, cc, pmin);   inv16_pivot<9>(a, l1, g, cc, pmin);   inv16_pivot<10>(a, l1, g, cc, pmin);  inv16_pivot<11>(a, l1, g, cc, pmin);
+    inv16_pivot<12>(a, l1, g, cc, pmin);  inv16_pivot<13>(a, l1, g, cc, pmin);  inv16_pivot<14>(a, l1, g, cc, pmin);  inv16_pivot<15>(a, l1, g, cc, pmin);
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) dst[tile_lds_index(4 * g + u, cc)] = a[u];
   return pmin;
 }
 
+#ifdef PMF_INV_STAMPS     // diagnostic build (tools/stamp_inv.hip): shader-clock stamps per wave, block step and phase
+__device__ unsigned long long g_inv_dbg[16 * 8 * 4];
+#define INV_STAMP(step, ph) do { if (lane == 0) g_inv_dbg[(wv * 8 + (step)) * 4 + (ph)] = clock64(); } while (0)
+#else
+#define INV_STAMP(step, ph) do { } while (0)
+#endif
 template <int NBLK>   // matrix order 16 NBLK (identity padded beyond k): 4 -> 64, 8 -> 128
 __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
                                                                              double* __restrict__ Ginv64,
@@ -100,7 +156,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   __shared__ __attribute__((aligned(16))) double pR[NBLK][256];        // R_j = D A_pj
   __shared__ __attribute__((aligned(16))) double dsrc[256];            // the diagonal tile on its way into inv16_wave
   __shared__ __attribute__((aligned(16))) double dD[2][256];           // D of step p in dD[p & 1]
-  __shared__ __attribute__((aligned(32))) double line[64];   // inv16_wave's pivot rows, one per lane group
+  __shared__ __attribute__((aligned(32))) double2 line[128];  // inv16_wave's pivot rows: two per lane group, plain and signed
   __shared__ double sc[KP];                    // 1 / sqrt(g_ii)
   __shared__ int dflag;                        // = la once tile (la, la) of the look-ahead is in dsrc
   __shared__ double pivmin[NBLK];              // smallest pivot of each step's diagonal tile
@@ -109,7 +165,22 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   const int bi = wv / CW, j0 = 4 * (wv % CW);
   const int g = lane >> 4, cc = lane & 15;
   __shared__ double sdiag[KP];
+  // every global load of the launch goes out here, the tiles beside the diagonal (one L2 / HBM latency, not two in a row;
+  // round 5: the launch has a fixed cost of 7-9 us around its block steps, and this was 1 us of it)
   for (int i = tid; i < KP; i += 64 * NBLK * CW) sdiag[i] = i < k ? Gd[(int64_t)i * ld + i] : 0.0;
+  // (NBLK = 8 is at its 128-VGPR budget: there every tile entry is fetched where it is scaled, as before)
+  constexpr bool EARLY = NBLK == 4;
+  f64x4 c[4];
+  auto fetch_tiles = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * bi + g + 4 * r, col = 16 * (j0 + t) + cc;
+        c[t][r] = (row < k && col < k) ? Gd[(int64_t)row * ld + col] : (row == col ? 1.0 : 0.0);
+      }
+  };
+  if constexpr (EARLY) fetch_tiles();
   if (tid == 0) dflag = 0;
   __syncthreads();
   double dead_below = -1.0;                    // (without Gpatched: nothing is dead, as before)
@@ -121,17 +192,23 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   for (int i = tid; i < KP; i += 64 * NBLK * CW) {
     const bool live = i < k && (Gpatched == nullptr || sdiag[i] > dead_below);
     const double gii = live ? sdiag[i] : 1.0;
-    sc[i] = gii > 0.0 ? 1.0 / sqrt(gii) : 1.0;
+    // 1 / sqrt(g_ii): v_rsq_f64 and one Newton step.  inv(G) = S inv(S G S) S holds for ANY diagonal S; all the scaling has to
+    // do is bring the diagonal to 1 within rounding, and the same sc[] is used on the way in and on the way out.
+    double y = 1.0;
+    if (gii > 0.0) {
+      y = __builtin_amdgcn_rsq(gii);
+      y = y * fma(-(0.5 * gii) * y, y, 1.5);
+    }
+    sc[i] = y;
   }
   __syncthreads();
-  f64x4 c[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * bi + g + 4 * r, col = 16 * (j0 + t) + cc;
       const bool live = row < k && col < k && (Gpatched == nullptr || (sdiag[row] > dead_below && sdiag[col] > dead_below));
-      const double gv = live ? Gd[(int64_t)row * ld + col] : (row == col ? 1.0 : 0.0);
+      const double gv = live ? (EARLY ? c[t][r] : Gd[(int64_t)row * ld + col]) : (row == col ? 1.0 : 0.0);
       if (Gpatched != nullptr && row < ld && col < ld) Gpatched[(int64_t)row * ld + col] = gv;
       c[t][r] = live ? gv * sc[row] * sc[col] : gv;
     }
@@ -151,7 +228,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   if (bi == 0 && j0 == 0) {                    // D of step 0
     store_tile(dsrc, c[0]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const double pm = inv16_wave(dsrc, dD[0], line, lane);
+    const double pm = inv16_wave<true>(dsrc, dD[0], line, lane);
     if (lane == 0) pivmin[0] = pm;
   }
   if (bi == 0) {
@@ -160,6 +237,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   }
   for (int p = 0; p < nsteps; ++p) {
     __syncthreads();                           // pold[p & 1] and dD[p & 1] are in place
+    INV_STAMP(p, 0);
     const f64x4 D = load_tile(dD[p & 1]);
     const int la = p + 1;                      // look-ahead: tile (la, la) is brought up to date and inverted during this step
     const bool owns_diag = (bi >> 2) == (wv % CW);               // tile (bi, bi) is one of this wave's four
@@ -188,17 +266,19 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
     }
     f64x4 ap = {0.0, 0.0, 0.0, 0.0};
     if (bi != p) ap = load_tile(pold[p & 1][bi]);                // (A_pi)^T, the A operand of this step's updates: at hand since the first barrier
+    INV_STAMP(p, 1);
     __syncthreads();                           // R_j are in place
+    INV_STAMP(p, 2);
     if (bi == p) {                             // these waves have no update to do in this step ...
       if (j0 == 0 && la < nsteps) {            // ... so one of them inverts the look-ahead tile
         while (__hip_atomic_load(&dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != la) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_s_setprio(3);
-        const double pm = inv16_wave(dsrc, dD[la & 1], line, lane);
+        const double pm = inv16_wave<true>(dsrc, dD[la & 1], line, lane);
         __builtin_amdgcn_s_setprio(0);
         if (lane == 0) pivmin[la] = pm;
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) c[t] = (j0 + t == p) ? D : load_tile(pR[j0 + t]);   // new row panel
+      for (int t = 0; t < 4; ++t) c[t] = load_tile(j0 + t == p ? dD[p & 1] : pR[j0 + t]);   // new row panel (D once more from LDS: not held across the inversion)
     } else {
       const double msig = (bi < p) ? 1.0 : -1.0;                 // -sigma_i
 #pragma unroll
@@ -230,6 +310,7 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
         for (int t = 0; t < 4; ++t) store_tile(pold[(p + 1) & 1][j0 + t], c[t]);
       }
     }
+    INV_STAMP(p, 3);
   }
   bool bad = false;                            // a zero pivot (LAPACK's "singular matrix") leaves inf / nan behind
 #pragma unroll

@@ -1,11 +1,16 @@
 // diagnostic: time and accuracy of k_inverse_spd_mfma (pmf_inv.h) on a random Gram matrix H H^T, H k x 128 uniform
 // build: hipcc --offload-arch=gfx950 -O3 -I pymf_amd/csrc tools/stamp_inv.hip -o /tmp/stamp_inv ; run: /tmp/stamp_inv [k]
 #include <hip/hip_runtime.h>
-#include "/root/repo/pymf_amd/csrc/pmf_inv.h"
+
 #include <vector>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#ifndef PMF_INV_HEADER
+#define PMF_INV_HEADER "/root/repo/pymf_amd/csrc/pmf_inv.h"
+#endif
+#include PMF_INV_HEADER
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); return 1;}}while(0)
 template <int NBLK>
 int run(int k) {
@@ -26,7 +31,23 @@ int run(int k) {
   }
   std::vector<double> I((size_t)KP*KP); CK(hipMemcpy(I.data(),dI,KP*KP*8,hipMemcpyDeviceToHost));
   double worst=0; for (int i=0;i<KP;++i) for(int j=0;j<KP;++j){ double s=0; for(int t=0;t<KP;++t) s+=G[(size_t)i*KP+t]*I[(size_t)t*KP+j]; const double e=fabs(s-(i==j)); if(!(e<=worst)) worst=e; }
-  printf("max |G inv(G) - I| = %.3e\n", worst);
+#ifdef PMF_INV_STAMPS
+  {
+    const int nw = NBLK * (NBLK / 4), ns = (k + 15) / 16;
+    std::vector<unsigned long long> d(16 * 8 * 4);
+    CK(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(g_inv_dbg), d.size() * 8));
+    const unsigned long long t0 = d[0];
+    printf("stamps (shader cycles since wave 0 passed the first barrier): per step, [wave: after barrier 1 | R formed | after barrier 2 | step done]\n");
+    for (int p = 0; p < ns; ++p) {
+      printf(" step %d:", p);
+      for (int w = 0; w < nw; ++w) { const unsigned long long* q = &d[(w * 8 + p) * 4]; printf("  w%d %llu|%llu|%llu|%llu", w, q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0); }
+      printf("\n");
+    }
+  }
+#endif
+  unsigned long long h = 1469598103934665603ull;
+  for (double x : I) { unsigned long long b; memcpy(&b, &x, 8); h = (h ^ b) * 1099511628211ull; }
+  printf("max |G inv(G) - I| = %.3e   bits of the inverse: %016llx\n", worst, h);
   return 0;
 }
 int main(int argc, char** argv){
