@@ -961,6 +961,39 @@ def test_snmf_gram_space_loop_equals_pass_per_iteration(pm, shape, k, sparse):
         close(outs[0][2], o.ferr, rtol=2e-8, what="gram ferr vs oracle")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3, 15, 16, 17, 31, 33, 47, 63, 64, 65, 97, 111, 127, 128])
+def test_snmf_w_step_at_the_edges_of_the_inverse(pm, k):
+    """W = V H^T inv(H H^T) (snmf.py:67-70) hook by hook at base counts around the tiles of k_inverse_spd_mfma: the in-wave
+    16 x 16 inverse eliminates two pivots per step (rank-2 updates, closed-form 2 x 2 blocks), so odd k puts an identity row of
+    the padding into the last pair, k = 16 j +- 1 moves that pair across a tile boundary, and two nearly parallel rows of H
+    make one 2 x 2 pivot block itself ill-conditioned (det = alpha gamma - beta^2 cancels)."""
+    from pymf_amd import _lib
+    from oracle import SNMFOracle
+    rs = np.random.RandomState(4000 + k)
+    m, n = 600, max(2 * k + 8, 48)
+    V = (rs.random_sample((m, n)) - 0.4).astype(np.float32)
+    H0 = (rs.random_sample((k, n)) + 0.05).astype(np.float32)
+    if k >= 2:                                             # rows 0 and 1 nearly parallel: the FIRST pivot pair is the hard one
+        H0[1] = (H0[0] * 1.25 + 2e-2 * rs.random_sample(n)).astype(np.float32)
+    if k >= 18:                                            # ... and one pair in a later tile, straddling an even / odd boundary
+        H0[17] = (H0[16] * 0.8 + 2e-2 * rs.random_sample(n)).astype(np.float32)
+    W0 = rs.random_sample((m, k)).astype(np.float32)
+    c = _lib.Context(_lib.ALGO_SNMF, m, n, k)
+    c.set_v_dense(V); c.set_w(W0); c.set_h(H0)
+    c.update_w()
+    Wd = c.get_w()
+    c.close()
+    o = SNMFOracle(V, num_bases=k); o.W, o.H = W0.astype(np.float64), H0.astype(np.float64)
+    o.update_w()
+    cond = np.linalg.cond(H0.astype(np.float64) @ H0.astype(np.float64).T)
+    # float32 storage of M^T = inv(H H^T) H and of W, a float32-MFMA product over n columns: measured 1.1e-7 (k = 1) ... 3.1e-7
+    # (k = 128, cond 8e6) -- the float64 inverse does not show at all; a wrong pivot is an O(1) error
+    tol = 2e-6
+    assert np.all(np.isfinite(Wd))
+    assert rel_fro(Wd, o.W, what="W after update_w, k = %d (cond %.1e)" % (k, cond)) < tol
+
+
 # ---- BASELINE's other configs at FULL size: size-independent properties (cfg4's are above) ----------
 def test_pipelined_w_write_of_the_csr_gram_loop_is_bit_identical(pm):
     """snmf_gram = 2 on CSR data writes W = V M in every iteration (snmf.py:67-70 does); since round 4 that write runs on
