@@ -237,6 +237,90 @@ def cpu_baseline(cfg, m, n, k, budget_s=24.0, sample=None):
     return out
 
 
+_THREAD_ENV = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "GOTO_NUM_THREADS")
+
+
+def cpu_baseline_in_child(cfg, m, n, k):
+    """cpu_baseline() in a CHILD process that never touches the GPU, with the launchers' BLAS thread caps taken out of its
+    environment: torch.distributed.run exports OMP_NUM_THREADS=1 to every rank (bench.py's own launcher: cpu_count / N) and a
+    BLAS pool that started with one thread cannot be grown afterwards (threadpoolctl reports the new limit, the GEMM runs at
+    the old speed -- measured) -- "the host's cores" would be one core.  Returns (cpu_baseline dict, oracle factors or None)."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="pymf_bench_cpu_")
+    try:
+        env = dict((a, b) for a, b in os.environ.items() if a not in _THREAD_ENV)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", tmp, "--config", cfg,
+                        "--rows", str(m), "--cols", str(n), "--bases", str(k)], env=env, check=True, stdout=sys.stderr)
+        cb = json.load(open(os.path.join(tmp, "cpu_baseline.json")))
+        fac = None
+        fp = os.path.join(tmp, "factors.npz")
+        if os.path.exists(fp):
+            z = np.load(fp)
+            fac = {"iters": int(z["meta"][0]), "ferr": float(z["meta"][1]), "W": z["W"], "H": z["H"]}
+        return cb, fac
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _cpu_baseline_child(tmp, cfg, m, n, k):
+    cb = cpu_baseline(cfg, m, n, k)
+    fac = cb.pop("_oracle_factors", None)
+    cb.pop("_parity", None)
+    if fac is not None and "ferr" in fac:          # the dense NMF configs: what the sharded device run is compared with
+        np.savez(os.path.join(tmp, "factors.npz"), W=fac["W"], H=fac["H"], meta=np.array([float(fac["iters"]), fac["ferr"]]))
+    cb["process"] = "a child of rank 0 without the launcher's BLAS thread caps (%s)" % ", ".join(_THREAD_ENV[:2])
+    with open(os.path.join(tmp, "cpu_baseline.json"), "w") as fh:
+        json.dump(cb, fh)
+
+
+def sharded_parity_nmf(ctx, dist, fac, m, n, k, lo, hi):
+    """`parity_full_size` of the ROW-SHARDED run (what the sharding changes is the m-reduction of
+    nmf.py:124-125).  Collective.  Rank 0 holds the float64 oracle's factors after `iters` iterations of the FULL problem from
+    the seeded W0 / H0 (cpu_baseline's timing loop); every rank restarts its shard from the same W0 rows / H0, runs the same
+    number of iterations through the real exchange, and compares ITS row block of W with the oracle's (scattered by rank 0) and
+    the replicated H with the oracle's H.  Also: a digest of every rank's device H -- the design's central invariant is that H
+    is bit-identical on all ranks (the N partials are added in rank order everywhere)."""
+    import hashlib
+    w = dist.world()
+    head = dist.broadcast_array(np.array([float(fac["iters"]), float(fac["ferr"])]) if w.rank == 0 else None)
+    iters, ferr_ref = int(head[0]), float(head[1])
+    Href = dist.broadcast_array(fac["H"] if w.rank == 0 else None)
+    los, his = dist.allgather_int(lo), dist.allgather_int(hi)
+    blob = dist.scatter_bytes([np.ascontiguousarray(fac["W"][a:b]).tobytes() for a, b in zip(los, his)] if w.rank == 0 else None,
+                              tag="oracleW")
+    Wref = np.frombuffer(blob, dtype=np.float64).reshape(hi - lo, k)
+    np.random.seed(42)
+    rs = np.random.mtrand._rand
+    ctx.set_w(gen_rows(rs, m, k, lo, hi))
+    ctx.set_h(np.random.random((k, n)))
+    _, done, _ = ctx.factorize(iters, compute_err=False)
+    Wd, Hd = ctx.get_w(), ctx.get_h()
+    ferr_d = ctx.frobenius()                       # collective: ||V||^2 and the trace terms are summed over the ranks
+    d = Wd.astype(np.float64) - Wref
+    mine = np.array([float(np.sum(d * d)), float(np.sum(Wref * Wref)), float(np.max(np.abs(d))),
+                     float(np.linalg.norm(Hd - Href) / np.linalg.norm(Href)), float(ferr_d), float(done)])
+    rows = [np.frombuffer(b, dtype=np.float64) for b in dist.allgather_bytes(mine.tobytes(), tag="parity")]
+    digests = dist.allgather_bytes(hashlib.sha256(np.ascontiguousarray(Hd).tobytes()).digest(), tag="Hdigest")
+    if w.rank != 0:
+        return None
+    rel_rank = [float(np.sqrt(r[0] / r[1])) for r in rows]
+    return {"iters": int(min(r[5] for r in rows)), "ranks": w.size,
+            "relW": float(np.sqrt(sum(r[0] for r in rows) / sum(r[1] for r in rows))),
+            "relW_per_rank": rel_rank, "relW_max_over_ranks": max(rel_rank),
+            "max_abs_W": max(float(r[2]) for r in rows),
+            "relH": float(rows[0][3]), "relH_max_over_ranks": max(float(r[3]) for r in rows),
+            "h_identical_across_ranks": all(dg == digests[0] for dg in digests),
+            "relferr": float(abs(rows[0][4] - ferr_ref) / ferr_ref), "ferr_gpu": float(rows[0][4]), "ferr_ref": ferr_ref,
+            "ferr_identical_across_ranks": all(r[4] == rows[0][4] for r in rows),
+            "tolerance": 2e-5, "tolerance_ferr": 1e-5,
+            "against": "oracle (NumPy restatement of nmf.py:122-132, float64 W/H, float32 V) on the UNSHARDED %dx%d problem, k=%d, on "
+                       "rank 0; the device run is sharded over %d ranks through the real per-iteration exchange, same seeded W0/H0, "
+                       "same iteration count; every rank compares its own row block of W (scattered by rank 0); "
+                       "||X_gpu - X_ref||_F / ||X_ref||_F" % (m, n, k, w.size)}
+
+
 def _visible_devices(timeout=180.0):
     """The number of GPUs a rank process will see, counted by a CHILD process (pmf_device_count): the launcher itself makes
     no HIP call (a process that has initialised the GPU must not be the parent that replaces / outlives the ranks)."""
@@ -347,7 +431,13 @@ def main():
                     help="pmf_set_option(NAME, VALUE) on the bench context (A/B measurements of tuning knobs)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="--gpus N > 1 without a launcher: wall-clock limit (s) for the N rank processes this script starts")
+    ap.add_argument("--cpu-baseline-child", metavar="DIR", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_child:                    # (rank 0's helper at N > 1: the oracle on the host's cores, no GPU, no ranks)
+        algo_name, m, n, k, _, _ = CONFIGS[args.config]
+        _cpu_baseline_child(args.cpu_baseline_child, args.config, args.m or m, args.n or n, args.k or k)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher (never touching the GPU in THIS process) and exit with the job's status
@@ -415,6 +505,17 @@ def main():
             host["W0"], host["H0"] = W0, H0      # for the from-the-random-start rate (below)
         del W0, H0
 
+    # ---- the COLD figure: the very first factorize(K) of this context on resident data -- no pre-roll, no
+    # warm-up, the chip at whatever clock it idles at, one-time work of a first call included; printed as a top-level sibling
+    # of the pre-rolled `value` so that both clock states are one glance apart ----
+    ctx.synchronize()
+    dist.barrier()
+    tc = time.perf_counter()
+    _, done_c, _ = ctx.factorize(args.steps, compute_err=False)
+    ctx.synchronize()
+    cold_dt = dist.allreduce_max(time.perf_counter() - tc)
+    cold_rate = done_c / cold_dt
+
     # ---- disclosed pre-conditioning (untimed, reported as "preroll_ms" / "preroll_iters") ----
     preroll_iters, preroll_ms = 0, 0.0
     state_dependent = algo_name == "NMFALS"      # the cost of an ALS iteration depends on how settled the active sets are
@@ -433,6 +534,10 @@ def main():
             # first iterations (every row QP still changing its active set) -- the settled rate is reported beside it.
             ctx.set_w(host["W0"])
             ctx.set_h(host["H0"])
+
+    elif state_dependent and "W0" in host:       # (no pre-roll: the cold call above still moved the factors)
+        ctx.set_w(host["W0"])
+        ctx.set_h(host["H0"])
 
     # ---- warm-up (untimed) ----
     if args.warmup > 0:
@@ -466,6 +571,35 @@ def main():
     launch_ms = np.sort(all_ms)
     first_ms = [round(float(x), 4) for x in all_ms[:5]]
     ctx.profile_enable(False)
+    per_rank_kernel_ms = dist.allgather_float(stats["mean_ms"])        # every rank's shard kernel: a slow GPU shows
+    # ---- N > 1: the OTHER transport in the same run.  `value` above rode on the one-shot exchange when it
+    # passed its self-test; the same K steps once more with the per-iteration sum carried by the transport behind it --
+    # ncclAllReduce (RCCL) on a multi-GPU node, the host round trip where the ranks share a GPU (RCCL refuses that set-up) ----
+    other_transport = None
+    if w.size > 1 and algo_name == "NMF":
+        behind = ("host transport (TCP star through rank 0; the ranks share GPU 0 and RCCL refuses two ranks on one GPU) -- "
+                  "NOT RCCL, a plumbing figure" if dist.transport() in ("host", "ipc") else "ncclAllReduce (RCCL)")
+        if dist.LAST_SETUP.get("oneshot") == "passed":
+            ctx.set_option("oneshot_allreduce", 0)                     # every rank, at the same point of its call sequence
+            ctx.factorize(max(args.warmup, 2), compute_err=False)
+            ctx.profile_enable(True)
+            ctx.synchronize()
+            dist.barrier()
+            t6 = time.perf_counter()
+            _, done_o, _ = ctx.factorize(args.steps, compute_err=False)
+            ctx.synchronize()
+            d6 = time.perf_counter() - t6
+            dist.barrier()
+            d6 = dist.allreduce_max(d6)
+            oc_ms, oc_n = ctx.collective_ms()
+            ctx.profile_enable(False)
+            ctx.set_option("oneshot_allreduce", 1)
+            ctx.factorize(2, compute_err=False)                        # (back on the main path, and both slots exercised again)
+            other_transport = {"transport": behind, "iters_per_sec": done_o / d6, "ms_per_step": d6 / max(done_o, 1) * 1e3,
+                               "steps": done_o, "collective_mean_ms": oc_ms if oc_n else None, "collective_launches": oc_n}
+        else:
+            other_transport = {"transport": behind, "skipped": "the one-shot exchange is not in front of it (%s): `value` itself "
+                               "was carried by this transport" % dist.LAST_SETUP.get("oneshot")}
     # NMFALS: the rate once the active sets have settled (about 300 iterations from the seeded start), same K steps
     settled, qp_counts = None, None
     if state_dependent:
@@ -622,6 +756,23 @@ def main():
         del Wd, Hd
     host.clear()
 
+    # ---- N > 1: the host-CPU number and the parity of the SHARDED run in the same line.  Rank 0 times the
+    # oracle on the host's cores AFTER every timed region (the other ranks wait in the barrier behind it: the rendezvous sockets
+    # block without a time limit, and nothing is being measured any more); the sharded parity run follows on all ranks ----
+    cb_multi, par_multi = None, None
+    if w.size > 1 and not args.no_cpu_baseline:
+        fac_m = None
+        if w.rank == 0:
+            cb_multi, fac_m = cpu_baseline_in_child(args.config, m, n, k)
+            cb_multi["note"] = "rank 0 of %d, after the timed regions; the other ranks idle in a barrier meanwhile" % w.size
+        dist.barrier()
+        if algo_name == "NMF" and args.fill == "numpy":
+            par_multi = sharded_parity_nmf(ctx, dist, fac_m, m, n, k, lo, hi)
+        elif w.rank == 0:
+            par_multi = {"skipped": "the sharded full-size comparison is built for the dense NMF configs with the BASELINE (numpy) fill; "
+                                    "%s / --fill %s at N > 1 is covered by tests/test_dist_ranks.py on small problems" % (args.config, args.fill)}
+        del fac_m
+
     if w.rank == 0:
         mean_s = stats["mean_ms"] * 1e-3
         fl, ex, by = stats["flops_per_launch"], stats["executed_flops_per_launch"], stats["bytes_per_launch"]
@@ -655,6 +806,7 @@ def main():
             "preroll_ms": preroll_ms,
             "preroll_iters": preroll_iters,
             "ms_per_step": dt / args.steps * 1e3,
+            "cold_iters_per_sec": cold_rate,       # the first factorize(K) on resident data: no pre-roll, no warm-up (see preroll_ms)
             "rank_ms_per_step": [x / args.steps * 1e3 for x in rank_dt],
             "higher_is_better": True,
             "scaling": "strong",
@@ -671,6 +823,9 @@ def main():
                                        else "external launcher (WORLD_SIZE in the environment)") if w.size > 1 else None,
                        "collective_mean_ms": coll_ms if coll_n else None,      # HIP events around the per-iteration sum, this rank
                        "collective_launches": coll_n,
+                       "other_transport_same_run": other_transport,
+                       "rccl_only_iters_per_sec": (other_transport or {}).get("iters_per_sec") if w.size > 1 and dist.transport() == "rccl" else None,
+                       "rccl_collective_mean_ms": (other_transport or {}).get("collective_mean_ms") if w.size > 1 and dist.transport() == "rccl" else None,
                        "compute_err_true_iters_per_sec": rate_err,
                        "class_factorize": class_rate,
                        "first_call": (class_rate or {}).get("first_call"),
@@ -687,6 +842,7 @@ def main():
                          "launches_in_timed_region": args.steps if algo_name != "NMFALS" else stats["launches"],
                          "timed_every": timed_every,
                          "mean_kernel_ms": stats["mean_ms"],
+                         "per_rank_kernel_ms": per_rank_kernel_ms,      # rank order; `achieved` is rank 0's shard kernel
                          "min_kernel_ms": float(launch_ms[0]) if len(launch_ms) else None,
                          "median_kernel_ms": float(np.median(launch_ms)) if len(launch_ms) else None,
                          "max_kernel_ms": float(launch_ms[-1]) if len(launch_ms) else None,
@@ -752,6 +908,9 @@ def main():
                                      "iteration, as the reference's update_w does; the write of iteration i runs on a stream of its "
                                      "own beside the k x n sized kernels of iteration i + 1 (option snmf_w_pipe; 0 = stream order)"
                                      if stats["name"].startswith("k_csr_w") else "one pass over the CSR rows per iteration")
+        if cb_multi is not None:
+            out["cpu_baseline"] = cb_multi
+            out["parity_full_size"] = par_multi
         if w.size == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.config, m, n, k, sample=als_sample)
             fac = cb.pop("_oracle_factors", None)

@@ -1263,13 +1263,13 @@ int nmf_update_w(pmf_ctx* c) {
   return wrc;
 }
 
-template <int NT, bool BNMF>
-int launch_h_gram(pmf_ctx* c) {
+template <int NT, bool BNMF, bool FOLD>
+int launch_h_gram_as(pmf_ctx* c) {
   constexpr size_t smem = hgram_smem_bytes<NT>();
   static bool attr_done_dev[PMF_MAX_DEVICES] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[pmf_current_device()];
   if (!attr_done) {
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, BNMF>),
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nmf_h_gram<NT, BNMF, FOLD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
@@ -1277,16 +1277,21 @@ int launch_h_gram(pmf_ctx* c) {
   // inside pmf_factorize's fused loop the next reader of G is the fused kernel, which adds the
   // per-workgroup partials itself: the kernel then ends without waiting for its last workgroup
   const int final_sum = c->gram_partial_ok ? 0 : 1;
-  hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
+  hipLaunchKernelGGL((k_nmf_h_gram<NT, BNMF, FOLD>), dim3((unsigned)wgs), dim3(1024), smem, c->stream, c->dH, c->np, c->dPS,
                      c->dG, (double*)nullptr /* no reader of the float64 copy on the NMF/BNMF paths */, BNMF ? (float)c->lamb_h : 0.f, c->want_trace ? c->dScal + 2 : nullptr,
                      c->dGpart, c->dT1part, c->dTicket, c->stop_arg, final_sum,
-                     c->fold_seq ? c->ipc : IpcPeers{}, c->fold_seq, c->fold_flags, c->dIpcErr, c->ipc_wait_ticks,
+                     FOLD ? c->ipc : IpcPeers{}, c->fold_seq, c->fold_flags, c->dIpcErr, c->ipc_wait_ticks,
                      c->profile ? c->dIpcWait : nullptr);
   c->fold_seq = 0;                    // consumed
   HIPCHK(c, hipGetLastError());
   c->g_parts = final_sum ? 0 : wgs;
   c->trace_parts = final_sum ? 0 : wgs;
   return PMF_OK;
+}
+// the folded exchange's consumer is an instantiation of its own (FOLD): the one-rank kernel carries none of it
+template <int NT, bool BNMF>
+int launch_h_gram(pmf_ctx* c) {
+  return (c->fold_seq && c->ipc.nranks > 1) ? launch_h_gram_as<NT, BNMF, true>(c) : launch_h_gram_as<NT, BNMF, false>(c);
 }
 
 // NMF / BNMF: H step and G = H H^T in one launch.  false: not for this algorithm.
@@ -1435,7 +1440,7 @@ int nmf_fused_pass(pmf_ctx* c) {
     // the folded exchange: this launch pushes the rank's partial tiles to every peer, the H-step launch behind it waits for
     // the peers' and adds them in rank order (h_step_from_ps -> launch_h_gram) -- only inside nmf_fused_iteration, where that
     // launch is certain to follow on every rank
-    const bool fold = c->fold_loop && c->opt_fold && c->ipc.nranks > 1 && ntu <= PMF_IPC_MAX_WGS &&
+    const bool fold = c->fold_loop && c->opt_fold && c->ipc.nranks > 1 && ntu <= PMF_IPC_MAX_WGS && c->np / 64 <= PMF_HGRAM_MAX_WGS &&
                       (size_t)ps_elems(c) * sizeof(float) <= PMF_IPC_MAX_BYTES &&
                       (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->nb == 1;
     const unsigned seq = fold ? ++c->ipc_seq : 0u;
@@ -2630,8 +2635,12 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       const int chunk = std::min(kChunk, niter - i);
       c->stop_arg = c->dStop;
       const double lamb_w0 = c->lamb_w, lamb_h0 = c->lamb_h;   // BNMF: every H step scales them (bnmf.py:84-85)
+      const unsigned ipc_seq0 = c->ipc_seq;
+      const long long fold_calls0 = c->fold_calls;
+      unsigned seq_after[kChunk];                           // the exchange counter behind iteration i + j
       int lrc = PMF_OK;
       for (int j = 0; j < chunk && lrc == PMF_OK; ++j) {
+        seq_after[j] = c->ipc_seq;                          // (overwritten below once the iteration is enqueued)
         c->gram_partial_ok = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && i + j + 1 < niter && !c->fused8;
         if (h_only) {
           lrc = ensure_ps(c);                               // current since the first iteration (W is fixed)
@@ -2659,6 +2668,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
                              (double)c->n, i + j, c->dFerr, c->dStop);
           if (hipGetLastError() != hipSuccess) lrc = fail(c, PMF_EHIP, "k_conv_check launch failed");
         }
+        seq_after[j] = c->ipc_seq;
       }
       c->stop_arg = nullptr;
       c->conv_iter = -1;
@@ -2676,6 +2686,18 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
       // all-reduces still ran on the stale (P | S): it no longer belongs to W)
       const int s_it = hstop[1];
       done += s_it - i + 1;
+      // The FOLDED exchanges behind the stop neither pushed nor waited (k_reduce_slabs_tiles / k_nmf_h_gram return on the
+      // flag), on every rank alike (H, and with it the stop, is bit-identical across ranks): take their sequence numbers back,
+      // so that the next exchange that really runs is the successor of the last one that did.  Counting the skipped ones
+      // broke the two-slot invariant of pmf_ipc.h (a rank is at most one exchange ahead of a peer BECAUSE it needs that
+      // peer's flags of exchange s + 1 before it can push s + 2 into the slot of s): after an odd number of skipped exchanges
+      // the next push could land in a slot a slower peer was still adding up (round-5 advisor).  k_ipc_allreduce launches
+      // run whatever the flag says, so a chunk that used those keeps its count.
+      if (c->fold_calls - fold_calls0 == (long long)(c->ipc_seq - ipc_seq0) && c->ipc_seq != ipc_seq0) {
+        const long long skipped = (long long)(c->ipc_seq - seq_after[s_it - i]);
+        c->ipc_seq = seq_after[s_it - i];
+        c->ipc_calls -= skipped; c->fold_calls -= skipped;
+      }
       if (c->algo == PMF_ALGO_BNMF) {                     // only s_it - i + 1 H steps really ran
         c->lamb_w = lamb_w0; c->lamb_h = lamb_h0;
         for (int q = 0; q < s_it - i + 1; ++q) { c->lamb_w *= 1.1; c->lamb_h *= 1.1; }
@@ -3339,6 +3361,12 @@ int pmf_ipc_selftest(pmf_ctx* c, int32_t rounds, int32_t* ok) {
   c->ipc_wait_ticks = 2ull * 100000000ull;             // 2 s: the ranks enter the test together
   // EVERY rank runs EVERY round whatever it has seen so far: a rank that left early would leave its peers waiting in the
   // next round's collectives
+  if (rounds < 2) rounds = 2;                          // (odd rounds run the split form the loop uses: never skipped)
+  // the split form at THIS context's sizes: one flag per (P | S) tile of k_reduce_slabs_tiles, polled by every workgroup of
+  // a consumer grid as large as launch_h_gram's
+  const int ntu_ctx = c->NT * (c->np / 16) + c->NT * (c->NT + 1) / 2;
+  const int nfl = ntu_ctx >= 1 && ntu_ctx <= PMF_IPC_MAX_WGS ? ntu_ctx : 74;   // (74: 64 bases x 256 columns)
+  const int npull = std::max(1, std::min(c->np / 64, PMF_HGRAM_MAX_WGS));
   for (int t = 0; t < rounds; ++t) {
     for (size_t i = 0; i < count; ++i) x[i] = (float)((c->ipc.me + 1) * (t + 1)) + 0.001f * (float)(i % 977);
     const size_t cnt = t % 3 == 2 ? std::max<size_t>(1, count / 3) : count;      // (a shorter payload now and then)
@@ -3349,9 +3377,8 @@ int pmf_ipc_selftest(pmf_ctx* c, int32_t rounds, int32_t* ok) {
       // the SPLIT form the loop uses (push inside a producer launch of many workgroups, wait + rank-ordered sum inside a
       // consumer launch): same slots, flags and sequence counter
       const unsigned seq = ++c->ipc_seq;
-      const int nfl = 74;                              // the tile count of k_reduce_slabs_tiles at 64 bases x 256 columns
       hipLaunchKernelGGL(k_ipc_fold_push, dim3(nfl), dim3(256), 0, c->stream, dA, (int64_t)cnt, c->ipc, seq);
-      hipLaunchKernelGGL(k_ipc_fold_pull, dim3(4), dim3(1024), 0, c->stream, dA, (int64_t)cnt, c->ipc, seq, nfl, c->dIpcErr, c->ipc_wait_ticks);
+      hipLaunchKernelGGL(k_ipc_fold_pull, dim3(npull), dim3(1024), 0, c->stream, dA, (int64_t)cnt, c->ipc, seq, nfl, c->dIpcErr, c->ipc_wait_ticks);
       if (hipGetLastError() != hipSuccess) { rc = PMF_EHIP; good = false; }
       ++c->ipc_calls;
     } else if (allreduce_sum(c, dA, cnt, false) != PMF_OK) { rc = PMF_EHIP; good = false; }

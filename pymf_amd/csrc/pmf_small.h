@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_nmf_h(float* __restrict__ H, int64_t ld
 template <int NT>
 constexpr size_t hgram_smem_bytes() { return (size_t)(16 * NT * (16 * NT + 4) + 2 * 16 * NT * 68) * sizeof(float); }
 
-template <int NT, bool BNMF>
+template <int NT, bool BNMF, bool FOLD>
 __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int np,
                                                      float* __restrict__ PS,
                                                      float* __restrict__ Gf, double* __restrict__ Gd,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
                                                      const int* __restrict__ stop, int final_sum,
                                                      IpcPeers pr, unsigned seq, int nflags, int* __restrict__ ipc_err,
                                                      unsigned long long wait_ticks, unsigned long long* __restrict__ waitstat) {
-  // pr.nranks > 1 (round 5, the folded exchange): PS is NOT yet summed over the ranks -- every rank's k_reduce_slabs_tiles has
+  // FOLD (round 5, the folded exchange; pr.nranks > 1): PS is NOT yet summed over the ranks -- every rank's k_reduce_slabs_tiles has
   // pushed its partial into slot [seq & 1] of this rank's receive area (nflags tiles, one flag each).  The prologue waits for
   // the flags of all ranks, forms S and its P panels as the sums of the N partials IN RANK ORDER (the bits of
   // k_ipc_allreduce and of the host transport) while loading them, and writes the sums to PS (S: workgroup 0, P: the owner
@@ -87,7 +87,9 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
   __shared__ double red[2][16];
   __shared__ unsigned s_last;
   __shared__ int s_ipc_ok;
-  const bool fold = pr.nranks > 1;
+  // (a template parameter since round 6: as a run-time branch on pr.nranks the eight mapped areas and the fold's addressing stayed
+  // live beside the one-rank path and the 128-base instantiations spilled 88 / 120 bytes per lane at their 128-register budget)
+  constexpr bool fold = FOLD;
   constexpr int KP = 16 * NT, LDS_S = KP + 4, LDS_H = 68;
   constexpr int HT = NT * 4;                  // H-step tiles of a panel
   constexpr int HTW = (HT + 15) / 16;         // ... per wave
@@ -118,16 +120,33 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
     }
   };
   auto load_pv_fold = [&](int p) {                  // this wave's P values: sums of the ranks' partials, written back to PS
+    // rank by rank (the order of ipc_sum1: 0 + p_0 + p_1 + ...), 32-bit element offsets from one scalar base per rank (the
+    // payload is at most PMF_IPC_MAX_BYTES) and an opaque zero as in load_panel below: eight 64-bit row pointers per rank,
+    // hoisted out of the panel loop, were the scratch of the 128-base instantiations
     const int c0 = 64 * p;
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    const char* base = pr.area[pr.me] + (size_t)(seq & 1u) * pr.nranks * PMF_IPC_MAX_BYTES;
+#pragma unroll
+    for (int h = 0; h < HTW; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pv[h][r] = 0.f;
+    for (int rk = 0; rk < pr.nranks; ++rk) {
+      const float* src = reinterpret_cast<const float*>(base + (size_t)rk * PMF_IPC_MAX_BYTES);
+#pragma unroll
+      for (int h = 0; h < HTW; ++h) {
+        const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (q < HT) pv[h][r] += __builtin_nontemporal_load(src + ((16 * mt + 4 * kq + r + z) * (int)ldp + c0 + 16 * ct + i));
+      }
+    }
 #pragma unroll
     for (int h = 0; h < HTW; ++h) {
       const int q = wv + 16 * h, mt = q >> 2, ct = q & 3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t e = (int64_t)(16 * mt + 4 * kq + r) * ldp + c0 + 16 * ct + i;
-        pv[h][r] = 0.f;
-        if (q < HT) { pv[h][r] = ipc_sum1(pr, seq, e); PS[e] = pv[h][r]; }
-      }
+      for (int r = 0; r < 4; ++r)
+        if (q < HT) PS[(16 * mt + 4 * kq + r + z) * (int)ldp + c0 + 16 * ct + i] = pv[h][r];
     }
   };
   auto load_panel = [&](int p) {
@@ -160,8 +179,11 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
       const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
       if (q < KP * (KP / 4)) {
         const int64_t e = (int64_t)r * ldp + np + 4 * c4;
-        sreg[u] = ipc_sum4(pr, seq, e);
-        if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(PS + e) = sreg[u];
+        // (straight to LDS: nothing to overlap with after the wait, and four more live 16-byte registers beside the fold's
+        // addressing spilled at 128 bases)
+        const f32x4 sv = ipc_sum4(pr, seq, e);
+        if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(PS + e) = sv;
+        *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) = sv;
       }
     }
     if (blockIdx.x < npanel) load_pv_fold(blockIdx.x);
@@ -174,10 +196,12 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
   }
   if (!fold && blockIdx.x < npanel) load_panel(blockIdx.x);
   if (stop != nullptr && *stop != 0) return;
+  if (!fold) {
 #pragma unroll
-  for (int u = 0; u < SQ; ++u) {
-    const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
-    if (q < KP * (KP / 4)) *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) = sreg[u];
+    for (int u = 0; u < SQ; ++u) {
+      const int q = tid + 1024 * u, r = q / (KP / 4), c4 = q % (KP / 4);
+      if (q < KP * (KP / 4)) *reinterpret_cast<f32x4*>(ss + r * LDS_S + 4 * c4) = sreg[u];
+    }
   }
   // accumulator chains per G tile: four where a wave owns one tile (independent MFMAs back to back); at
   // num_bases > 64 a wave owns four tiles -- already four independent chains, and 64 accumulator registers
@@ -196,7 +220,8 @@ __global__ __launch_bounds__(1024) void k_nmf_h_gram(float* __restrict__ H, int 
 
   for (int p = blockIdx.x; p < npanel; p += gridDim.x) {
     const int c0 = 64 * p;
-    if (p != blockIdx.x) {                            // (grids of fewer workgroups than panels: np > 4096)
+    if (FOLD && p != blockIdx.x) break;               // (the folded payload is <= 256 KiB: np / 64 <= 63 panels, one per workgroup -- the host checks)
+    if (!FOLD && p != blockIdx.x) {                   // (grids of fewer workgroups than panels: np > 4096)
       __syncthreads();                                // the previous panel's images are free
       load_panel(p);
     }

@@ -93,31 +93,58 @@ class Watchdog(object):
     job instead of hanging.  ctypes releases the GIL during the C calls, so the timer thread does get to run."""
 
     EXIT_STATUS = 70
+    DEFAULT_SECONDS = 240.0
+    _active = 0            # time-boxes currently armed in this process: a nested one (setup_collectives inside make_context) rides on the outer
+
+    @classmethod
+    def default_seconds(cls):
+        """PYMF_DIST_INIT_TIMEOUT in seconds; unset, empty or not a number -> 240 (0 or negative: no time-box)."""
+        raw = os.environ.get("PYMF_DIST_INIT_TIMEOUT", "").strip()
+        if not raw:
+            return cls.DEFAULT_SECONDS
+        try:
+            return float(raw)
+        except ValueError:
+            sys.stderr.write("pymf_amd.dist: PYMF_DIST_INIT_TIMEOUT=%r is not a number of seconds; using %.0f\n" % (raw, cls.DEFAULT_SECONDS))
+            return cls.DEFAULT_SECONDS
 
     def __init__(self, what, seconds=None):
         self.what = what
-        self.seconds = float(seconds if seconds is not None else os.environ.get("PYMF_DIST_INIT_TIMEOUT", "240"))
+        self.explicit = seconds is not None
+        self.seconds = float(seconds) if seconds is not None else self.default_seconds()
         self._t = None
+        self._armed = False
 
     def _fire(self):
         try:
             sys.stderr.write("pymf_amd.dist: rank %d of %d is still in '%s' after %.0f s (PYMF_DIST_INIT_TIMEOUT); a peer rank died or "
                              "the transport does not come up -- giving up instead of hanging\n"
-                             % (_WORLD.rank, _WORLD.size, self.what, self.seconds))
-            sys.stderr.flush()
+                             % (_WORLD.rank if _WORLD else 0, _WORLD.size if _WORLD else 1, self.what, self.seconds))
+            for f in (sys.stdout, sys.stderr):     # what the process has buffered so far is not lost with it
+                try:
+                    f.flush()
+                except Exception:
+                    pass
         finally:
             os._exit(self.EXIT_STATUS)
 
     def __enter__(self):
-        if self.seconds > 0:
+        # one timer per start-up: a default-length box inside an armed one would only be a second, independent deadline
+        # for the same hang (an explicit `seconds` -- the tests' short boxes -- is always honoured)
+        if self.seconds > 0 and (self.explicit or Watchdog._active == 0):
             self._t = threading.Timer(self.seconds, self._fire)
             self._t.daemon = True
             self._t.start()
+            Watchdog._active += 1
+            self._armed = True
         return self
 
     def __exit__(self, *exc):
         if self._t is not None:
             self._t.cancel()
+        if self._armed:
+            Watchdog._active -= 1
+            self._armed = False
         return False
 
 
@@ -381,13 +408,13 @@ class CollectiveMismatch(RuntimeError):
     raised on every rank instead of pairing unrelated payloads or waiting for ever."""
 
 
-def allgather_bytes(payload, tag=""):
-    """list of every rank's payload, in rank order, on every rank.  Every frame carries (sequence number, tag): rank 0
-    checks that all ranks are making the SAME call and otherwise fails the collective on every rank (CollectiveMismatch)."""
+def _star(payload, tag, reply_for):
+    """One round trip through rank 0, the form of every collective here.  Every frame carries (sequence number, tag): rank 0
+    checks that all ranks are making the SAME call and otherwise fails the collective on every rank (CollectiveMismatch).
+    Rank 0 gets every rank's payload (`parts`, in rank order) and answers rank r with reply_for(parts, r); returns
+    (parts on rank 0 / None elsewhere, this rank's reply)."""
     global _SEQ
     w = _WORLD
-    if w.size == 1:
-        return [bytes(payload)]
     _SEQ += 1
     head = struct.pack("<Q8s", _SEQ, tag.encode()[:8])
     if w.rank == 0:
@@ -407,21 +434,57 @@ def allgather_bytes(payload, tag=""):
                 _send(_PEERS[q], b"\x01" + msg.encode())
             raise CollectiveMismatch(msg)
         parts = [bytes(payload)] + [f[16:] for f in frames]
-        blob = b"\x00" + b"".join(struct.pack("<Q", len(p)) + p for p in parts)
         for r in range(1, w.size):
-            _send(_PEERS[r], blob)
-        return parts
+            _send(_PEERS[r], b"\x00" + reply_for(parts, r))
+        return parts, reply_for(parts, 0)
     _send(_PEERS[0], head + bytes(payload))
     blob = _recv(_PEERS[0])
     if blob[:1] != b"\x00":
         raise CollectiveMismatch(blob[1:].decode("utf-8", "replace"))
-    blob = blob[1:]
+    return None, blob[1:]
+
+
+def allgather_bytes(payload, tag=""):
+    """list of every rank's payload, in rank order, on every rank."""
+    w = _WORLD
+    if w.size == 1:
+        return [bytes(payload)]
+    cache = {}
+
+    def everything(parts, r):
+        if "b" not in cache:
+            cache["b"] = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+        return cache["b"]
+    parts, blob = _star(payload, tag, everything)
+    if parts is not None:
+        return parts
     parts, off = [], 0
     while off < len(blob):
         (n,) = struct.unpack_from("<Q", blob, off)
         parts.append(blob[off + 8:off + 8 + n])
         off += 8 + n
     return parts
+
+
+def gather_bytes(payload, tag="gather"):
+    """Every rank's payload on rank 0 (list in rank order); None on the other ranks -- a W block per rank need not travel to
+    all of them."""
+    if _WORLD.size == 1:
+        return [bytes(payload)]
+    parts, _ = _star(payload, tag, lambda parts, r: b"")
+    return parts
+
+
+def scatter_bytes(parts, tag="scatter"):
+    """Rank 0 passes one payload per rank (`parts`, rank order; ignored elsewhere); rank r gets parts[r]."""
+    w = _WORLD
+    if w.size == 1:
+        return bytes(parts[0])
+    if w.rank == 0 and len(parts) != w.size:
+        raise ValueError("scatter_bytes: %d payloads for %d ranks" % (len(parts), w.size))
+    mine = parts if w.rank == 0 else None
+    _, got = _star(b"", tag, lambda _parts, r: bytes(mine[r]))
+    return got
 
 
 def broadcast_bytes(payload, src=0, tag="bcast"):

@@ -96,6 +96,10 @@ class _LateDataCheck(object):
             raise self.err
         return self.fp != self.owner._v_fp
 
+    def finish(self):
+        self.thread.join()
+        self.ctx.abort(False)
+
     def restart(self):
         o, ctx = self.owner, self.ctx
         ctx.abort(False)
@@ -580,6 +584,12 @@ class NMF(object):
                 # whose step may fail had it flushed before the call)
                 self._after_failed_call(ctx, snap)
                 raise
+            finally:
+                # however this call ends (KeyboardInterrupt between the loop and the digest's verdict, an error re-raised from
+                # the side thread): the digest thread has finished with `data` and the context's abort request is withdrawn --
+                # a flag left set would make the NEXT pmf_factorize return at once with iters_done = 0 and no error (round-5 advisor)
+                if late is not None:
+                    late.finish()
         self._last_iters = done
         self._pull(ctx, compute_w and done > 0, compute_h and done > 0)
         if hasattr(ctx, "last_loop_ms"):

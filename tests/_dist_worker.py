@@ -82,6 +82,25 @@ def main():
     assert np.array_equal(Hl, np.random.random((k, n)))
     got = dist.broadcast_array(np.arange(6, dtype=np.float32).reshape(2, 3) * (w.rank + 1), src=w.size - 1)
     assert np.array_equal(got, np.arange(6, dtype=np.float32).reshape(2, 3) * w.size)
+    # round 6 (bench.py's sharded parity): rank 0 hands every rank ITS block, and collects one block per rank, without the
+    # payloads travelling to everybody -- same frame check (sequence number + tag) as every other collective
+    blocks = [np.full((r + 2, 3), float(r + 1)) for r in range(w.size)]
+    mine = np.frombuffer(dist.scatter_bytes([b.tobytes() for b in blocks] if w.rank == 0 else None, tag="blk"), dtype=np.float64)
+    assert mine.shape == ((w.rank + 2) * 3,) and np.all(mine == float(w.rank + 1))
+    back = dist.gather_bytes((mine * 2.0).tobytes(), tag="blk2")
+    if w.rank == 0:
+        assert [np.frombuffer(b, dtype=np.float64)[0] for b in back] == [2.0 * (r + 1) for r in range(w.size)]
+        assert [len(b) for b in back] == [8 * 3 * (r + 2) for r in range(w.size)]
+    else:
+        assert back is None
+    try:                                   # a scatter on rank 0 against a gather elsewhere: different tags -> every rank fails loudly
+        if w.rank == 0:
+            dist.scatter_bytes([b"x"] * w.size, tag="one")
+        else:
+            dist.gather_bytes(b"y", tag="other")
+        raise AssertionError("mismatched collectives went through")
+    except dist.CollectiveMismatch:
+        pass
     if "--assert-no-torch" in sys.argv:
         assert "torch" not in sys.modules, "the product must not import torch"
     dist.shutdown()

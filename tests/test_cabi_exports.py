@@ -175,3 +175,29 @@ def test_a_library_built_from_other_sources_is_refused(monkeypatch):
         _lib.load()
     monkeypatch.undo()
     assert _lib.load() is not None
+
+
+# Kernels allowed to keep a private (scratch) segment, with its size in bytes per lane.  k_snmf_csr_mfma<8, 8>: round 1's
+# one-pass CSR kernel at 128 bases -- 512 registers, three spilled dwords; not selected by default (the Gram-space loop and
+# k_csr_w_blocks carry cfg5), kept for the pass-per-iteration A/B in bench.py.
+SCRATCH_ALLOWED = {"k_snmf_csr_mfma<8, 8>": 12}
+
+
+def test_no_product_kernel_uses_scratch(lib):
+    """k_nmf_h_gram<8,*> picked up 88-120 B of scratch per lane when the folded exchange's arguments
+    arrived and nobody noticed.  Every gfx950 kernel of the built library is read back (AMDGPU metadata notes of the code
+    objects: .private_segment_fixed_size) and a non-zero entry outside the allow-list above fails the suite."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_regs
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf of the ROCm image is not here")
+    rows = kernel_regs.kernels(lib.LIB_PATH)
+    assert len(rows) > 200, "the metadata of the code objects was not found (%d kernels)" % len(rows)
+    bad = [(r["dem"], r["scratch"]) for r in rows
+           if int(r["scratch"]) != 0 and SCRATCH_ALLOWED.get(r["dem"]) != int(r["scratch"])]
+    assert not bad, "kernels with a private segment (spills): %s" % bad
+    # the instantiations the verdict named, by name: both forms of the 128-base H step, folded exchange or not
+    names = {r["dem"] for r in rows}
+    for want in ("k_nmf_h_gram<8, false, false>", "k_nmf_h_gram<8, true, false>", "k_nmf_h_gram<8, false, true>", "k_nmf_h_gram<8, true, true>"):
+        assert want in names, want

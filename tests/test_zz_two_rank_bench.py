@@ -59,6 +59,12 @@ def test_two_rank_bench_line_on_one_gpu():
     assert j["roofline"]["traffic_source"] and j["config"]["class_factorize"] is None
     assert "one-shot IPC all-reduce" in j["config"]["collective"] and "ipc 0 (" not in j["config"]["collective"], j["config"]["collective"]
     assert j["config"]["collective_launches"] == 20 and 0.0 < j["config"]["collective_mean_ms"] < 5.0, j["config"]
+    # round 6: both clock states side by side, every rank's shard kernel, and the OTHER transport timed in the same run
+    assert 0.0 < j["cold_iters_per_sec"] and len(j["roofline"]["per_rank_kernel_ms"]) == 2
+    ot = j["config"]["other_transport_same_run"]
+    assert ot["steps"] == 20 and ot["iters_per_sec"] > 0 and "NOT RCCL" in ot["transport"], ot
+    assert j["config"]["rccl_only_iters_per_sec"] is None       # (two ranks on one GPU: there is no RCCL figure to report)
+    assert "cpu_baseline" not in j                              # --no-cpu-baseline
 
 
 @pytest.mark.gpu
@@ -73,8 +79,8 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--rows", "131072",
-           "--fill", "device", "--no-cpu-baseline", "--preroll-ms", "20"]
-    p = subprocess.run(cmd + ["--debug-share-gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+           "--preroll-ms", "20"]
+    p = subprocess.run(cmd + ["--debug-share-gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=env)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()
@@ -85,7 +91,21 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert "bench.py itself" in cfgj["launched_by"]
     assert "one-shot IPC all-reduce" in cfgj["collective"] and "ipc 0 (" not in cfgj["collective"], cfgj["collective"]
     assert cfgj["collective_launches"] == 20 and cfgj["collective_mean_ms"] is not None
+    # the N > 1 line is a COMPLETE measurement -- the host-CPU number (rank 0, its BLAS pool not capped by the
+    # launcher) and the parity of the SHARDED run against the unsharded float64 oracle, per rank, with H bit-identical across
+    # the ranks; the transport behind the one-shot exchange timed in the same run (here the host transport, labelled so)
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and "rank 0 of 2" in cb["note"], cb
+    par = j["parity_full_size"]
+    assert par["ranks"] == 2 and par["iters"] >= 4 and len(par["relW_per_rank"]) == 2, par
+    assert par["h_identical_across_ranks"] is True and par["ferr_identical_across_ranks"] is True, par
+    assert par["relW_max_over_ranks"] <= par["tolerance"] and par["relH_max_over_ranks"] <= par["tolerance"], par
+    assert par["relferr"] <= par["tolerance_ferr"], par
+    ot = cfgj["other_transport_same_run"]
+    assert ot["iters_per_sec"] > 0 and "NOT RCCL" in ot["transport"] and cfgj["rccl_only_iters_per_sec"] is None, ot
+    assert len(j["roofline"]["per_rank_kernel_ms"]) == 2 and j["cold_iters_per_sec"] > 0
     from pymf_amd import _lib
+    cmd = cmd + ["--fill", "device", "--no-cpu-baseline"]
     if _lib.device_count() < 2:
         q = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
         assert q.returncode != 0 and q.stdout.decode().strip() == "", (q.returncode, q.stdout.decode())
