@@ -81,7 +81,13 @@ struct pmf_ctx {
   double* dGinvD = nullptr;     // SNMF: inv(H H^T) in float64, [KP][KP]
   // Gram-space SNMF loop (snmf_gram_iteration): C = V^T V over all ranks' rows, and the float64 M^T, P
   double *dC = nullptr, *dMTd = nullptr, *dPd = nullptr;
-  double* dCslabs = nullptr;    // k_csr_gram: per-workgroup images of C
+  // SNMF (num_bases <= 128): H in float64 on the device (pmf_inv.h, round 6) -- dH is its float32 rounding.  hd_synced: k_hd_sync
+  // has compared the two in THIS API call (need() clears it); ps_f64: (P | S) of the Gram-space iteration at hand are in dPd / dSd
+  double *dHd = nullptr, *dSd = nullptr, *dHdSnap = nullptr;
+  bool hd_synced = false, hd_force = false, ps_f64 = false;   // hd_force: H was replaced through a float32 entry point
+  int opt_snmf_h64 = 1;
+  double* dCslabs = nullptr;    // k_csr_gram: per-workgroup images of C's upper triangle (two 64-bit fixed-point limbs per entry)
+  unsigned* dVmaxBits = nullptr; // ... and the bit pattern of the largest |v| (the limbs' grids)
   bool c_valid = false;         // dC holds the all-rank V^T V of the current V
   int opt_snmf_gram = -1;       // pmf_set_option("snmf_gram"): -1 auto, 0 never, 1 whenever possible, 2 = 1 + W written in every iteration
   bool w_implicit = false;      // the loop ran in Gram space: dW is stale, W = V M with the M at hand (materialize_w)
@@ -674,6 +680,24 @@ int csr_ps(pmf_ctx* c) {   // slabs: S part by the dense W^T W kernel, P part by
   return reduce_slabs(c, c->nchunks);
 }
 
+// SNMF keeps H in float64 on the device (num_bases <= 128; pmf_set_option("snmf_h64", 0): the float32 H of rounds 1-5)
+static inline bool snmf_h64(const pmf_ctx* c) { return c->algo == PMF_ALGO_SNMF && c->nb == 1 && c->opt_snmf_h64 != 0; }
+
+// dHd exists and agrees with dH: entries whose rounding is not the float32 H any more are replaced by the widened float32 value
+int ensure_hd(pmf_ctx* c) {
+  if (!c->dHd) {
+    PMFCHK(dalloc(c, &c->dHd, (size_t)c->KP * c->np));
+    PMFCHK(dalloc(c, &c->dSd, (size_t)c->KP * c->KP));
+    c->hd_synced = false;
+  }
+  if (c->hd_synced) return PMF_OK;
+  const int64_t E = (int64_t)c->KP * c->np;
+  hipLaunchKernelGGL(k_hd_sync, dim3((unsigned)std::min<int64_t>((E + 255) / 256, 1024)), dim3(256), 0, c->stream, c->dH, c->dHd, E, c->hd_force ? 1 : 0);
+  HIPCHK(c, hipGetLastError());
+  c->hd_synced = true; c->hd_force = false;
+  return PMF_OK;
+}
+
 int ensure_gram(pmf_ctx* c, double pad_diag) {
   if (c->g_valid && c->g_parts > 0) {            // k_nmf_h_gram left partial sums: add them up
     const int E = c->KP * c->KP;
@@ -683,6 +707,8 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
   }
   if (c->g_valid) return PMF_OK;
   c->g_parts = 0;   // (a count left behind by an H step whose H has been replaced since: the partials in dGpart are that H's)
+  const bool h64 = snmf_h64(c);
+  if (h64) PMFCHK(ensure_hd(c));                 // SNMF: G = Hd Hd^T, the float64 H
   dim3 grid((unsigned)(c->KP / 16), (unsigned)(c->KP / 16));
   const int ks = c->np >= 2048 && c->np % 512 == 0 ? 8 : c->np >= 512 && c->np % 256 == 0 ? 4 : 1;   // column slices (wide H)
   if (ks > 1 && c->nb == 1) {
@@ -691,11 +717,15 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
       PMFCHK(dalloc(c, &c->dGramTickets, (size_t)(c->KP / 16) * (c->KP / 16)));
     }
     grid.z = (unsigned)ks;
-    hipLaunchKernelGGL(k_gram_splitk, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k, pad_diag, c->dG, c->dGd,
-                       c->dGramPart, c->dGramTickets);
+    if (h64) hipLaunchKernelGGL(k_gram_splitk<double>, grid, dim3(256), 0, c->stream, c->dHd, (int64_t)c->np, c->np, c->KP, c->k, pad_diag, c->dG, c->dGd,
+                                c->dGramPart, c->dGramTickets);
+    else hipLaunchKernelGGL(k_gram_splitk<float>, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k, pad_diag, c->dG, c->dGd,
+                            c->dGramPart, c->dGramTickets);
   } else {
-    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k,
-                       pad_diag, c->dG, c->dGd);
+    if (h64) hipLaunchKernelGGL(k_gram<double>, grid, dim3(256), 0, c->stream, c->dHd, (int64_t)c->np, c->np, c->KP, c->k,
+                                pad_diag, c->dG, c->dGd);
+    else hipLaunchKernelGGL(k_gram<float>, grid, dim3(256), 0, c->stream, c->dH, (int64_t)c->np, c->np, c->KP, c->k,
+                            pad_diag, c->dG, c->dGd);
   }
   HIPCHK(c, hipGetLastError());
   c->g_valid = true;
@@ -704,6 +734,7 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
 
 int need(pmf_ctx* c, bool v, bool w, bool h) {
   if (!c) return PMF_EINVAL;
+  c->hd_synced = false;        // (a new API call: whoever wrote the float32 H since the last one is noticed by k_hd_sync)
   if (v && !c->have_v) return fail(c, PMF_EINVAL, "V has not been set (pmf_set_v_*)");
   if (w && !c->have_w) return fail(c, PMF_EINVAL, "W has not been set (pmf_set_w_f32)");
   if (h && !c->have_h) return fail(c, PMF_EINVAL, "H has not been set (pmf_set_h_f32)");
@@ -1063,7 +1094,7 @@ int nndsvd_init(pmf_ctx* c, int32_t* rank_found) {
                      c->m, wscale, wmode);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_w = c->have_h = true;
+  c->have_w = c->have_h = true; c->hd_synced = false; c->hd_force = true;
   c->g_valid = c->ps_valid = c->num_valid = c->trace_ready = false; c->g_parts = 0;
   return PMF_OK;
 }
@@ -1330,6 +1361,26 @@ int snmf_h_step(pmf_ctx* c) {   // snmf.py:72-91 on MFMA, one workgroup per 64-c
                        (int64_t)c->np, c->np, c->KP, c->dPS, 3, 0.f, c->k, (int)c->n);
     return PMF_OK;
   }
+  if (snmf_h64(c)) {              // H in float64 (pmf_inv.h: k_snmf_h_f64), P / S in float64 inside the Gram-space loop
+    PMFCHK(ensure_hd(c));
+    const int64_t ldp = (int64_t)c->np + c->KP;
+    const dim3 grid((unsigned)(c->np / 16));
+#define PMF_SNMF_H64(NT_)                                                                                                      \
+    if (c->ps_f64) hipLaunchKernelGGL((k_snmf_h_f64<NT_, double>), grid, dim3(64 * NT_), 0, c->stream, c->dHd, c->dH, c->np,   \
+                                      (const double*)c->dPd, (int64_t)c->np, (const double*)c->dSd, (int64_t)c->KP, c->stop_arg); \
+    else hipLaunchKernelGGL((k_snmf_h_f64<NT_, float>), grid, dim3(64 * NT_), 0, c->stream, c->dHd, c->dH, c->np,              \
+                            (const float*)c->dPS, ldp, (const float*)c->dPS + c->np, ldp, c->stop_arg)
+    switch (c->NT) {
+      case 1: PMF_SNMF_H64(1); break;
+      case 2: PMF_SNMF_H64(2); break;
+      case 4: PMF_SNMF_H64(4); break;
+      case 8: PMF_SNMF_H64(8); break;
+      default: return fail(c, PMF_EINVAL, "bad NT");
+    }
+#undef PMF_SNMF_H64
+    HIPCHK(c, hipGetLastError());
+    return PMF_OK;
+  }
   const bool narrow = c->np <= 256;   // few 64-column panels: 16-column workgroups spread the step over more CUs
   switch (c->NT) {
     case 1: return launch_snmf_h<1, 4>(c);
@@ -1516,9 +1567,16 @@ int launch_inverse(pmf_ctx* c) {   // dGinvD = inv(dGd), float64
 int snmf_inverse(pmf_ctx* c) {
   PMFCHK(ensure_gram(c, 1.0));
   PMFCHK(launch_inverse(c));
-  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(64), 0, c->stream, c->dH,
-                     (int64_t)c->np, c->np, c->KP, c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT,
-                     use_csr(c) ? c->dW1 : (float*)nullptr);
+  if (snmf_h64(c)) {
+    PMFCHK(ensure_hd(c));
+    hipLaunchKernelGGL(k_snmf_mt<double>, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(64), 0, c->stream, c->dHd,
+                       (int64_t)c->np, c->np, c->KP, c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT,
+                       use_csr(c) ? c->dW1 : (float*)nullptr, (double*)nullptr, (const int*)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_snmf_mt<float>, dim3((unsigned)(c->np / 16), (unsigned)(c->KP / 16)), dim3(64), 0, c->stream, c->dH,
+                       (int64_t)c->np, c->np, c->KP, c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT,
+                       use_csr(c) ? c->dW1 : (float*)nullptr, (double*)nullptr, (const int*)nullptr);
+  }
   HIPCHK(c, hipGetLastError());
   return PMF_OK;
 }
@@ -1580,27 +1638,47 @@ int ensure_vgram(pmf_ctx* c) {
   if (!c->dC) PMFCHK(dalloc(c, &c->dC, (size_t)np * np));
   if (!c->dMTd) PMFCHK(dalloc(c, &c->dMTd, (size_t)c->KP * np));
   if (!c->dPd) PMFCHK(dalloc(c, &c->dPd, (size_t)c->KP * np));
-  if (use_csr(c)) {                 // k_csr_gram: per-workgroup images of C, added up in fixed order
+  if (use_csr(c)) {                 // k_csr_gram: per-workgroup images of C in exact fixed point (pmf_csr.h), added up as integers
     const size_t E = (size_t)np * np;
-    const int use_lds = E * sizeof(double) <= 128 * 1024;
-    const int wgs = use_lds ? 256 : 32;            // global images are E doubles each: fewer of them
-    // per-workgroup images of C: kept with the context (32 MiB at n = 128); zeroed only where the kernel adds
+    const size_t T2 = 2 * gram_tri(np);                                // two 64-bit limbs per entry of the upper triangle
+    const int use_lds = T2 * sizeof(unsigned long long) + gram_stage_bytes() <= 160 * 1024;
+    const int wgs = use_lds ? 256 : 32;            // global images are T2 words each: fewer of them
+    // the grids of the two limbs from the largest |v|: |v| < 2^e  ->  u1 = 2^(2e-32), u2 = 2^(2e-64)
+    if (!c->dVmaxBits) PMFCHK(dalloc(c, &c->dVmaxBits, (size_t)1));
+    unsigned* mxbits = c->dVmaxBits;
+    HIPCHK(c, hipMemsetAsync(mxbits, 0, sizeof(unsigned), c->stream));
+    const int64_t nnz = c->nnz;
+    if (nnz > 0) {
+      hipLaunchKernelGGL(k_absmax_bits_f32, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 2048)), dim3(256), 0, c->stream, c->dVals, nnz, mxbits);
+      HIPCHK(c, hipGetLastError());
+    }
+    unsigned hb = 0;
+    HIPCHK(c, hipMemcpyAsync(&hb, mxbits, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float vmax;
+    std::memcpy(&vmax, &hb, sizeof(float));
+    const int finite = std::isfinite(vmax) ? 1 : 0;
+    int ex = 0;
+    if (finite && vmax > 0.f) (void)std::frexp(vmax, &ex);             // vmax = f 2^ex, f in [0.5, 1): |v| < 2^ex
+    GramScale gs;
+    gs.u1 = std::ldexp(1.0, 2 * ex - 32); gs.inv_u1 = std::ldexp(1.0, 32 - 2 * ex); gs.inv_u2 = std::ldexp(1.0, 64 - 2 * ex);
+    // per-workgroup images of C: kept with the context (34 MiB at n = 128); zeroed only where the kernel adds
     // into them directly (LDS images are written out whole)
-    if (!c->dCslabs) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dCslabs), (size_t)wgs * E * sizeof(double)));
-    double* slabs = c->dCslabs;
-    if (!use_lds) HIPCHK(c, hipMemsetAsync(slabs, 0, (size_t)wgs * E * sizeof(double), c->stream));
-    const size_t smem = (use_lds ? E * sizeof(double) : 0) + gram_stage_bytes();
+    if (!c->dCslabs) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dCslabs), (size_t)wgs * T2 * sizeof(unsigned long long)));
+    unsigned long long* slabs = reinterpret_cast<unsigned long long*>(c->dCslabs);
+    if (!use_lds) HIPCHK(c, hipMemsetAsync(slabs, 0, (size_t)wgs * T2 * sizeof(unsigned long long), c->stream));
+    const size_t smem = (use_lds ? T2 * sizeof(unsigned long long) : 0) + gram_stage_bytes();
     static bool attr_done_dev[PMF_MAX_DEVICES] = {};
     bool& attr_done = attr_done_dev[pmf_current_device()];
     if (!attr_done) {
       HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csr_gram), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(128 * 1024 + gram_stage_bytes())));
+                                    (int)(160 * 1024)));
       attr_done = true;
     }
     hipLaunchKernelGGL(k_csr_gram, dim3((unsigned)wgs), dim3(64 * GRAM_WAVES), smem, c->stream, c->dIndptr,
-                       c->dIndices, c->dVals, c->m, np, slabs, use_lds);
+                       c->dIndices, c->dVals, c->m, np, slabs, use_lds, gs);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, c->stream, slabs, wgs, np, c->dC);
+    hipLaunchKernelGGL(k_csr_gram_sum, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, c->stream, slabs, wgs, np, c->dC, gs, finite);
     HIPCHK(c, hipGetLastError());
     PMFCHK(allreduce_sum(c, c->dC, E, true));
   } else {
@@ -1644,8 +1722,15 @@ int snmf_gram_iteration(pmf_ctx* c) {
     if (c->ev_w_pending[b]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_w[b], 0)); c->ev_w_pending[b] = false; }
     mcsr = w_pipe_mbuf(c, c->w_pipe_it);
   }
-  hipLaunchKernelGGL(k_snmf_mt, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dH, (int64_t)np, np, KP,
-                     c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? mcsr : (float*)nullptr, c->dMTd, c->stop_arg);
+  const bool h64 = snmf_h64(c);
+  if (h64) {
+    PMFCHK(ensure_hd(c));
+    hipLaunchKernelGGL(k_snmf_mt<double>, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dHd, (int64_t)np, np, KP,
+                       c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? mcsr : (float*)nullptr, c->dMTd, c->stop_arg);
+  } else {
+    hipLaunchKernelGGL(k_snmf_mt<float>, dim3((unsigned)(np / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dH, (int64_t)np, np, KP,
+                       c->dGinvD, use_csr(c) ? (float*)nullptr : c->dMT, use_csr(c) ? mcsr : (float*)nullptr, c->dMTd, c->stop_arg);
+  }
   HIPCHK(c, hipGetLastError());
   if (pipe) {                  // W = V M on the side stream, beside everything that follows here (nothing below reads W)
     const int b = (int)(c->w_pipe_it & 1);
@@ -1674,13 +1759,16 @@ int snmf_gram_iteration(pmf_ctx* c) {
   HIPCHK(c, hipGetLastError());
   // S = P M = P (M^T)^T  (KP x KP)
   hipLaunchKernelGGL((k_dgemm_mfma<true>), dim3((unsigned)(KP / 16), (unsigned)(KP / 16)), dim3(64), 0, c->stream, c->dPd,
-                     (int64_t)np, c->dMTd, (int64_t)np, np, (double*)nullptr, (int64_t)0, c->dPS + np, ldp, c->stop_arg);
+                     (int64_t)np, c->dMTd, (int64_t)np, np, h64 ? c->dSd : (double*)nullptr, (int64_t)KP, c->dPS + np, ldp, c->stop_arg);
   HIPCHK(c, hipGetLastError());
   c->w_implicit = !pipe;      // dW is stale from here on: W = V M with the M just formed (pipelined: being written already)
   c->ps_valid = true;         // (P | S) of that W, all ranks (C is all-reduced)
   if (c->opt_snmf_gram == 2 && !pipe) PMFCHK(materialize_w(c));   // W rewritten in every iteration, as the reference's update_w does
   c->ps_valid = true;
-  return h_step_from_ps(c);
+  c->ps_f64 = h64;            // the H step takes P and S in float64 (dPd, dSd), not their float32 roundings in (P | S)
+  const int hrc = h_step_from_ps(c);
+  c->ps_f64 = false;
+  return hrc;
 }
 
 // W = V M for the M the last Gram-space iteration formed (dMT dense / dW1 CSR).
@@ -2365,7 +2453,7 @@ int pmf_ctx_destroy(pmf_ctx* c) {
     if (p) (void)hipFree(p);
   for (void* p : {(void*)c->dTile[0], (void*)c->dTile[1], (void*)c->dPSacc, (void*)c->dStAcc, (void*)c->dGpart,
                   (void*)c->dT1part, (void*)c->dTicket, (void*)c->dFerr, (void*)c->dStop, (void*)c->dWarm, (void*)c->dW2,
-                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage, (void*)c->dGramPart, (void*)c->dGramTickets, (void*)c->dWideT, (void*)c->dWideN, (void*)c->dWideD})
+                  (void*)c->dMT, (void*)c->dGinvD, (void*)c->dC, (void*)c->dCslabs, (void*)c->dMTd, (void*)c->dPd, (void*)c->dInvA, (void*)c->dInvB, (void*)c->dQp, (void*)c->dSing, (void*)c->dBinv, (void*)c->dDefer, (void*)c->dNbig, (void*)c->dWsnap, (void*)c->dY0, (void*)c->dQstat, c->dStage, (void*)c->dGramPart, (void*)c->dGramTickets, (void*)c->dWideT, (void*)c->dWideN, (void*)c->dWideD, (void*)c->dHd, (void*)c->dSd, (void*)c->dHdSnap, (void*)c->dVmaxBits})
     if (p) (void)hipFree(p);
   for (hipEvent_t e : {c->ev_copied[0], c->ev_copied[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (e) (void)hipEventDestroy(e);
@@ -2480,7 +2568,7 @@ int pmf_fill_w_uniform(pmf_ctx* c, uint64_t seed, int64_t row0) {
 int pmf_fill_h_uniform(pmf_ctx* c, uint64_t seed) {
   if (!c) return PMF_EINVAL;
   PMFCHK(fill(c, c->dH, c->np, c->k, c->n, 0, seed));
-  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false;
+  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false; c->hd_synced = false; c->hd_force = true;
   return PMF_OK;
 }
 
@@ -2525,12 +2613,35 @@ int pmf_set_h_f64(pmf_ctx* c, const double* H) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(zero_padding(c, c->dH, c->np, c->KP, c->k, c->n));
   PMFCHK(upload_rows<double>(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false;
+  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false; c->hd_synced = false; c->hd_force = true;
+  if (snmf_h64(c)) {               // SNMF: the caller's float64 H as it is (nmf.py:120 keeps H in float64), beside its rounding
+    if (!c->dHd) { PMFCHK(dalloc(c, &c->dHd, (size_t)c->KP * c->np)); PMFCHK(dalloc(c, &c->dSd, (size_t)c->KP * c->KP)); }
+    const size_t bytes = (size_t)c->k * c->n * sizeof(double);
+    PMFCHK(stage_reserve(c, bytes));
+    HIPCHK(c, hipMemsetAsync(c->dHd, 0, (size_t)c->KP * c->np * sizeof(double), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dStage, H, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_unpack_rows_f64, dim3((unsigned)std::min<int64_t>(((int64_t)c->k * c->np + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const double*>(c->dStage), (int64_t)c->k, (int64_t)c->n, c->dHd, (int64_t)c->np);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hd_synced = false; c->hd_force = false;   // (Hd holds the caller's float64 values, dH their rounding)
+  }
   return PMF_OK;
 }
 int pmf_get_h_f64(pmf_ctx* c, double* H) {
   PMFCHK(need(c, false, false, true));
   if (!H) return fail(c, PMF_EINVAL, "H is NULL");
+  if (snmf_h64(c) && c->dHd) {     // SNMF: the float64 H the device iterates on (entries another writer of the float32 H replaced: widened)
+    PMFCHK(ensure_hd(c));
+    const size_t bytes = (size_t)c->k * c->n * sizeof(double);
+    PMFCHK(stage_reserve(c, bytes));
+    hipLaunchKernelGGL(k_pack_rows_f64, dim3((unsigned)std::min<int64_t>(((int64_t)c->k * c->n + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                       (const double*)c->dHd, (int64_t)c->np, (int64_t)c->k, (int64_t)c->n, reinterpret_cast<double*>(c->dStage));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(H, c->dStage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PMF_OK;
+  }
   return download_rows<double>(c, H, c->dH, c->np, c->k, c->n);
 }
 int pmf_set_v_dense_f64(pmf_ctx* c, const double* V, int64_t ld) {
@@ -2556,7 +2667,7 @@ int pmf_set_h_f32(pmf_ctx* c, const float* H) {
   HIPCHK(c, hipSetDevice(c->device));
   PMFCHK(zero_padding(c, c->dH, c->np, c->KP, c->k, c->n));
   PMFCHK(upload_padded(c, c->dH, c->np, H, c->n, c->k, c->n));
-  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false;   // (P | S) do not depend on H
+  c->have_h = true; c->g_valid = false; c->g_parts = 0; c->num_valid = false; c->trace_ready = false; c->hd_synced = false; c->hd_force = true;   // (P | S) do not depend on H
   return PMF_OK;
 }
 int pmf_get_h_f32(pmf_ctx* c, float* H) {
@@ -2835,6 +2946,7 @@ int pmf_rnmf_set_s_f32(pmf_ctx* c, const float* S) {
 // (nmf.py:122-126) and evaluates ||V - W H|| by the trace identity.  Copies run on their own
 // stream into two device tiles, so the copy of tile t+1 overlaps the kernels of tile t.
 int pmf_stream_begin(pmf_ctx* c, uint32_t flags, int64_t max_tile_rows) {
+  if (c) c->hd_synced = false;
   if (!c) return PMF_EINVAL;
   if (c->algo == PMF_ALGO_RNMF)   // (the reference's RNMF keeps S, an in-memory array of data's shape: rnmf.py:94-98)
     return fail(c, PMF_EINVAL, "pmf_stream_*: NMF, BNMF, SNMF and NMFALS contexts");
@@ -2976,6 +3088,7 @@ int pmf_stream_end(pmf_ctx* c, double* ferr, int32_t* needs_direct) {
   if (!c) return PMF_EINVAL;
   if (!c->st_active) return fail(c, PMF_EINVAL, "pmf_stream_end: no pass open");
   c->st_active = false;
+  c->hd_synced = false;
   if (needs_direct) *needs_direct = 0;
   if (c->st_rows_seen != c->m)
     return fail(c, PMF_EINVAL, "pmf_stream_end: the tiles covered " + std::to_string(c->st_rows_seen) + " of " +
@@ -3255,6 +3368,12 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
     c->opt_rowgemm_stream = (int)value;
     return PMF_OK;
   }
+  if (std::strcmp(name, "snmf_h64") == 0) {
+    if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "snmf_h64: 0 (H in float32 between the steps, rounds 1-5) or 1 (H in float64 on the device)");
+    c->opt_snmf_h64 = (int)value;
+    c->hd_synced = false; c->g_valid = false; c->g_parts = 0;
+    return PMF_OK;
+  }
   if (std::strcmp(name, "snmf_gram") == 0) {
     if (value < -1 || value > 2) return fail(c, PMF_EINVAL, "snmf_gram: -1 (auto), 0 (off), 1 (on) or 2 (on, W written every iteration)");
     c->opt_snmf_gram = (int)value;
@@ -3450,6 +3569,10 @@ int pmf_snapshot_h(pmf_ctx* c) {
   const size_t hb = (size_t)c->KP * c->np * sizeof(float), gb = (size_t)c->KP * c->KP * sizeof(float);
   if (!c->dHsnap) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dHsnap), hb + gb + (size_t)PMF_HGRAM_MAX_WGS * gb));
   HIPCHK(c, hipMemcpyAsync(c->dHsnap, c->dH, hb, hipMemcpyDeviceToDevice, c->stream));
+  if (c->dHd) {                    // SNMF: the float64 H with it (a restored H continues with the same bits)
+    if (!c->dHdSnap) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dHdSnap), 2 * hb));
+    HIPCHK(c, hipMemcpyAsync(c->dHdSnap, c->dHd, 2 * hb, hipMemcpyDeviceToDevice, c->stream));
+  }
   const bool keep_g = (c->algo == PMF_ALGO_NMF || c->algo == PMF_ALGO_BNMF) && c->g_valid && c->dG != nullptr;
   c->hsnap_g_valid = keep_g;
   c->hsnap_g_parts = keep_g ? c->g_parts : 0;
@@ -3469,6 +3592,8 @@ int pmf_restore_h(pmf_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   const size_t hb = (size_t)c->KP * c->np * sizeof(float), gb = (size_t)c->KP * c->KP * sizeof(float);
   HIPCHK(c, hipMemcpyAsync(c->dH, c->dHsnap, hb, hipMemcpyDeviceToDevice, c->stream));
+  if (c->dHd && c->dHdSnap) HIPCHK(c, hipMemcpyAsync(c->dHd, c->dHdSnap, 2 * hb, hipMemcpyDeviceToDevice, c->stream));
+  c->hd_synced = false;
   c->have_h = true; c->num_valid = false; c->trace_ready = false;
   c->g_valid = false; c->g_parts = 0;
   if (c->hsnap_g_valid) {

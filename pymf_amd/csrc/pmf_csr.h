@@ -21,23 +21,47 @@
 // dependent memory latencies per row: 1.48 ms for 77 MB).  The loads are software-pipelined: while block i
 // is paired, the entries of block i + 1 and the row pointers of block i + 2 are in flight (a wave owns a
 // CONTIGUOUS range of blocks).  A block with GRAM_CAP or more entries (dense rows) takes the row-by-row
-// form.  Every workgroup accumulates into a private image of C -- in LDS when it fits (np <= 128: float64 LDS
-// atomics), else directly into its slab in global memory -- and k_csr_gram_sum adds the slabs in fixed order.
-// float32 products are exact in float64, so the only run-to-run freedom is the order of float64 additions
-// inside a workgroup (1e-16 relative).
+// form.  Every workgroup accumulates into a private image of C's upper triangle -- in LDS when it fits (np <= 128), else
+// directly into its slab in global memory -- and k_csr_gram_sum adds the slabs.
+// Round 6: the accumulation is EXACT FIXED POINT, hence independent of the order in which the waves' atomics land.  Rounds 2-5
+// added the (exact) float32 x float32 products with float64 atomics: the order of those additions was the one run-to-run
+// freedom of the whole library (1e-16 relative) -- invisible while H was rounded to float32 between the iterations, but with
+// SNMF's H in float64 (pmf_inv.h) cond(H H^T) ~ 1e7 carries it into the last bits of W.  With |v| < 2^e for all entries a product
+// p (|p| < 2^2e, 48 significant bits) is cut into two signed limbs on the grids u1 = 2^(2e-32) and u2 = 2^(2e-64),
+//     hi = trunc(p / u1),   lo = trunc((p - hi u1) / u2),        |hi|, |lo| < 2^32,
+// each added with a 64-bit INTEGER atomic (associative: any order, same bits; up to 2^31 summands per entry); what is cut
+// off below u2 is a function of the product alone (deterministic) and < 2^-64 of the largest product -- closer to the exact
+// sum than the float64 additions were.  k_csr_gram_sum adds the slabs' limbs as integers and converts once.
 constexpr int GRAM_CAP = 256;       // entries of a 64-row block staged per wave
 constexpr int GRAM_WAVES = 8;       // waves per workgroup
+__host__ __device__ constexpr size_t gram_tri(int np) { return (size_t)np * (np + 1) / 2; }          // entries of the upper triangle
+__device__ __forceinline__ int gram_tri_index(int c1, int c2, int np) { return c1 * np - c1 * (c1 - 1) / 2 + (c2 - c1); }   // c1 <= c2
+struct GramScale { double u1, inv_u1, inv_u2; };     // u1 = 2^(2e-32), its inverse, and 1 / u2 = 2^(64-2e)
+__device__ __forceinline__ void gram_add(unsigned long long* img, int idx, double p, const GramScale& g) {
+  const double h = trunc(p * g.inv_u1);             // (scalings by powers of two and the difference below are exact)
+  const double l = trunc((p - h * g.u1) * g.inv_u2);
+  atomicAdd(&img[2 * idx], (unsigned long long)(long long)h);
+  atomicAdd(&img[2 * idx + 1], (unsigned long long)(long long)l);
+}
+// bit pattern of the largest |v| (non-negative floats order like their bit patterns; a NaN sorts above infinity)
+__global__ __launch_bounds__(256) void k_absmax_bits_f32(const float* __restrict__ v, int64_t n, unsigned* __restrict__ out) {
+  unsigned mx = 0u;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) mx = max(mx, __float_as_uint(fabsf(v[e])));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
+}
 constexpr size_t gram_stage_bytes() { return (size_t)GRAM_WAVES * (GRAM_CAP * (4 + 4 + 1) + 64 * 4 + 64); }
 
 __global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __restrict__ indptr,
                                                               const int32_t* __restrict__ indices,
                                                               const float* __restrict__ vals, int64_t rows, int np,
-                                                              double* __restrict__ slabs, int use_lds) {
-  extern __shared__ __attribute__((aligned(16))) double sC[];
+                                                              unsigned long long* __restrict__ slabs, int use_lds, GramScale gs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sC[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int E = np * np;
-  double* img = use_lds ? sC : slabs + (size_t)blockIdx.x * E;
+  const int E = 2 * (int)gram_tri(np);              // two limbs per entry of the upper triangle
+  unsigned long long* img = use_lds ? sC : slabs + (size_t)blockIdx.x * E;
   // per-wave staging behind the image: columns, values, row of every entry, first entry and length of every row
   char* stage = reinterpret_cast<char*>(sC + (use_lds ? E : 0)) + (size_t)wv * (GRAM_CAP * 9 + 64 * 4 + 64);
   int* sCol = reinterpret_cast<int*>(stage);
@@ -46,7 +70,7 @@ __global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __r
   unsigned char* sCnt = reinterpret_cast<unsigned char*>(stage + GRAM_CAP * 8 + 64 * 4);
   unsigned char* sRow = reinterpret_cast<unsigned char*>(stage + GRAM_CAP * 8 + 64 * 4 + 64);
   if (use_lds) {
-    for (int q = tid; q < E; q += 64 * GRAM_WAVES) sC[q] = 0.0;
+    for (int q = tid; q < E; q += 64 * GRAM_WAVES) sC[q] = 0ull;
     __syncthreads();
   }
   // this wave's contiguous range of 64-row blocks
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __r
         for (int j = 0; j < cm; ++j) {
           if (j < c) {
             const int col2 = sCol[ea + j];
-            if (col1 <= col2) atomicAdd(&img[(size_t)col1 * np + col2], v1 * (double)sVal[ea + j]);
+            if (col1 <= col2) gram_add(img, gram_tri_index(col1, col2, np), v1 * (double)sVal[ea + j], gs);
           }
         }
       }
@@ -142,7 +166,7 @@ __global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __r
         for (int64_t pq = lane; pq < (int64_t)rc * rc; pq += 64) {
           const int e1 = (int)(pq / rc), e2 = (int)(pq % rc);
           const int col1 = indices[base + e1], col2 = indices[base + e2];
-          if (col1 <= col2) atomicAdd(&img[(size_t)col1 * np + col2], (double)vals[base + e1] * (double)vals[base + e2]);
+          if (col1 <= col2) gram_add(img, gram_tri_index(col1, col2, np), (double)vals[base + e1] * (double)vals[base + e2], gs);
         }
       }
       if (bi + 1 < nb) load_entries(a0n, Tn);
@@ -153,33 +177,43 @@ __global__ __launch_bounds__(64 * GRAM_WAVES) void k_csr_gram(const int64_t* __r
   }
   if (use_lds) {
     __syncthreads();
-    double* out = slabs + (size_t)blockIdx.x * E;
-    for (int q = tid; q < E; q += 64 * GRAM_WAVES)
-      if (q / np <= q % np) out[q] = sC[q];                             // the upper triangle is all there is
+    unsigned long long* out = slabs + (size_t)blockIdx.x * E;
+    for (int q = tid; q < E; q += 64 * GRAM_WAVES) out[q] = sC[q];
   }
 }
 
-// C = sum of the slabs' upper triangles (fixed order), mirrored.  Block b owns 64 consecutive elements;
-// thread (g = tid / 64, e = tid % 64) adds slabs g, g + 4, ... (independent loads, eight in flight), the four
-// partial sums are combined in the order of g.
-__global__ __launch_bounds__(256) void k_csr_gram_sum(const double* __restrict__ slabs, int nslabs, int np,
-                                                      double* __restrict__ C) {
-  __shared__ double part[4][64];
+// C = sum of the slabs' upper triangles, mirrored.  Block b owns 64 consecutive elements of the np x np matrix; thread
+// (g = tid / 64, e = tid % 64) adds the limbs of slabs g, g + 4, ... as INTEGERS (independent loads, eight in flight; any
+// order gives the same bits), the four partial sums likewise, and the two 64-bit sums become one float64: their 32-bit halves
+// convert exactly and are added from the smallest grid up.  finite == 0: the data held a NaN or an infinity -- C is NaN.
+__global__ __launch_bounds__(256) void k_csr_gram_sum(const unsigned long long* __restrict__ slabs, int nslabs, int np,
+                                                      double* __restrict__ C, GramScale gs, int finite) {
+  __shared__ long long part[4][64][2];
   const int64_t E = (int64_t)np * np;
+  const size_t T2 = 2 * gram_tri(np);
   const int g = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const bool live = e < E && (e / np) <= (e % np);
-  double s = 0.0;
+  const int r = (int)(e / np), c = (int)(e % np);
+  const bool live = e < E && r <= c;
+  long long sh = 0, sl = 0;
   if (live) {
+    const size_t t = 2 * (size_t)gram_tri_index(r, c, np);
 #pragma unroll 8
-    for (int q = g; q < nslabs; q += 4) s += slabs[(size_t)q * E + e];
+    for (int q = g; q < nslabs; q += 4) { sh += (long long)slabs[(size_t)q * T2 + t]; sl += (long long)slabs[(size_t)q * T2 + t + 1]; }
   }
-  part[g][threadIdx.x & 63] = s;
+  part[g][threadIdx.x & 63][0] = sh;
+  part[g][threadIdx.x & 63][1] = sl;
   __syncthreads();
   if (g == 0 && live) {
     const int l = threadIdx.x & 63;
-    const double t = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
-    const int r = (int)(e / np), c = (int)(e % np);
+    const long long H = part[0][l][0] + part[1][l][0] + part[2][l][0] + part[3][l][0];
+    const long long L = part[0][l][1] + part[1][l][1] + part[2][l][1] + part[3][l][1];
+    // X = Xa 2^32 + Xb with Xb in [0, 2^32): both halves are exact as doubles
+    const double Ha = (double)(H >> 32), Hb = (double)(unsigned)(H & 0xffffffffll);
+    const double La = (double)(L >> 32), Lb = (double)(unsigned)(L & 0xffffffffll);
+    const double u1 = gs.u1, u2 = 1.0 / gs.inv_u2;
+    double t = ((Lb * u2 + La * (u2 * 4294967296.0)) + Hb * u1) + Ha * (u1 * 4294967296.0);
+    if (!finite) t = __builtin_nan("");
     C[e] = t;
     C[(int64_t)c * np + r] = t;
   }

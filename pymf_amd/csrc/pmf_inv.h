@@ -396,14 +396,15 @@ __global__ __launch_bounds__(64) void k_dgemm_mfma(const double* __restrict__ A,
 // operands that are exact to float32 rounding and nothing is amplified; it also drops the m k^2
 // product from the pass.  Writes MT [KP][np] float32 (dense kernels: the "H" operand), M [np][KP]
 // float32 (CSR kernels gather rows of it) and MTd float64 (Gram-space loop); any may be null.
-// grid = (np / 16, KP / 16), 64 threads.
-__global__ __launch_bounds__(64) void k_snmf_mt(const float* __restrict__ H, int64_t ldh, int np, int KP,
+// grid = (np / 16, KP / 16), 64 threads.  TH: float (the float32 H) or double (SNMF's float64 H of round 6, k_snmf_h_f64 below).
+template <typename TH>
+__global__ __launch_bounds__(64) void k_snmf_mt(const TH* __restrict__ H, int64_t ldh, int np, int KP,
                                                 const double* __restrict__ Ginv64, float* __restrict__ MT,
                                                 float* __restrict__ M, double* __restrict__ MTd = nullptr,
                                                 const int* __restrict__ stop = nullptr) {
   if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep M
   const int lane = threadIdx.x, col0 = blockIdx.x * 16, kp0 = blockIdx.y * 16;
-  const f64x4 acc = tile_dgemm<false, float>(Ginv64, KP, H, ldh, KP, kp0, col0, lane);
+  const f64x4 acc = tile_dgemm<false, TH>(Ginv64, KP, H, ldh, KP, kp0, col0, lane);
   const int col = col0 + (lane & 15), g = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -418,8 +419,9 @@ __global__ __launch_bounds__(64) void k_snmf_mt(const float* __restrict__ H, int
 // grid = (KP / 16, KP / 16), 256 threads: wave w of the four takes the columns [w np / 4, (w + 1) np / 4)
 // (np is a multiple of 64), the four partial tiles are added in wave order.
 // Gf: float32 copy (MFMA operand), Gd: float64 copy (SNMF inverse, NMFALS Hessian); rows / columns >= k
-// (padding) get `pad_diag` on the diagonal and 0 elsewhere.
-__global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64_t ldh, int np,
+// (padding) get `pad_diag` on the diagonal and 0 elsewhere.  TH: float or double (as k_snmf_mt).
+template <typename TH>
+__global__ __launch_bounds__(256) void k_gram(const TH* __restrict__ H, int64_t ldh, int np,
                                               int KP, int k, double pad_diag,
                                               float* __restrict__ Gf, double* __restrict__ Gd) {
   __shared__ double part[3][4][64];
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ra = blockIdx.x * 16, rb = blockIdx.y * 16;
   const int kq = np / 4;
-  f64x4 acc = tile_dgemm<true, float, float>(H + wv * kq, ldh, H + wv * kq, ldh, kq, ra, rb, lane);
+  f64x4 acc = tile_dgemm<true, TH, TH>(H + wv * kq, ldh, H + wv * kq, ldh, kq, ra, rb, lane);
   if (wv > 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wv - 1][r][lane] = acc[r];
@@ -450,7 +452,8 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ H, int64
 // 64 x 1024 H was 16 dependent L2 round trips per wave, 16 us of an NMFALS iteration -- each leaves its partial tile in
 // `part` [KS][KP][KP]; the LAST slice of a tile to arrive (ticket per tile, reset for the next launch) adds the KS partials in
 // slice order: deterministic.  part: KS * KP * KP doubles, tickets: (KP / 16)^2 zeroed unsigneds.
-__global__ __launch_bounds__(256) void k_gram_splitk(const float* __restrict__ H, int64_t ldh, int np, int KP, int k, double pad_diag,
+template <typename TH>
+__global__ __launch_bounds__(256) void k_gram_splitk(const TH* __restrict__ H, int64_t ldh, int np, int KP, int k, double pad_diag,
                                                      float* __restrict__ Gf, double* __restrict__ Gd, double* __restrict__ part,
                                                      unsigned* __restrict__ tickets) {
   __shared__ double wpart[3][4][64];
@@ -459,8 +462,8 @@ __global__ __launch_bounds__(256) void k_gram_splitk(const float* __restrict__ H
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ra = blockIdx.x * 16, rb = blockIdx.y * 16, KS = gridDim.z, z = blockIdx.z;
   const int ksl = np / KS, kq = ksl / 4;                       // columns per slice / per wave (multiples of 16)
-  const float* Hs = H + (size_t)z * ksl + wv * kq;
-  f64x4 acc = tile_dgemm<true, float, float>(Hs, ldh, Hs, ldh, kq, ra, rb, lane);
+  const TH* Hs = H + (size_t)z * ksl + wv * kq;
+  f64x4 acc = tile_dgemm<true, TH, TH>(Hs, ldh, Hs, ldh, kq, ra, rb, lane);
   if (wv > 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) wpart[wv - 1][r][lane] = acc[r];
@@ -490,4 +493,96 @@ __global__ __launch_bounds__(256) void k_gram_splitk(const float* __restrict__ H
     if (Gd) Gd[(int64_t)ga * KP + gb] = v;
   }
   if (lane == 0) tickets[tile] = 0u;                            // ready for the next launch (stream order)
+}
+
+// ---- SNMF: H in float64 on the device (round 6) -------------------------------------------------------------------------
+// The reference keeps H in float64 (pymf/nmf.py:120) and its W step multiplies by inv(H H^T) (snmf.py:69-70): with k = n
+// (cfg5: 128 x 128) cond(H H^T) ~ 1e7, and an H that is ROUNDED to float32 between iterations puts 6e-8 * sigma_max / sigma_min
+// ~ 2e-4 into W after 50 iterations (round-5 verdict W2).  H is k x n -- 128 KiB as float64 at cfg5 -- so the device now
+// holds it in float64 (Hd) and every consumer that feeds the inverse reads THAT: k_gram<double>, k_snmf_mt<double>, and the
+// H step below; the float32 H (what the float32 MFMA kernels, the error's trace terms and float32 callers read) is its rounding.
+
+// Hd[e] stays if it rounds to H[e], else it becomes the widened H[e]: whoever wrote the float32 H last (an upload, a restore,
+// NNDSVD, a float32 kernel) is noticed HERE, by value -- no bookkeeping at the writers.  One launch per API call.
+// force != 0: the caller replaced H through a float32 entry point -- the widened values, whatever Hd held.
+__global__ __launch_bounds__(256) void k_hd_sync(const float* __restrict__ H, double* __restrict__ Hd, int64_t count, int force) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
+    const float h = H[e];
+    if (force || !((float)Hd[e] == h)) Hd[e] = (double)h;
+  }
+}
+// host float64 [rows][cols] (contiguous, staged on the device) -> Hd [.][dld], columns >= cols zero (rows beyond: memset)
+__global__ __launch_bounds__(256) void k_unpack_rows_f64(const double* __restrict__ src, int64_t rows, int64_t cols,
+                                                         double* __restrict__ dst, int64_t dld) {
+  const int64_t total = rows * dld;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / dld, c = e - r * dld;
+    dst[e] = c < cols ? src[r * cols + c] : 0.0;
+  }
+}
+__global__ __launch_bounds__(256) void k_pack_rows_f64(const double* __restrict__ src, int64_t sld, int64_t rows, int64_t cols,
+                                                       double* __restrict__ dst) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / cols, c = e - r * cols;
+    dst[e] = src[r * sld + c];
+  }
+}
+
+// SNMF H step (pymf/snmf.py:72-91) in float64 on the float64 MFMA, with XW^T = P = W^T V and WW = S = W^T W:
+//   H1 = pos(P) + neg(S) H,   H2 = neg(P) + pos(S) H + 1e-9,   H *= sqrt(H1 / H2)      (S is symmetric)
+// P, S as float64 (the Gram-space loop forms them in float64: TP = double) or float32 (a pass over V left them in (P | S):
+// TP = float).  One workgroup per 16-column panel, NT waves: wave w owns the 16 x 16 tile of block row w and takes its
+// operands straight from L2 in MFMA operand order, pos(S) / neg(S) split in registers as the A fragments arrive -- two
+// accumulator chains each over the same loads.  The panel is read by all waves before any of them writes (in-place step).
+// Writes Hd and its float32 rounding H.
+template <int NT, typename TP>
+__global__ __launch_bounds__(64 * NT) void k_snmf_h_f64(double* Hd /* read by every wave, written in place: NOT restrict */, float* __restrict__ H, int np,
+                                                        const TP* __restrict__ P, int64_t ldp,
+                                                        const TP* __restrict__ S, int64_t lds,
+                                                        const int* __restrict__ stop) {
+  if (stop != nullptr && *stop != 0) return;
+  constexpr int KP = 16 * NT, KS = KP / 4;                      // k-steps of 4
+  constexpr int RND = KS < 16 ? KS : 16;                        // k-steps whose loads are in flight together
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int c0 = 16 * blockIdx.x, r0 = 16 * wv;
+  // this lane's four outputs: rows r0 + g + 4 r, column c0 + i (C/D layout)
+  double hv[4], xw[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = r0 + g + 4 * r;
+    hv[r] = Hd[row * np + c0 + i];
+    xw[r] = (double)P[row * ldp + c0 + i];
+  }
+  const TP* ap = S + (int64_t)(r0 + i) * lds + g;               // A[r0 + i][4 s + g] = S[r0 + i][4 s + g]
+  const double* bp = Hd + (int64_t)g * np + c0 + i;             // B[4 s + g][c0 + i] = H[4 s + g][c0 + i]
+  f64x4 accp[2], accn[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { accp[e] = f64x4{0.0, 0.0, 0.0, 0.0}; accn[e] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+  for (int s0 = 0; s0 < KS; s0 += RND) {
+    double a[RND], b[RND];
+#pragma unroll
+    for (int u = 0; u < RND; ++u) { a[u] = (double)ap[4 * (s0 + u)]; b[u] = bp[(int64_t)(s0 + u) * 4 * np]; }
+#pragma unroll
+    for (int u = 0; u < RND; ++u) {
+      const double wp = (fabs(a[u]) + a[u]) * 0.5;               // snmf.py:73-74
+      const double wn = (fabs(a[u]) - a[u]) * 0.5;               // snmf.py:76-77
+      accp[u & 1] = mfma_f64(wp, b[u], accp[u & 1]);
+      accn[u & 1] = mfma_f64(wn, b[u], accn[u & 1]);
+    }
+  }
+  const f64x4 a2 = accp[0] + accp[1], a1 = accn[0] + accn[1];
+  __syncthreads();                                              // every wave has read the old panel
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = r0 + g + 4 * r;
+    const double h1 = (fabs(xw[r]) + xw[r]) * 0.5 + a1[r];       // snmf.py:79-86
+    const double h2 = (fabs(xw[r]) - xw[r]) * 0.5 + a2[r] + 1e-9;
+    const double hn = hv[r] * sqrt(h1 / h2);                    // snmf.py:91
+    Hd[row * np + c0 + i] = hn;
+    H[row * np + c0 + i] = (float)hn;
+  }
 }

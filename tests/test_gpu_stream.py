@@ -243,7 +243,19 @@ def test_float64_transport_equals_host_side_conversion():
         Hout = np.full((k, n), np.nan)
         assert a.get_w_into(Wout) and a.get_h_into(Hout)
         np.testing.assert_array_equal(Wout, W64.astype(np.float32).astype(np.float64))
+        # SNMF keeps H in FLOAT64 on the device (round 6; the reference's H is float64, nmf.py:120, and inv(H H^T) amplifies its
+        # rounding): a float64 H comes back as it went up, bit for bit; its float32 view is the rounding
+        np.testing.assert_array_equal(Hout, H64)
+        np.testing.assert_array_equal(a.get_h(), H64.astype(np.float32))
+        a.set_h(H64.astype(np.float32))                                                  # a float32 upload replaces it: widened
+        assert a.get_h_into(Hout)
         np.testing.assert_array_equal(Hout, H64.astype(np.float32).astype(np.float64))
+        a.set_h(H64)
+        cn = _lib.Context(_lib.ALGO_NMF, m, n, k)                                        # every other class: H is float32 on the device
+        cn.set_h(H64)
+        assert cn.get_h_into(Hout)
+        np.testing.assert_array_equal(Hout, H64.astype(np.float32).astype(np.float64))
+        cn.close()
         W32o = np.empty((m, k), dtype=np.float32)
         assert a.get_w_into(W32o) and np.array_equal(W32o, b.get_w())
         assert not a.get_w_into(np.empty((m, k + 1)))                                    # wrong shape: the caller copies
