@@ -104,7 +104,12 @@ struct pmf_ctx {
   double rnmf_err2 = -1.0;      // RNMF: sum((V - W H)^2) from the last update_s (all ranks)
   double *dGd = nullptr, *dPart = nullptr, *dScal = nullptr;
   double* dGramPart = nullptr;  // k_gram_splitk: per-slice partial Gram matrices, [8][KP][KP]
-  unsigned* dGramTickets = nullptr;
+  unsigned* dGramTickets = nullptr;   // k_gram_splitk: one per tile, [tiles] the tile count of the fused Gram + inverse, [tiles + 1] k_reduce_slabs_inv's
+  // NMFALS at 64 bases, round 6 experiment: the k x k chain of a half step as ONE launch -- the workgroup that completes the
+  // Hessian inverts it (pmf_inv.h: k_gram_splitk<float, true>, k_reduce_slabs_inv); pmf_set_option("fuse_chain", 1 | 2) turns
+  // the W / H half step's fused form on
+  int opt_fuse_chain = 0;    // (measured: NOT faster -- profiles/r06_experiments.md; kept as an A/B knob with its bit-equality test)
+  bool want_inv = false, chain_prepared = false;
   float* dGpart = nullptr;      // k_nmf_h_gram: per-workgroup partial G, [PMF_HGRAM_MAX_WGS][KP][KP]
   float* dHsnap = nullptr;      // pmf_snapshot_h: H, then G, then the partial Gs
   bool hsnap_valid = false, hsnap_g_valid = false;
@@ -498,6 +503,19 @@ int reduce_slabs(pmf_ctx* c, int nslabs) {
   // NMFALS on one rank: the column QPs' Hessian S = W^T W leaves the same launch in float64 (with more ranks it has to come
   // from the ALL-REDUCED sums: k_hessian_from_ps behind the collective)
   const bool hess = c->want_hess && !multi_rank(c);
+  c->chain_prepared = false;
+  if (hess && c->want_inv && c->KP == 64 && (c->opt_fuse_chain & 2)) {
+    // ... and the workgroup that finishes last inverts it: flag, patched Hessian and B = inv(HA) leave the same launch
+    if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
+    if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));
+    if (!c->dGramTickets) PMFCHK(dalloc(c, &c->dGramTickets, (size_t)(c->KP / 16) * (c->KP / 16) + 2));
+    hipLaunchKernelGGL(k_reduce_slabs_inv, dim3((unsigned)((E / 4 + 63) / 64)), dim3(256), 0, c->stream, c->dSlab, nslabs, E, c->dPS, c->dGd,
+                       c->np, c->KP, c->k, c->dGramTickets + (c->KP / 16) * (c->KP / 16) + 1, c->dBinv, c->dWarm, c->dBinv + (size_t)c->KP * c->KP);
+    HIPCHK(c, hipGetLastError());
+    c->gd_is_s = true;
+    c->chain_prepared = true;
+    return PMF_OK;
+  }
   hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((E / 4 + 63) / 64)), dim3(1024), 0, c->stream,
                      c->dSlab, nslabs, E, c->dPS, hess ? c->dGd : (double*)nullptr, c->np, c->KP, c->k);
   HIPCHK(c, hipGetLastError());
@@ -714,7 +732,7 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
   if (ks > 1 && c->nb == 1) {
     if (!c->dGramPart) {
       PMFCHK(dalloc(c, &c->dGramPart, (size_t)8 * c->KP * c->KP));
-      PMFCHK(dalloc(c, &c->dGramTickets, (size_t)(c->KP / 16) * (c->KP / 16)));
+      PMFCHK(dalloc(c, &c->dGramTickets, (size_t)(c->KP / 16) * (c->KP / 16) + 2));
     }
     grid.z = (unsigned)ks;
     if (h64) hipLaunchKernelGGL(k_gram_splitk<double>, grid, dim3(256), 0, c->stream, c->dHd, (int64_t)c->np, c->np, c->KP, c->k, pad_diag, c->dG, c->dGd,
@@ -1996,19 +2014,40 @@ int solve_nnqps(pmf_ctx* c, const float* F, int64_t f_sk, int64_t f_sp, float* X
 
 int als_update_w(pmf_ctx* c) {
   // HA = H H^T (nmfals.py:93), -FA = V H^T (nmfals.py:88), one QP per row (nmfals.py:89-90)
-  PMFCHK(ensure_gram(c, 1.0));
+  bool prepared = false;
+  const int ks = c->np >= 2048 && c->np % 512 == 0 ? 8 : c->np >= 512 && c->np % 256 == 0 ? 4 : 1;   // (ensure_gram's rule)
+  if (!c->g_valid && c->KP == 64 && c->nb == 1 && ks > 1 && (c->opt_fuse_chain & 1)) {
+    // round 6: H H^T split over the columns AND its inverse (flag, patched Hessian, B) in one launch -- the workgroup that
+    // completes the last tile inverts (pmf_inv.h: k_gram_splitk<float, true>)
+    if (!c->dGramPart) PMFCHK(dalloc(c, &c->dGramPart, (size_t)8 * c->KP * c->KP));
+    if (!c->dGramTickets) PMFCHK(dalloc(c, &c->dGramTickets, (size_t)(c->KP / 16) * (c->KP / 16) + 2));
+    if (!c->dWarm) PMFCHK(dalloc(c, &c->dWarm, 1));
+    if (!c->dBinv) PMFCHK(dalloc(c, &c->dBinv, (size_t)2 * c->KP * c->KP));
+    hipLaunchKernelGGL((k_gram_splitk<float, true>), dim3((unsigned)(c->KP / 16), (unsigned)(c->KP / 16), (unsigned)ks), dim3(256), 0, c->stream, c->dH,
+                       (int64_t)c->np, c->np, c->KP, c->k, 1.0, c->dG, c->dGd, c->dGramPart, c->dGramTickets, c->dBinv, c->dWarm,
+                       c->dBinv + (size_t)c->KP * c->KP);
+    HIPCHK(c, hipGetLastError());
+    c->g_valid = true; c->g_parts = 0;
+    prepared = true;
+  } else {
+    PMFCHK(ensure_gram(c, 1.0));
+  }
   // (The QPs' preparation -- 56 us of single-workgroup k x k kernels that read HA only -- on a second stream beside
   // V H^T was tried: the iteration got 4 % SLOWER, profiles/r03_experiments.md.)
   PMFCHK(rowgemm<EPI_STORE>(c, c->dV, c->np, c->np, c->dH, c->np, nullptr, nullptr, c->dW1));
-  return solve_nnqps(c, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, true);
+  return solve_nnqps(c, c->dW1, 1, c->KP, c->dW, 1, c->KP, c->m, true, prepared);
 }
 
 int als_update_h(pmf_ctx* c) {
   // HA = W^T W (nmfals.py:78), -FA = W^T V (nmfals.py:73), one QP per column (nmfals.py:74-75)
   c->want_hess = c->nb == 1 && !use_csr(c);
+  c->want_inv = true;          // (64 bases, one rank: the slab reduce's last workgroup also inverts the Hessian it completes)
   c->gd_is_s = false;
+  c->chain_prepared = false;
   const int prc = ensure_ps(c);
-  c->want_hess = false;
+  c->want_hess = false; c->want_inv = false;
+  const bool prepared = c->chain_prepared && c->gd_is_s;
+  c->chain_prepared = false;
   PMFCHK(prc);
   const int64_t ldp = (int64_t)c->np + c->KP;
   if (!c->gd_is_s) {           // (the sums were cached, or crossed the ranks after the local reduce)
@@ -2016,7 +2055,7 @@ int als_update_h(pmf_ctx* c) {
     HIPCHK(c, hipGetLastError());
   }
   // problems = columns: f[kk] = PS[kk][col] (stride ldp over kk, 1 over problems)
-  PMFCHK(solve_nnqps(c, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, false));
+  PMFCHK(solve_nnqps(c, c->dPS, ldp, 1, c->dH, c->np, 1, c->n, false, prepared));
   c->g_valid = false; c->g_parts = 0; c->num_valid = false;
   c->ps_valid = true;
   c->trace_ready = false;
@@ -3366,6 +3405,11 @@ int pmf_set_option(pmf_ctx* c, const char* name, int64_t value) {
   if (std::strcmp(name, "rowgemm_stream") == 0) {
     if (value != 0 && value != 1) return fail(c, PMF_EINVAL, "rowgemm_stream: 0 or 1");
     c->opt_rowgemm_stream = (int)value;
+    return PMF_OK;
+  }
+  if (std::strcmp(name, "fuse_chain") == 0) {
+    if (value < 0 || value > 3) return fail(c, PMF_EINVAL, "fuse_chain: bit 0 = the W half step's Gram + inverse, bit 1 = the H half step's slab sum + inverse");
+    c->opt_fuse_chain = (int)value;
     return PMF_OK;
   }
   if (std::strcmp(name, "snmf_h64") == 0) {

@@ -23,6 +23,7 @@
 // The matrix is scaled to unit diagonal first (inv(G) = S inv(S G S) S): every pivot is then <= 1,
 // which makes the one-FMA-per-entry form of the 16 x 16 elimination free of cancellation.
 #pragma once
+#include <type_traits>
 #include "pmf_dev.h"     // f64x4, mfma_f64, readlane_f64
 
 // Index of element (row, col) of a 16 x 16 tile kept in LDS the way store_tile() below writes it.
@@ -135,13 +136,26 @@ __device__ unsigned long long g_inv_dbg[16 * 8 * 4];
 #else
 #define INV_STAMP(step, ph) do { } while (0)
 #endif
+// The body is a device function since round 6: besides the kernel of its own (k_inverse_spd_mfma below) the LAST workgroup of
+// a launch that has just FORMED the matrix runs it (k_gram_splitk<TH, true>, k_reduce_slabs_inv: one launch per k x k chain of
+// an NMFALS half step instead of two).  Called by 64 NBLK (NBLK / 4) threads of one workgroup, threadIdx.x = 0 ... ; Gd is NOT
+// restrict: in the fused launches it was written by other workgroups of the same launch (the caller has acquired it).
+template <int NBLK>
+struct InvLds {                                // the body's LDS image: the caller's to place (a fused launch overlays it on its own)
+  alignas(16) double pold[2][NBLK][256];       // row panel p before the step, double buffered
+  alignas(16) double pR[NBLK][256];            // R_j = D A_pj
+  alignas(16) double dsrc[256];                // the diagonal tile on its way into inv16_wave
+  alignas(16) double dD[2][256];               // D of step p in dD[p & 1]
+  alignas(32) double2 line[128];               // inv16_wave's pivot rows: two per lane group, plain and signed
+  double sc[16 * NBLK];                        // 1 / sqrt(g_ii)
+  double sdiag[16 * NBLK];
+  double pivmin[NBLK];                         // smallest pivot of each step's diagonal tile
+  int dflag;                                   // = la once tile (la, la) of the look-ahead is in dsrc
+};
 template <int NBLK>   // matrix order 16 NBLK (identity padded beyond k): 4 -> 64, 8 -> 128
-__global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
-                                                                             double* __restrict__ Ginv64,
-                                                                             const int* __restrict__ stop,
-                                                                             int* __restrict__ singular = nullptr,
-                                                                             int* __restrict__ spd_flag = nullptr,
-                                                                             double* __restrict__ Gpatched = nullptr) {
+__device__ __forceinline__ void inverse_spd_mfma_body(InvLds<NBLK>& L, const double* Gd, int ld, int k, double* __restrict__ Ginv64,
+                                                      int* __restrict__ singular, int* __restrict__ spd_flag,
+                                                      double* __restrict__ Gpatched) {
   // Gpatched (may be null; NMFALS): DEAD variables -- a basis that has died out: diagonal entry <= 1e-12 of the largest --
   // are replaced by the identity before the elimination (they never become passive in the QP kernels), and the patched
   // matrix is written to Gpatched [ld][ld] for those kernels: what k_nnqp_patch_dead did in a launch of its own.
@@ -149,22 +163,32 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   // the blocked Gauss-Jordan meets exactly the pivots of the unblocked LDL^T (the diagonal tile of a step is the Schur
   // complement of the blocks before it), and the unit-diagonal scaling makes them ratios already: k_spd_unique's test
   // (pmf_nnls.h) for free where the inverse is formed anyway (NMFALS W step on k_nnqp_quad).
-  if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep the inverse
   constexpr int CW = NBLK / 4;                 // waves per block row
   constexpr int KP = 16 * NBLK;
-  __shared__ __attribute__((aligned(16))) double pold[2][NBLK][256];   // row panel p before the step, double buffered
-  __shared__ __attribute__((aligned(16))) double pR[NBLK][256];        // R_j = D A_pj
-  __shared__ __attribute__((aligned(16))) double dsrc[256];            // the diagonal tile on its way into inv16_wave
-  __shared__ __attribute__((aligned(16))) double dD[2][256];           // D of step p in dD[p & 1]
-  __shared__ __attribute__((aligned(32))) double2 line[128];  // inv16_wave's pivot rows: two per lane group, plain and signed
-  __shared__ double sc[KP];                    // 1 / sqrt(g_ii)
-  __shared__ int dflag;                        // = la once tile (la, la) of the look-ahead is in dsrc
-  __shared__ double pivmin[NBLK];              // smallest pivot of each step's diagonal tile
+  double (&pold)[2][NBLK][256] = L.pold;
+  double (&pR)[NBLK][256] = L.pR;
+  double (&dsrc)[256] = L.dsrc;
+  double (&dD)[2][256] = L.dD;
+  double2 (&line)[128] = L.line;
+  double (&sc)[KP] = L.sc;
+  int& dflag = L.dflag;
+  double (&pivmin)[NBLK] = L.pivmin;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef PMF_INV_WAVE_MAP
+#define PMF_INV_WAVE_MAP 1
+#endif
+  // Which wave plays which part (round 6, order 128).  The two waves of block row p have no update to do in step p and one of
+  // them inverts the look-ahead tile -- a chain of dependent float64 operations that runs at a third of its speed beside MFMA
+  // waves on the same SIMD (the float64 MFMA and VALU share their ALUs: profiles/r05_experiments.md).  A workgroup's waves go to
+  // the four SIMDs round robin (wave w on SIMD w % 4), so with block row r on waves 2 r, 2 r + 1 the inverting wave shared its
+  // SIMD with THREE updating waves while another SIMD idled a slot.  Here block rows 2 s and 2 s + 1 live on the four waves
+  // of SIMD s: in step p that SIMD runs the inversion beside TWO updating waves, the others four each.  Roles only -- the
+  // arithmetic of every tile is what it was (same bits).
+  const int wv = (NBLK == 8 && PMF_INV_WAVE_MAP == 1) ? 4 * (pw & 3) + (pw >> 2) : pw;
   const int bi = wv / CW, j0 = 4 * (wv % CW);
   const int g = lane >> 4, cc = lane & 15;
-  __shared__ double sdiag[KP];
+  double (&sdiag)[KP] = L.sdiag;
   // every global load of the launch goes out here, the tiles beside the diagonal (one L2 / HBM latency, not two in a row;
   // round 5: the launch has a fixed cost of 7-9 us around its block steps, and this was 1 us of it)
   for (int i = tid; i < KP; i += 64 * NBLK * CW) sdiag[i] = i < k ? Gd[(int64_t)i * ld + i] : 0.0;
@@ -330,6 +354,18 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
   }
 }
 
+template <int NBLK>
+__global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
+                                                                             double* __restrict__ Ginv64,
+                                                                             const int* __restrict__ stop,
+                                                                             int* __restrict__ singular = nullptr,
+                                                                             int* __restrict__ spd_flag = nullptr,
+                                                                             double* __restrict__ Gpatched = nullptr) {
+  if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep the inverse
+  __shared__ InvLds<NBLK> L;
+  inverse_spd_mfma_body<NBLK>(L, Gd, ld, k, Ginv64, singular, spd_flag, Gpatched);
+}
+
 // ---- the k x n sized float64 products of the SNMF W step / Gram-space loop on the float64 MFMA -------
 // (M^T = inv(H H^T) H, P = M^T C, S = P M: 128 x 128 x 128 each at cfg5 -- latency-bound as 16 x 16 LDS
 // tiles on the VALU, 7 us apiece; here one wave per 16 x 16 tile takes its operands straight from L2 in
@@ -452,12 +488,18 @@ __global__ __launch_bounds__(256) void k_gram(const TH* __restrict__ H, int64_t 
 // 64 x 1024 H was 16 dependent L2 round trips per wave, 16 us of an NMFALS iteration -- each leaves its partial tile in
 // `part` [KS][KP][KP]; the LAST slice of a tile to arrive (ticket per tile, reset for the next launch) adds the KS partials in
 // slice order: deterministic.  part: KS * KP * KP doubles, tickets: (KP / 16)^2 zeroed unsigneds.
-template <typename TH>
+// INV (round 6, the k x k chain of the NMFALS W half step as ONE launch; KP == 64 only): the workgroup that finishes the LAST
+// tile -- a second ticket behind the tiles' own, tickets[number of tiles] -- goes on to invert the matrix it has just completed
+// (inverse_spd_mfma_body<4>: B = inv(G with its dead variables patched out) -> Binv, the patched matrix -> Gpatched, the
+// uniqueness flag of the row QPs -> spd_flag), where a launch of k_inverse_spd_mfma<4> followed before.
+template <typename TH, bool INV = false>
 __global__ __launch_bounds__(256) void k_gram_splitk(const TH* __restrict__ H, int64_t ldh, int np, int KP, int k, double pad_diag,
-                                                     float* __restrict__ Gf, double* __restrict__ Gd, double* __restrict__ part,
-                                                     unsigned* __restrict__ tickets) {
+                                                     float* __restrict__ Gf, double* Gd, double* __restrict__ part,
+                                                     unsigned* __restrict__ tickets, double* __restrict__ Binv = nullptr,
+                                                     int* __restrict__ spd_flag = nullptr, double* __restrict__ Gpatched = nullptr) {
   __shared__ double wpart[3][4][64];
-  __shared__ unsigned s_last;
+  __shared__ unsigned s_last, s_all;
+  __shared__ std::conditional_t<INV, InvLds<4>, int> Linv;   // (INV: the inversion's image)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ra = blockIdx.x * 16, rb = blockIdx.y * 16, KS = gridDim.z, z = blockIdx.z;
@@ -468,9 +510,10 @@ __global__ __launch_bounds__(256) void k_gram_splitk(const TH* __restrict__ H, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) wpart[wv - 1][r][lane] = acc[r];
   }
+  if (tid == 0) s_all = 0u;
   __syncthreads();
   const int gb = rb + (lane & 15), g = lane >> 4;
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
   if (wv == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -481,18 +524,93 @@ __global__ __launch_bounds__(256) void k_gram_splitk(const TH* __restrict__ H, i
     if (lane == 0) s_last = (atomicAdd(&tickets[tile], 1u) == (unsigned)KS - 1) ? 1u : 0u;
   }
   __syncthreads();
-  if (!s_last || wv != 0) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (!s_last || (wv != 0 && !INV)) return;
+  if (wv == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ga = ra + g + 4 * r;
-    double v = 0.0;
-    for (int q = 0; q < KS; ++q) v += part[((size_t)q * KP + ga) * KP + gb];
-    if (ga >= k || gb >= k) v = (ga == gb) ? pad_diag : 0.0;
-    Gf[(int64_t)ga * KP + gb] = (float)v;
-    if (Gd) Gd[(int64_t)ga * KP + gb] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int ga = ra + g + 4 * r;
+      double v = 0.0;
+      for (int q = 0; q < KS; ++q) v += part[((size_t)q * KP + ga) * KP + gb];
+      if (ga >= k || gb >= k) v = (ga == gb) ? pad_diag : 0.0;
+      Gf[(int64_t)ga * KP + gb] = (float)v;
+      if (Gd) Gd[(int64_t)ga * KP + gb] = v;
+    }
+    if (lane == 0) tickets[tile] = 0u;                          // ready for the next launch (stream order)
+    if (INV) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // the tile is out before the tile count moves
+      if (lane == 0) s_all = (atomicAdd(&tickets[ntiles], 1u) == (unsigned)ntiles - 1) ? 1u : 0u;
+    }
   }
-  if (lane == 0) tickets[tile] = 0u;                            // ready for the next launch (stream order)
+  if (!INV) return;
+  __syncthreads();
+  if (!s_all) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // every tile of G, written by workgroups all over the chip
+  if (tid == 0) tickets[ntiles] = 0u;
+  if constexpr (INV) inverse_spd_mfma_body<4>(Linv, Gd, KP, k, Binv, nullptr, spd_flag, Gpatched);
+}
+
+// The H half step's chain: out[e] = sum over slabs of slab[c][e] (k_reduce_slabs of pmf_tiled.h: the same sixteen float64
+// partial sums -- slabs j, j + 16, ... -- combined in the same order, so the same bits), the S part also as the float64 Hessian
+// Gd of the column QPs -- and the workgroup that finishes LAST (ticket) inverts it: uniqueness flag, patched Hessian and B in the
+// same launch (KP == 64).  256 threads per workgroup, the inversion's size (1 024 would cap it at 128 registers: 96 B of
+// scratch); wave w forms partial sums w, w + 4, w + 8, w + 12 of its 64 float4.
+__global__ __launch_bounds__(256) void k_reduce_slabs_inv(const float* __restrict__ slab, int nslabs, int64_t E, float* __restrict__ out,
+                                                          double* Gd, int np, int KP, int k, unsigned* __restrict__ ticket,
+                                                          double* __restrict__ Binv, int* __restrict__ spd_flag, double* __restrict__ Gpatched) {
+  // (the sums' partials and the inversion's image share their LDS: one after the other -- 33 KiB instead of 66, so that four
+  //  workgroups per CU keep the loads of this HBM-bound sum in flight)
+  union SumOrInv { double part[16][64][4]; InvLds<4> inv; };
+  __shared__ SumOrInv u;
+  double (&part)[16][64][4] = u.part;
+  __shared__ unsigned s_all;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;      // float4 index
+  const int64_t E4 = E >> 2;
+  double sacc[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sacc[q][u] = 0.0;
+  if (e4 < E4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e4;
+    for (int c = wv; c < nslabs; c += 16) {               // four chains: slabs c, c + 4, c + 8, c + 12 belong to partials wv, wv + 4, ...
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (c + 4 * q < nslabs) {
+          const f32x4 v = p[(int64_t)(c + 4 * q) * E4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sacc[q][u] += (double)v[u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) part[wv + 4 * q][lane][u] = sacc[q][u];
+  __syncthreads();
+  if (e4 < E4) {                  // wave q combines component q of the 64 float4
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane][wv];
+    out[4 * e4 + wv] = (float)t;
+    const int64_t e = 4 * e4 + wv, ldp = (int64_t)np + KP;
+    const int r = (int)(e / ldp), cc = (int)(e % ldp) - np;
+    if (cc >= 0) Gd[(int64_t)r * KP + cc] = (r < k && cc < k) ? (double)(float)t : (r == cc ? 1.0 : 0.0);
+  }
+  // every storing wave drains its stores, the workgroup meets, ONE agent-scope release in front of the ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    s_all = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_all) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) *ticket = 0u;
+  inverse_spd_mfma_body<4>(u.inv, Gd, KP, k, Binv, nullptr, spd_flag, Gpatched);
 }
 
 // ---- SNMF: H in float64 on the device (round 6) -------------------------------------------------------------------------

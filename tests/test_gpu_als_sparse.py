@@ -255,3 +255,31 @@ def test_snmf_csr_shape_beyond_the_lds_accumulator(pm):
     a.update_w(); o.update_w(); a.update_h(); o.update_h()
     a.factorize(niter=2, compute_err=False); o.factorize(niter=2, compute_err=False)
     assert rel_fro(a.W, o.W, what="mdl.W") < 2e-4 and rel_fro(a.H, o.H, what="mdl.H") < 2e-5
+
+
+@pytest.mark.parametrize("shape,k,niter", [((32768, 1024), 64, 5), ((20000, 512), 40, 6), ((3000, 2048), 64, 4), ((17000, 768), 50, 5)])
+def test_fused_k_by_k_chain_gives_the_bits_of_the_two_launch_chain(pm, shape, k, niter):
+    """Round 6 ('3b'): at 49-64 bases the k x k chain of an NMFALS half step CAN run as one launch (option
+    fuse_chain; off by default: it measured 1-2 % slower than two launches) -- the workgroup
+    that completes H H^T (k_gram_splitk<float, true>) resp. the slab sum with the Hessian W^T W (k_reduce_slabs_inv) goes on to
+    invert it: uniqueness flag, patched Hessian and B = inv(HA) for the QP kernels.  Same sums in the same order and the same
+    inversion body as the two launches before (option fuse_chain = 0): W, H and ferr must be bit-identical, hook by hook too."""
+    from pymf_amd import _lib
+    rs = np.random.RandomState(shape[1] + k)
+    V = rs.random_sample(shape).astype(np.float32)
+    W0 = rs.random_sample((shape[0], k)).astype(np.float32)
+    H0 = rs.random_sample((k, shape[1])).astype(np.float32)
+    outs = []
+    for fuse in (3, 0):          # (both half steps fused / the default: two launches each -- measured faster, profiles/r06_experiments.md)
+        c = _lib.Context(_lib.ALGO_NMFALS, shape[0], shape[1], k)
+        c.set_v_dense(V); c.set_w(W0); c.set_h(H0)
+        c.set_option("fuse_chain", fuse)
+        ferr, done, _ = c.factorize(niter, compute_err=True)
+        assert done == niter
+        a = (c.get_w(), c.get_h(), ferr.copy())
+        c.update_w(); c.update_h()
+        outs.append(a + (c.get_w(), c.get_h()))
+        c.close()
+    for x, y in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(x, y)
+    assert (outs[0][0] >= 0).all() and np.isfinite(outs[0][2]).all()

@@ -106,8 +106,13 @@ def test_s_survives_new_data_and_copies(pm):
         b = how(a)
         assert rel_fro(b.S, o.S, what="S of a copy") < 1e-5
         oc = copy.deepcopy(o)
+        # ONE step from the SAME state (round-5 verdict W3: compared along the two trajectories this sat at 9.3e-4 of 1e-3 -- the
+        # bound then depends on how many residual entries had fallen on different sides of +-lamb in float32 and float64 over the
+        # iterations before, not on the step under test).  The oracle copy takes the device copy's W, H and S as they are: what
+        # is left is the float32 MFMA arithmetic of a single update_w, and the stated tolerance of the multiplicative rule holds
+        oc.W, oc.H, oc.S = np.array(b.W, dtype=np.float64), np.array(b.H, dtype=np.float64), np.array(b.S, dtype=np.float64)
         b.update_w(); oc.update_w()
-        assert rel_fro(b.W, oc.W, what="a copy's update_w") < 1e-3
+        assert rel_fro(b.W, oc.W, what="a copy's update_w") < 2e-5
         b.factorize(niter=2); oc.factorize(niter=2)
         # (soft thresholding is discontinuous: entries of the residual next to +-lamb fall on different sides in float32 and
         # float64, and every further iteration spreads that -- the reason RNMF's tolerances are what they are)
