@@ -4,10 +4,18 @@
  *
  * Plain C, no C++ or torch types.  One pmf_ctx drives ONE GPU from one host
  * thread (thread-compatible, not thread-safe); multi-GPU = one process (ctx)
- * per GPU, rows of V/W sharded, one RCCL all-reduce of (W^T V | W^T W) per iteration
+ * per GPU, rows of V/W sharded, ONE cross-rank sum of (W^T V | W^T W) per iteration
  * inside pmf_factorize (for the single hooks: inside whichever of pmf_update_w /
- * pmf_update_h forms those sums -- all ranks make the same calls in the same order).  The caller owns every host buffer; the library owns all
- * device memory, its HIP stream and its RCCL communicator.
+ * pmf_update_h forms those sums -- all ranks make the same calls in the same order).
+ * How that sum travels: for 2..8 ranks of one node, once
+ * pmf_ipc_export / pmf_ipc_import have mapped the peers' receive areas and pmf_ipc_selftest
+ * has agreed with the other transport on every rank, a ONE-SHOT exchange -- every rank writes
+ * its partial into every peer's memory and adds the N partials in rank order -- folded into
+ * the slab-reduce and H-step launches of the loop (no launch of its own); otherwise, and for
+ * payloads beyond 256 KiB, ncclAllReduce on the context's RCCL communicator (or the host
+ * callback of pmf_set_host_allreduce where the ranks cannot form one).  Every transport adds
+ * in rank order: H stays bit-identical across the ranks.  The caller owns every host buffer;
+ * the library owns all device memory, its HIP stream and its RCCL communicator.
  *
  * Reference interface each entry point replaces (paths into nils-werner/pymf):
  *   pmf_ctx_create        NMF.__init__                 pymf/nmf.py:71-97
@@ -102,7 +110,9 @@ int pmf_get_w_f32(pmf_ctx* ctx, float* W);
 int pmf_set_h_f32(pmf_ctx* ctx, const float* H);
 int pmf_get_h_f32(pmf_ctx* ctx, float* H);
 /* ... and for float64 host arrays -- what self.W / self.H are by default (nmf.py:117,120): rounded to / widened from the
- * device's float32 on the device, so that neither direction needs a conversion pass over m x k on the host. */
+ * device's float32 on the device, so that neither direction needs a conversion pass over m x k on the host.
+ * SNMF (option "snmf_h64", default on): H is KEPT in float64 on the device -- pmf_set_h_f64 / pmf_get_h_f64 carry
+ * the float64 values as they are; pmf_get_h_f32 returns their rounding. */
 int pmf_set_w_f64(pmf_ctx* ctx, const double* W);
 int pmf_get_w_f64(pmf_ctx* ctx, double* W);
 int pmf_set_h_f64(pmf_ctx* ctx, const double* H);
@@ -229,6 +239,14 @@ int pmf_host_checksum(const void* data, uint64_t nbytes, uint64_t* out2);
  *   "nnqp_wave"  1 (default): NMFALS / NMFNNLS sub-problems at 64 < num_bases <= 128 on k_nnqp_wave (one wave per problem,
  *                block principal pivoting on the smaller of HA[P,P] / inv(HA)[N,N], LDL^T in registers); 0: k_nnqp_big (one
  *                variable at a time, the inverse image in global memory).  Same KKT point, float32 results equal to rounding.
+ *   "snmf_h64"   1 (default): SNMF with num_bases <= 128 keeps H in FLOAT64 on the device (the reference's H is float64,
+ *                pymf/nmf.py:120, and W = V H^T inv(H H^T) amplifies its rounding by sigma_max / sigma_min of H): G = H H^T,
+ *                M^T = inv(G) H and the H step (snmf.py:72-91, on the float64 MFMA) read and write that copy; the float32 H is
+ *                its rounding.  pmf_set_h_f64 / pmf_get_h_f64 round-trip the float64 values exactly; a float32 upload
+ *                replaces them by the widened values.  0: H is float32 between the steps (rounds 1-5).
+ *   "fuse_chain" NMFALS at 49..64 bases, 0 (default): the k x k chain of a half step as two launches (Gram / slab sum, then
+ *                the inverse); bit 0 / bit 1: the W / H half step's chain as ONE launch whose last workgroup inverts the
+ *                Hessian it has completed.  Bit-identical; measured 1-2 % slower per iteration (an A/B knob).
  *   "force_tiled" 1: every path of this context takes the any-shape two-pass kernels (k_rowgemm / k_colgemm)
  *                even where a one-pass kernel covers the shape; 0 gives the one-pass kernels back.  For tests
  *                and measurements of the any-shape kernels on the bench shapes. */
