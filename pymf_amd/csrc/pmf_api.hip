@@ -85,6 +85,7 @@ struct pmf_ctx {
   // has compared the two in THIS API call (need() clears it); ps_f64: (P | S) of the Gram-space iteration at hand are in dPd / dSd
   double *dHd = nullptr, *dSd = nullptr, *dHdSnap = nullptr;
   bool hd_synced = false, hd_force = false, ps_f64 = false;   // hd_force: H was replaced through a float32 entry point
+  bool psd_fresh = false;      // dPd / dSd are the float64 (P | S) of the CURRENT W (set by a Gram-space iteration, for the error behind it; an API entry clears it)
   int opt_snmf_h64 = 1;
   double* dCslabs = nullptr;    // k_csr_gram: per-workgroup images of C's upper triangle (two 64-bit fixed-point limbs per entry)
   unsigned* dVmaxBits = nullptr; // ... and the bit pattern of the largest |v| (the limbs' grids)
@@ -753,6 +754,7 @@ int ensure_gram(pmf_ctx* c, double pad_diag) {
 int need(pmf_ctx* c, bool v, bool w, bool h) {
   if (!c) return PMF_EINVAL;
   c->hd_synced = false;        // (a new API call: whoever wrote the float32 H since the last one is noticed by k_hd_sync)
+  c->psd_fresh = false;
   if (v && !c->have_v) return fail(c, PMF_EINVAL, "V has not been set (pmf_set_v_*)");
   if (w && !c->have_w) return fail(c, PMF_EINVAL, "W has not been set (pmf_set_w_f32)");
   if (h && !c->have_h) return fail(c, PMF_EINVAL, "H has not been set (pmf_set_h_f32)");
@@ -1786,6 +1788,7 @@ int snmf_gram_iteration(pmf_ctx* c) {
   c->ps_f64 = h64;            // the H step takes P and S in float64 (dPd, dSd), not their float32 roundings in (P | S)
   const int hrc = h_step_from_ps(c);
   c->ps_f64 = false;
+  c->psd_fresh = h64 && hrc == PMF_OK;     // the error of this iteration takes <P,H>, <S H,H> from the float64 P, S and H
   return hrc;
 }
 
@@ -2065,6 +2068,7 @@ int als_update_h(pmf_ctx* c) {
 int do_update_w(pmf_ctx* c) {
   c->w_implicit = false;        // about to be overwritten (SNMF) -- only SNMF loops leave it set
   c->ps_valid = false;
+  c->psd_fresh = false;
   c->trace_ready = false;
   switch (c->algo) {
     case PMF_ALGO_NMF: return nmf_update_w(c);
@@ -2130,6 +2134,29 @@ int ensure_vnorm(pmf_ctx* c) {
 // ||V||^2 - 2<P,H> + <S H,H> gives the same number from k x n sized data in float64 -- no third
 // pass over V and, across ranks, no extra collective (P, S are already all-reduced).  The identity
 // cancels when the fit is nearly exact; below 1e-3 relative residual energy the direct pass runs.
+// part[2 b], part[2 b + 1] = this column block's share of <P, H>, <S H, H> (k_trace_terms): from the float32 (P | S) and H, or --
+// SNMF with its float64 H -- from Hd, and inside the Gram-space loop from the float64 P, S of the iteration at hand (psd_fresh)
+int ensure_hd(pmf_ctx* c);
+int launch_trace_terms(pmf_ctx* c) {
+  const int nb = c->np / 16;
+  const int64_t ldp = (int64_t)c->np + c->KP;
+  if (c->algo == PMF_ALGO_SNMF && c->nb == 1 && c->opt_snmf_h64 != 0) {
+    PMFCHK(ensure_hd(c));
+    const size_t smem = (size_t)c->KP * 16 * sizeof(double);
+    if (c->psd_fresh && c->ps_valid)
+      hipLaunchKernelGGL((k_trace_terms<double, double>), dim3(nb), dim3(256), smem, c->stream, (const double*)c->dHd, (int64_t)c->np, c->np, c->KP,
+                         (const double*)c->dPd, (int64_t)c->np, (const double*)c->dSd, (int64_t)c->KP, c->dPart);
+    else
+      hipLaunchKernelGGL((k_trace_terms<double, float>), dim3(nb), dim3(256), smem, c->stream, (const double*)c->dHd, (int64_t)c->np, c->np, c->KP,
+                         (const float*)c->dPS, ldp, (const float*)c->dPS + c->np, ldp, c->dPart);
+  } else {
+    hipLaunchKernelGGL((k_trace_terms<float, float>), dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream, (const float*)c->dH,
+                       (int64_t)c->np, c->np, c->KP, (const float*)c->dPS, ldp, (const float*)c->dPS + c->np, ldp, c->dPart);
+  }
+  HIPCHK(c, hipGetLastError());
+  return PMF_OK;
+}
+
 int trace_e2(pmf_ctx* c, double* e2_out) {   // needs ps_valid and vnorm_valid
   double t[2] = {0.0, 0.0};
   if (c->trace_ready && c->ps_valid && c->trace_parts > 0) {   // ... as per-workgroup pairs
@@ -2141,9 +2168,7 @@ int trace_e2(pmf_ctx* c, double* e2_out) {   // needs ps_valid and vnorm_valid
     HIPCHK(c, hipMemcpyAsync(t, c->dScal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   } else {
     const int nb = c->np / 16;
-    hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
-                       c->dH, (int64_t)c->np, c->np, c->KP, c->dPS, c->dPart);
-    HIPCHK(c, hipGetLastError());
+    PMFCHK(launch_trace_terms(c));
     hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(t, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2803,8 +2828,7 @@ int pmf_factorize(pmf_ctx* c, int32_t niter, uint32_t flags, double conv_eps, do
         if (lrc == PMF_OK && c->trace_ready && c->trace_parts > 0) { tt = c->dT1part; ntt = c->trace_parts; }   // ... or as pairs
         if (lrc == PMF_OK && !c->trace_ready) {           // SNMF: the H-step kernel does not form them
           const int nb = c->np / 16;
-          hipLaunchKernelGGL(k_trace_terms, dim3(nb), dim3(256), (size_t)c->KP * 16 * sizeof(float), c->stream,
-                             c->dH, (int64_t)c->np, c->np, c->KP, c->dPS, c->dPart);
+          lrc = launch_trace_terms(c);
           hipLaunchKernelGGL(k_sum_pairs_f64, dim3(1), dim3(256), 0, c->stream, c->dPart, nb, c->dScal);
           tt = c->dScal;
         }

@@ -532,24 +532,29 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ X, int6
 // Trace identity for the residual: with P = W^T V, S = W^T W of the CURRENT W,
 //   ||V - W H||^2 = ||V||^2 - 2 <P, H> + <S H, H>.
 // One block per 16 columns of H; part[2*b] = sum P.H, part[2*b+1] = sum (S H).H, float64.
-__global__ __launch_bounds__(256) void k_trace_terms(const float* __restrict__ H, int64_t ldh, int np,
-                                                     int KP, const float* __restrict__ PS,
+// TH / TP: float (H, and P | S as the float32 roundings in (P | S)) or double (round 6, SNMF: the float64 H of pmf_inv.h; inside
+// the Gram-space loop also P and S as the float64 products dPd / dSd -- the identity cancels ||V||^2 against <P,H>, and the
+// float32 rounding of P alone cost 1e-4 of ferr on a fit at 7 % of ||V||).
+template <typename TH, typename TP>
+__global__ __launch_bounds__(256) void k_trace_terms(const TH* __restrict__ H, int64_t ldh, int np,
+                                                     int KP, const TP* __restrict__ P, int64_t ldP,
+                                                     const TP* __restrict__ S, int64_t ldS,
                                                      double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) float hs[];   // [KP][16]
+  extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];   // [KP][16] of TH
+  TH* hs = reinterpret_cast<TH*>(hs_raw);
   __shared__ double w1[4], w2[4];
   const int tid = threadIdx.x;
   const int c = tid & 15;
   const int col = blockIdx.x * 16 + c;
-  const int64_t ldp = (int64_t)np + KP;
   for (int kk = tid >> 4; kk < KP; kk += 16) hs[kk * 16 + c] = H[(int64_t)kk * ldh + col];
   __syncthreads();
   double t1 = 0.0, t2 = 0.0;
   for (int kk = tid >> 4; kk < KP; kk += 16) {
-    const float* srow = PS + (int64_t)kk * ldp + np;
+    const TP* srow = S + (int64_t)kk * ldS;
     double sh = 0.0;
     for (int j = 0; j < KP; ++j) sh = fma((double)srow[j], (double)hs[j * 16 + c], sh);
     const double h = (double)hs[kk * 16 + c];
-    t1 = fma((double)PS[(int64_t)kk * ldp + col], h, t1);
+    t1 = fma((double)P[(int64_t)kk * ldP + col], h, t1);
     t2 = fma(sh, h, t2);
   }
   t1 = wave_sum_f64(t1);

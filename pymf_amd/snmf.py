@@ -5,6 +5,12 @@ H >= 0.  update_w: W = (V H^T) inv(H H^T)  (snmf.py:67-70, REBINDS self.W);
 update_h: the pos/neg-split multiplicative sqrt rule (snmf.py:72-91).
 scipy.sparse CSR data is accepted (the reference cannot run on it; semantics =
 dense SNMF on data.toarray(), frobenius_norm() keeps the reference's -123456).
+
+Precision: `data` and W are float32 on the device like every other class, but H -- k x n, and the
+operand of inv(H H^T), which amplifies its rounding by sigma_max / sigma_min of H (3e3 for a square
+uniform H) -- is kept in FLOAT64 there, as the reference keeps it (nmf.py:120): a float64 self.H goes
+up and comes back exactly, and the H step (snmf.py:72-91) runs on the float64 matrix cores
+(num_bases <= 128).
 """
 import numpy as np
 
