@@ -15,6 +15,9 @@ MAP = {
     ("cfg2", "void k_nmf_fused<2, 4, 0, 2>"): ("k_nmf_fused<2,4,SPLIT 2>", "65536x512x32"),
     ("cfg3", "void k_nnqp_quad<16, 12, false>"): ("k_nnqp_quad(update_w)", "262144x1024x64"),
     ("cfg5", "void k_csr_w_blocks<8>"): ("k_csr_w_blocks(W = V M)", "4194304x128x128"),
+    # cfg3's two long products (not the line's `roofline` kernel: recorded for DESIGN 3.3 / the verdict's traffic ratios)
+    ("cfg3", "void k_rowgemm_stream<4, 4, 0, false>"): ("k_rowgemm_stream<4,4,store>", "262144x1024x64"),
+    ("cfg3", "void k_colgemm_stream<4, true>"): ("k_colgemm_stream<4,true>", "262144x1024x64"),
 }
 out = {"_provenance": "round %s (tools/pmc_configs.sh %s -> profiles/%s_pmc_summary.csv): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                       "separate passes over bench.py per config; bytes = 2 * FETCH_SIZE (gfx950: FETCH_SIZE reports half of a wide "
