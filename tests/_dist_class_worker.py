@@ -152,6 +152,34 @@ def main():
     fs = dist.allgather_bytes(np.ascontiguousarray(e.ferr, dtype=np.float64).tobytes())
     assert all(f == fs[0] for f in fs), "ferr must be bit-identical on every rank"
     digest("early-exit ferr", e.ferr)
+    if FAKE:
+        # ---- bench.py's sharded `parity_full_size` (round 6): rank 0 holds the unsharded float64 oracle's factors; every rank restarts
+        # its shard from the seeded W0 rows / H0, runs the same iterations through the cross-rank sum and compares ITS row block
+        # (scattered by rank 0); H digests are all-gathered.  Here on the NumPy stand-in of the device context: the collective
+        # sequence (broadcasts, scatter, all-gathers with their tags) is what is under test ----
+        import bench
+        mb, nb_, kb = 517, 96, 8
+        lob, hib = w.row_range(mb)
+        fctx = FakeContext(_lib.ALGO_NMF, hib - lob, nb_, kb)
+        fctx.set_v_dense(bench.gen_rows(np.random.RandomState(1234), mb, nb_, lob, hib))
+        fac = None
+        if w.rank == 0:
+            Vb = bench.gen_rows(np.random.RandomState(1234), mb, nb_, 0, mb)
+            np.random.seed(42)
+            ob = oracle.NMFOracle(Vb, num_bases=kb)
+            ob.W, ob.H = np.random.random((mb, kb)), np.random.random((kb, nb_))
+            ob.W = ob.W.astype(np.float32).astype(np.float64)            # (bench.py uploads float32 rows of W0: gen_rows)
+            ob.factorize(niter=6, compute_err=False)
+            fac = {"iters": 6, "W": ob.W, "H": ob.H, "ferr": float(oracle.frobenius_norm(Vb, ob.W, ob.H))}
+        par = bench.sharded_parity_nmf(fctx, dist, fac, mb, nb_, kb, lob, hib)
+        if w.rank == 0:
+            print("sharded parity: %s" % {k_: v_ for k_, v_ in par.items() if k_ != "against"})
+            assert par["ranks"] == w.size and par["iters"] == 6 and len(par["relW_per_rank"]) == w.size
+            assert par["h_identical_across_ranks"] is True and par["ferr_identical_across_ranks"] is True
+            assert par["relW_max_over_ranks"] < 1e-6 and par["relH_max_over_ranks"] < 1e-6 and par["relferr"] < 1e-6, par
+        else:
+            assert par is None
+
     if not FAKE:
         # ---- loops that stop inside a chunk, back to back on the bare context (no per-call vote between them: bench.py's
         # pattern): the folded exchanges behind a stop push nothing, so their sequence numbers must be taken back or the two-slot
