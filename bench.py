@@ -350,6 +350,8 @@ def launch_ranks(args, child=None):
                   "not be an N-GPU measurement (use --debug-share-gpu for the plumbing check on one GPU)" % (n, have),
                   file=sys.stderr)
             return 2
+    # (picked, released, re-bound by rank 0: another process may take the port in between -- pymf_amd.dist then serves on the next
+    #  free port of its span and the joiners, who scan the same span and authenticate by HMAC, find it there)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -360,13 +362,21 @@ def launch_ranks(args, child=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYMF_BENCH_SELF_LAUNCHED="1")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
         procs.append(subprocess.Popen(child or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+                                      stdout=subprocess.PIPE, stderr=None))
+    stray = []                                # JSON lines printed by ranks other than 0 (there must be none)
 
-    def _drain():
-        for line in procs[0].stdout:
-            out0.append(line.decode("utf-8", "replace"))
-    t = threading.Thread(target=_drain, daemon=True)
-    t.start()
+    def _drain(r):
+        for line in procs[r].stdout:
+            text = line.decode("utf-8", "replace")
+            if r == 0:
+                out0.append(text)
+            else:                             # a non-zero rank's stdout goes to our stderr, its JSON lines are counted
+                if text.startswith("{"):
+                    stray.append(r)
+                sys.stderr.write(text)
+    drains = [threading.Thread(target=_drain, args=(r,), daemon=True) for r in range(n)]
+    for t in drains:
+        t.start()
     deadline = time.time() + float(args.launch_timeout)
     status, why = 0, ""
     while True:
@@ -391,10 +401,12 @@ def launch_ranks(args, child=None):
             except subprocess.TimeoutExpired:
                 pass
         print("bench.py: %s; the other ranks were stopped" % why, file=sys.stderr)
-    t.join(timeout=10)
+    for t in drains:
+        t.join(timeout=10)
     lines = [l for l in out0 if l.startswith("{")]
-    if status == 0 and len(lines) != 1:
-        print("bench.py: rank 0 printed %d JSON lines" % len(lines), file=sys.stderr)
+    if status == 0 and (len(lines) != 1 or stray):
+        print("bench.py: rank 0 printed %d JSON lines, other ranks %d (ranks %s): exactly one line, from rank 0, is the contract"
+              % (len(lines), len(stray), sorted(set(stray))), file=sys.stderr)
         status = 5
     if status == 0:
         sys.stdout.write(lines[0])

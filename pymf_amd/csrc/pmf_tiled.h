@@ -774,8 +774,18 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_tiles(const float* __rest
   const int tile = blockIdx.x;
   const f32x4* p = reinterpret_cast<const f32x4*>(slab) + (size_t)tile * 64 + lane;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // (round 6: sixteen loads in flight per wave -- 256 slabs are one batch, not four dependent round trips to memory the
+  //  one-pass kernel's workgroups all over the chip have just written; the order of the additions is what it was)
+  int c = wv;
+  for (; c + 16 * 15 < nslabs; c += 256) {
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(c + 16 * u) * NTU * 64];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { s0 += (double)v[u][0]; s1 += (double)v[u][1]; s2 += (double)v[u][2]; s3 += (double)v[u][3]; }
+  }
 #pragma unroll 4
-  for (int c = wv; c < nslabs; c += 16) {
+  for (; c < nslabs; c += 16) {
     const f32x4 v = p[(size_t)c * NTU * 64];
     s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
   }

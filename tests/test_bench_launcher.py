@@ -61,3 +61,14 @@ def test_fewer_gpus_than_ranks_is_an_error_not_a_one_gpu_line():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
     assert p.returncode != 0
     assert p.stdout.decode().strip() == "" and "GPU(s) are visible" in p.stderr.decode()
+
+
+def test_a_json_line_from_another_rank_breaks_the_one_line_contract(capfd):
+    """Round-5 advisor: the stdout of ranks >= 1 went to the launcher's stderr unseen, so a second JSON line printed by a
+    non-zero rank was not counted.  Every rank's stdout is drained now; a JSON line from anybody but rank 0 fails the job."""
+    prog = ("import os, json; r = int(os.environ['RANK']); "
+            "print(json.dumps({'rank': r})) if r in (0, 2) else None")
+    rc = bench.launch_ranks(_args(3), child=[sys.executable, "-c", prog])
+    out, err = capfd.readouterr()
+    assert rc == 5 and out.strip() == "", (rc, out)
+    assert "exactly one line, from rank 0" in err and "[2]" in err, err
