@@ -22,6 +22,9 @@
 // row p -- idle in this step -- which inverts it on the VALU while the others keep the MFMA busy.
 // The matrix is scaled to unit diagonal first (inv(G) = S inv(S G S) S): every pivot is then <= 1,
 // which makes the one-FMA-per-entry form of the 16 x 16 elimination free of cancellation.
+// Round 6: the order-128 instantiation keeps only the UPPER TRIANGLE (inverse_spd_sym8_body below: 28 tile updates per step
+// instead of 49, the panel's tiles left of the diagonal published as -(tile)^T by the column's owners): 34.1 -> 30.1 us.  The
+// full-matrix form described above is what order 64 runs (and order 128 with -DPMF_INV_SYM8=0, for A/B).
 #pragma once
 #include <type_traits>
 #include "pmf_dev.h"     // f64x4, mfma_f64, readlane_f64
@@ -354,6 +357,211 @@ __device__ __forceinline__ void inverse_spd_mfma_body(InvLds<NBLK>& L, const dou
   }
 }
 
+// ---- order 128, the UPPER TRIANGLE only (round 6; round-5 verdict next 5) ---------------------------------------------
+// The full-matrix form above updates 7 x 7 tiles per block step (196 + 28 MFMAs) on ONE CU -- at four waves per SIMD those
+// MFMAs, not the in-wave inverse beside them, are what a step costs (grouping the wave roles by SIMD moved 0.5 us).  The
+// in-place state is sign-symmetric -- M_ji = (M_ij)^T when i and j are both eliminated or both not, -(M_ij)^T otherwise --
+// so the 36 tiles on and above the diagonal carry everything: 28 tile updates per step instead of 49.  What the updates need
+// of the lower triangle is row panel p COMPLETE in LDS (tile (p, i) as the A operand of every update in row i -- its C layout
+// is the A-operand layout of its transpose --, tile (p, j) under D for R_j): its tiles left of the diagonal are the
+// transposes of the column above the diagonal, so the owner of tile (i, p + 1), i <= p, publishes -(tile)^T into the panel
+// of the next step when its update of step p is done (i is eliminated by then, p + 1 is not: the minus sign) -- four 8-byte
+// LDS stores per lane, 4-way bank conflicts, once per tile and step, off the critical chain.  No MFMA operand is ever read
+// transposed.  Waves 0 .. 7 own one diagonal tile each and carry the step's serial chain -- wave j forms R_j; wave p + 1
+// brings its tile up to date first and hands it over; wave p, whose tile only becomes D in step p, inverts it -- while
+// waves 8 .. 15 own the 28 tiles above the diagonal (3 or 4 each, 7 per SIMD) and run the updates beside that chain.
+// The result is written to both triangles.
+__device__ __forceinline__ void inverse_spd_sym8_body(InvLds<8>& L, const double* Gd, int ld, int k, double* __restrict__ Ginv64,
+                                                      int* __restrict__ singular, int* __restrict__ spd_flag,
+                                                      double* __restrict__ Gpatched) {
+  constexpr int NBLK = 8, KP = 128, NTH = 1024;
+  double (&pold)[2][NBLK][256] = L.pold;
+  double (&pR)[NBLK][256] = L.pR;
+  double (&dsrc)[256] = L.dsrc;
+  double (&dD)[2][256] = L.dD;
+  double2 (&line)[128] = L.line;
+  double (&sc)[KP] = L.sc;
+  double (&sdiag)[KP] = L.sdiag;
+  int& dflag = L.dflag;
+  double (&pivmin)[NBLK] = L.pivmin;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, cc = lane & 15;
+  // this wave's tiles.  Waves 0 .. 7: the diagonal tile (wv, wv) and nothing else -- wave j forms R_j, wave p + 1 brings its tile
+  // up to date first and hands it over, wave p inverts it, all of that while waves 8 .. 15 run the step's updates: they own the
+  // 28 tiles above the diagonal (numbered row by row), wave 8 + u the numbers u, u + 8, u + 16 and, u < 4, u + 24 -- 7 tiles on
+  // the two of them that share a SIMD.  Scalars, no arrays: every index below is wave-uniform.
+  auto tile_off = [](int o, int& i, int& j) {
+    i = 0;
+    while (i < 6 && o >= 7 - i) { o -= 7 - i; ++i; }
+    j = i + 1 + o;
+  };
+  const bool diag_wave = wv < 8;
+  const int u = wv - 8;
+  int i0 = wv, j0 = wv, i1 = 0, j1 = 0, i2 = 0, j2 = 0, i3 = 0, j3 = 0;
+  if (!diag_wave) { tile_off(u, i0, j0); tile_off(u + 8, i1, j1); tile_off(u + 16, i2, j2); }
+  const bool has1 = !diag_wave, has3 = !diag_wave && u < 4;
+  if (has3) tile_off(u + 24, i3, j3);
+  for (int i = tid; i < KP; i += NTH) sdiag[i] = i < k ? Gd[(int64_t)i * ld + i] : 0.0;
+  if (tid == 0) dflag = 0;
+  __syncthreads();
+  double dead_below = -1.0;
+  if (Gpatched != nullptr) {
+    double dm = 0.0;
+    for (int i = 0; i < k; ++i) dm = fmax(dm, sdiag[i]);
+    dead_below = 1e-12 * dm;
+  }
+  for (int i = tid; i < KP; i += NTH) {
+    const bool live = i < k && (Gpatched == nullptr || sdiag[i] > dead_below);
+    const double gii = live ? sdiag[i] : 1.0;
+    double y = 1.0;
+    if (gii > 0.0) {
+      y = __builtin_amdgcn_rsq(gii);
+      y = y * fma(-(0.5 * gii) * y, y, 1.5);
+    }
+    sc[i] = y;
+  }
+  __syncthreads();
+  auto fetch = [&](int ti, int tj) -> f64x4 {
+    f64x4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ti + g + 4 * r, col = 16 * tj + cc;
+      const bool live = row < k && col < k && (Gpatched == nullptr || (sdiag[row] > dead_below && sdiag[col] > dead_below));
+      const double gv = live ? Gd[(int64_t)row * ld + col] : (row == col ? 1.0 : 0.0);
+      if (Gpatched != nullptr && row < ld && col < ld) {
+        Gpatched[(int64_t)row * ld + col] = gv;
+        if (ti != tj) Gpatched[(int64_t)col * ld + row] = gv;
+      }
+      c[r] = live ? gv * sc[row] * sc[col] : gv;
+    }
+    return c;
+  };
+  f64x4 c0 = fetch(i0, j0), c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0}, c3 = {0.0, 0.0, 0.0, 0.0};
+  if (has1) { c1 = fetch(i1, j1); c2 = fetch(i2, j2); }
+  if (has3) c3 = fetch(i3, j3);
+  const int nsteps = (k + 15) / 16;
+
+  auto store_tile = [&](double* dstp, const f64x4& v) {
+    reinterpret_cast<double2*>(dstp)[lane] = double2{v[0], v[1]};
+    reinterpret_cast<double2*>(dstp + 128)[lane] = double2{v[2], v[3]};
+  };
+  auto load_tile = [&](const double* srcp) {
+    const double2 lo = reinterpret_cast<const double2*>(srcp)[lane];
+    const double2 hi = reinterpret_cast<const double2*>(srcp + 128)[lane];
+    return f64x4{lo.x, lo.y, hi.x, hi.y};
+  };
+  // -(tile)^T in store_tile()'s layout: this lane's element (row, col) = (g + 4 r, cc) of the tile is element (cc, g + 4 r) there
+  auto store_neg_transposed = [&](double* dstp, const f64x4& v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dstp[tile_lds_index(cc, g + 4 * r)] = -v[r];
+  };
+  // a tile's part in the next step's row panel (la): on / right of the diagonal as it is, left of it -(tile (i, la))^T, i < la
+  auto publish = [&](int ti, int tj, const f64x4& c, int la) {
+    if (ti == la) store_tile(pold[la & 1][tj], c);
+    else if (tj == la) store_neg_transposed(pold[la & 1][ti], c);
+  };
+
+  if (wv == 0) {                               // D of step 0
+    store_tile(dsrc, c0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const double pm = inv16_wave<true>(dsrc, dD[0], line, lane);
+    if (lane == 0) pivmin[0] = pm;
+  }
+  publish(i0, j0, c0, 0);                      // row panel 0: all of it is on or above the diagonal
+  if (has1) { publish(i1, j1, c1, 0); publish(i2, j2, c2, 0); }
+  if (has3) publish(i3, j3, c3, 0);
+
+  for (int p = 0; p < nsteps; ++p) {
+    __syncthreads();                           // pold[p & 1] and dD[p & 1] are in place
+    INV_STAMP(p, 0);
+    const int la = p + 1;
+    if (wv < NBLK && wv != p) {                // R_j = D A_pj for j = wv (D is symmetric: its C layout is its A layout)
+      const f64x4 D = load_tile(dD[p & 1]);
+      const bool la_wave = la < nsteps && wv == la;
+      if (la_wave) __builtin_amdgcn_s_setprio(3);
+      const f64x4 apj = load_tile(pold[p & 1][wv]);
+      f64x4 rj = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) rj = mfma_f64(D[s], apj[s], rj);
+      if (la_wave) {                           // A_ll - A_lp R_l, A_lp = (A_pl)^T: the same tile once more, as A operand
+        f64x4 acc = c0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma_f64(-apj[s], rj[s], acc);
+        c0 = acc;
+        store_tile(dsrc, acc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&dflag, la, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      store_tile(pR[wv], rj);
+    }
+    INV_STAMP(p, 1);
+    __syncthreads();                           // R_j are in place
+    INV_STAMP(p, 2);
+    if (wv == p && la < nsteps) {              // this wave's diagonal tile only becomes D in this step: it inverts the look-ahead tile
+      while (__hip_atomic_load(&dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != la) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_setprio(3);
+      const double pm = inv16_wave<true>(dsrc, dD[la & 1], line, lane);
+      __builtin_amdgcn_s_setprio(0);
+      if (lane == 0) pivmin[la] = pm;
+    }
+    // One tile's step.  Row p: D on the diagonal, R_j right of it (loads only).  The look-ahead tile: up to date already.
+    // Column p above the diagonal: -A_ip D.  Everything else: A_ij - A_ip R_j.  The A operand is (A_pi)^T with the sign of
+    // i's state -- row panel tile (p, i) as it lies in LDS --, the B operand D resp. R_j; both are read here, behind the
+    // inversion (held across it they cost the kernel its 128-register budget; so do two or four tiles side by side -- 152 /
+    // 212 B of scratch and 34.5 / 36.5 us where this form takes 30.2).
+    auto step_tile = [&](int ti, int tj, f64x4& c) {
+      if (ti == p) { c = load_tile(tj == p ? dD[p & 1] : pR[tj]); return; }
+      if (ti == la && tj == la && la < nsteps) return;
+      f64x4 a = load_tile(pold[p & 1][ti]);
+      const f64x4 b = load_tile(tj == p ? dD[p & 1] : pR[tj]);
+      const double msig = (ti < p) ? 1.0 : -1.0;                   // -sigma_i
+      f64x4 acc = c;
+      if (tj == p) acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma_f64(a[s] * msig, b[s], acc);
+      c = acc;
+    };
+    step_tile(i0, j0, c0);
+    if (has1) { step_tile(i1, j1, c1); step_tile(i2, j2, c2); }
+    if (has3) step_tile(i3, j3, c3);
+    if (la < nsteps) {                         // row panel of the next step
+      publish(i0, j0, c0, la);
+      if (has1) { publish(i1, j1, c1, la); publish(i2, j2, c2, la); }
+      if (has3) publish(i3, j3, c3, la);
+    }
+    INV_STAMP(p, 3);
+  }
+  bool bad = false;
+  int z = 0;
+  asm volatile("" : "+v"(z));                  // (an opaque zero: the output addresses are formed here, not held across the loop -- 8 B of scratch)
+  auto put = [&](int ti, int tj, const f64x4& c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ti + g + 4 * r + z, col = 16 * tj + cc + z;
+      const double v = (row < k && col < k) ? c[r] * sc[row] * sc[col] : (row == col ? 1.0 : 0.0);
+      bad |= !(fabs(v) <= 1.7e308);
+      if (row < ld && col < ld) {
+        Ginv64[(int64_t)row * ld + col] = v;
+        if (ti != tj) Ginv64[(int64_t)col * ld + row] = v;
+      }
+    }
+  };
+  put(i0, j0, c0);
+  if (has1) { put(i1, j1, c1); put(i2, j2, c2); }
+  if (has3) put(i3, j3, c3);
+  if (singular != nullptr && __ballot(bad) != 0ull && lane == 0) *singular = 1;
+  if (spd_flag != nullptr && tid == 0) {
+    double pm = 1.0e300;
+    for (int q = 0; q < nsteps; ++q) pm = fmin(pm, pivmin[q]);
+    *spd_flag = (pm > 1e-8) ? 1 : 0;
+  }
+}
+
+#ifndef PMF_INV_SYM8
+#define PMF_INV_SYM8 1
+#endif
 template <int NBLK>
 __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(const double* __restrict__ Gd, int ld, int k,
                                                                              double* __restrict__ Ginv64,
@@ -363,7 +571,8 @@ __global__ __launch_bounds__(64 * NBLK * (NBLK / 4)) void k_inverse_spd_mfma(con
                                                                              double* __restrict__ Gpatched = nullptr) {
   if (stop != nullptr && *stop != 0) return;   // free-running loop behind a converged iteration: keep the inverse
   __shared__ InvLds<NBLK> L;
-  inverse_spd_mfma_body<NBLK>(L, Gd, ld, k, Ginv64, singular, spd_flag, Gpatched);
+  if constexpr (NBLK == 8 && PMF_INV_SYM8 != 0) inverse_spd_sym8_body(L, Gd, ld, k, Ginv64, singular, spd_flag, Gpatched);
+  else inverse_spd_mfma_body<NBLK>(L, Gd, ld, k, Ginv64, singular, spd_flag, Gpatched);
 }
 
 // ---- the k x n sized float64 products of the SNMF W step / Gram-space loop on the float64 MFMA -------
